@@ -1,0 +1,232 @@
+/*
+ * usseg.h - C ABI of libusseg_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * ResNeSt/UNet segmentation hot path of silverlight6/Ultrasound_Modeling.
+ *
+ * The reference (TensorFlow/Keras) has no FFI or operator boundary of its own: every
+ * kernel it runs is implicit inside tf.keras.layers.*.  Each entry point below therefore cites the
+ * reference call sites whose implicit framework kernel it replaces (paths relative to the reference
+ * repo root).  INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Contract (all functions)
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *  - the caller owns every buffer, including workspaces; the library allocates nothing, keeps no
+ *    global mutable state except a thread-local error string, never synchronises and never throws;
+ *  - all work is enqueued on the hipStream_t passed in (graph-capture safe);
+ *  - return value: 0 on success, negative UssegStatus on error (usseg_last_error() has the text).
+ *
+ * Data layout
+ *  - activations: NHWC, bf16, channel stride `ld` (elements) >= C; C and ld are multiples of 8 and
+ *    the base pointer is 16-byte aligned, so a pixel's channels can be read 8 at a time.  Channels
+ *    beyond the layer's logical width are kept exactly zero by every kernel ("pad channels").
+ *  - packed conv operand ("Wp"): bf16 matrix [Nrows][Kw], Nrows = roundup(N,16), K index =
+ *    tap*Cin + c  (Cin = physical input channels of the op), row stride Kw = ntaps*Cin.
+ *    Built from the fp32 Keras-layout master weights by usseg_pack_weight().
+ *  - per-channel vectors (bias, gamma, beta, ...) are fp32, padded with zeros to the physical width.
+ */
+#ifndef USSEG_H
+#define USSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* usseg_stream_t; /* a hipStream_t */
+
+typedef enum UssegStatus {
+  USSEG_OK = 0,
+  USSEG_ERR_BAD_ARG = -1,
+  USSEG_ERR_UNSUPPORTED = -2,
+  USSEG_ERR_LAUNCH = -3
+} UssegStatus;
+
+typedef enum UssegAct { USSEG_ACT_NONE = 0, USSEG_ACT_LRELU = 1, USSEG_ACT_RELU = 2, USSEG_ACT_ELU = 3 } UssegAct;
+
+enum {
+  USSEG_OUT_F32 = 1,   /* y is float* (ldy counted in floats); default bf16 */
+  USSEG_ACCUMULATE = 2 /* y += result (residual pointer == y is also allowed) */
+};
+
+/* Geometry of one Conv2D (stride 1, SAME, dilation d) or Conv2DTranspose (stride 2, SAME). */
+typedef struct UssegConvDesc {
+  int32_t B, H, W;     /* batch and INPUT spatial size of the forward op (tconv output is 2H x 2W) */
+  int32_t Cin, Cout;   /* physical channel counts (multiples of 8) of the forward input / output */
+  int32_t ldx, ldy;    /* channel strides (elements) of the forward input / output buffers */
+  int32_t ksize;       /* conv: 1 or 3; tconv: 3 or 4 */
+  int32_t dilation;    /* conv only */
+  int32_t act;         /* UssegAct fused into the forward epilogue */
+  float alpha;         /* LeakyReLU / ELU alpha */
+  int32_t flags;       /* USSEG_OUT_F32 | USSEG_ACCUMULATE */
+} UssegConvDesc;
+
+const char* usseg_last_error(void);
+int usseg_version(void);
+
+/* ---- convolution: Conv2D 3x3 / dilated 3x3 / 1x1, stride 1, SAME -------------------------------
+ * replaces tf.keras.layers.Conv2D at ResNest.py:14,17,21,77,82,122,128,160,166; Decoder.py:11-25,
+ * 36-50,103; VisionTransformer.py:106; TBI_ResNest.py:83,85,88,140,143,162,167,189,195.
+ * y = act(conv(x, Wp) + bias) (+ residual).  bias may be NULL; residual (bf16, stride ldr) may be NULL. */
+int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const void* wp_fwd, const float* bias,
+                     const void* residual, int32_t ldr, void* y, usseg_stream_t stream);
+/* dx = conv_transpose(dy, W) (+ residual): the backward-data of the op above.  wp_dgrad is the operand
+ * packed with in/out swapped (K index = tap*Cout + co).  dx has d->Cin channels, stride d->ldx. */
+int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp_dgrad, const void* residual,
+                       int32_t ldr, void* dx, usseg_stream_t stream);
+/* dW[tap][ci][co] += sum_pixels x * dy  (fp32 atomics into a zeroed [ntaps][Cin][Cout] scratch). */
+int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw_scratch,
+                       usseg_stream_t stream);
+
+/* ---- transposed convolution: Conv2DTranspose 3x3 s2 (Decoder.py:57,120) and 4x4 s2 (TBI_ResNest.py:124,210),
+ * padding 'same' (k=3: out[2i+k] += x[i] w[k], last row/col cropped; k=4: out[2i+k-1]).  Four parity-class
+ * implicit GEMMs, no zero insertion. */
+int usseg_tconv2d_fwd(const UssegConvDesc* d, const void* x, const void* wp_fwd, const float* bias, void* y,
+                      usseg_stream_t stream);
+int usseg_tconv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp_dgrad, const void* residual,
+                        int32_t ldr, void* dx, usseg_stream_t stream);
+int usseg_tconv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw_scratch,
+                        usseg_stream_t stream);
+
+/* ---- operand packing -------------------------------------------------------------------------
+ * dst[(n_off+n)*Kw + tap*tap_stride + k_off + k] = bf16(src[tap*sT + n*sN + k*sK]),  n<Nn, k<Kk, tap<T.
+ * Inverse (gradient gather): dst_f32[tap*sT + n*sN + k*sK] (+)= scale * scratch[tap][k_off+k][n_off+n],
+ * scratch being the [T][Mrows][Ncols] fp32 output of a *_wgrad call. */
+int usseg_pack_weight(const float* src, int64_t sT, int64_t sN, int64_t sK, int32_t T, int32_t Nn, int32_t Kk,
+                      void* dst, int32_t Kw, int32_t tap_stride, int32_t n_off, int32_t k_off,
+                      usseg_stream_t stream);
+int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t Ncols, int32_t T, int32_t Nn, int32_t Kk,
+                       int32_t n_off, int32_t k_off, float* dst, int64_t sT, int64_t sN, int64_t sK,
+                       float scale, int32_t accumulate, usseg_stream_t stream);
+
+/* ---- normalisation + activation (bf16 rows of C channels, G groups of Cg = C/G) ---------------
+ * mode 0: LayerNormalization(axis=-1, eps) per pixel and per group (ResNest.py:86,125,132,164; Decoder.py:112)
+ * mode 1: BatchNormalization in inference mode = per-channel affine with moving statistics
+ *         (ResNest.py:19,23; Decoder.py:32-35,51-54; TBI_ResNest.py:90,144,164,169,190,213)
+ * followed by act (LeakyReLU / ReLU / ELU / none).  mult scales the activated output (Arch A dropout = 2*mask). */
+typedef struct UssegNormDesc {
+  int64_t M;          /* pixels */
+  int32_t C, Cphys;   /* logical channels, physical channels (multiple of 8; pad channels written as 0) */
+  int32_t ldx, ldy;   /* channel strides of input and output */
+  int32_t G;          /* groups (LN only), C % G == 0 */
+  int32_t mode;       /* 0 LN, 1 affine */
+  float eps;
+  int32_t act;
+  float alpha;
+} UssegNormDesc;
+int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const float* gamma, const float* beta,
+                       const float* mean, const float* var, void* y, usseg_stream_t stream);
+/* dx, and dgamma/dbeta accumulated with fp32 atomics.  x is the SAME pre-normalisation input as in fwd. */
+int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma, const float* beta,
+                       const float* mean, const float* var, void* dx, float* dgamma, float* dbeta,
+                       usseg_stream_t stream);
+/* BatchNormalization training mode statistics: per-channel sum and sum of squares (fp32 atomics). */
+int usseg_channel_stats(const void* x, int64_t M, int32_t C, int32_t ldx, float* sum, float* sumsq,
+                        usseg_stream_t stream);
+
+/* ---- plain activation (conv1 + LeakyReLU, ResNest.py:39-40; TBI_ResNest.py:83-87) ------------- */
+int usseg_act_fwd(const void* x, int64_t M, int32_t C, int32_t ldx, int32_t ldy, int32_t act, float alpha, void* y,
+                  usseg_stream_t stream);
+int usseg_act_bwd(const void* x, const void* dy, int64_t M, int32_t C, int32_t ldx, int32_t lddy, int32_t lddx,
+                  int32_t act, float alpha, void* dx, usseg_stream_t stream);
+
+/* ---- AveragePooling2D(2,2) (ResNest.py:25-28,47-53; TBI_ResNest.py:92-107) -------------------- */
+int usseg_avgpool2_fwd(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy, void* y,
+                       usseg_stream_t stream);
+/* dx = 0.25 * dy[h/2,w/2] (+ add, bf16 stride ldadd, may be NULL) */
+int usseg_avgpool2_bwd(const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t lddy, int32_t lddx,
+                       const void* add, int32_t ldadd, void* dx, usseg_stream_t stream);
+
+/* ---- channel-slice copy / accumulate: tf.concat(axis=3) and the raw reshape re-injection
+ * (ResNest.py:96; Decoder.py:66,75,87,140-141; TBI_ResNest.py:110-122,139) ---------------------- */
+int usseg_copy_channels(const void* src, int64_t M, int32_t C, int32_t lds, void* dst, int32_t ldd, int32_t accumulate,
+                        usseg_stream_t stream);
+/* fp32/fp64 NHWC host-layout input -> bf16 with the channel count padded to Cphys (ResNest.py:39 input cast) */
+int usseg_cast_input(const void* src, int32_t src_is_f64, int64_t M, int32_t C, void* dst, int32_t Cphys,
+                     usseg_stream_t stream);
+int usseg_cast_bf16_to_f32(const void* src, int64_t M, int32_t C, int32_t lds, float* dst, usseg_stream_t stream);
+
+/* ---- split attention (ResNest.py:171-199; TBI_ResNest.py:175-207) ----------------------------
+ * Tensors: y [B,HW,P*R*Cg] bf16 (P cardinal paths, R distinct radix branches, Cg=cvkk channels each).
+ * gap:    g[b][c] = sum_hw y[b,hw,c]                                  (fp32, zeroed by caller)
+ * mlp:    per (b,path): a = act(norm(dense1(mult/HW * sum_r g))) ; z_r = dense2_r(a) ; s_r = softmax_c(z_r)
+ * apply:  out[b,hw,p,c] = mult * sum_r y[b,hw,p,r,c] * s[b,p,r,c]
+ * In the reference's Arch B the R branches share weights and are identical: R=1, mult=radix. */
+typedef struct UssegSplitAttnDesc {
+  int32_t B, HW;
+  int32_t P, R, Cg, Hd;     /* paths, distinct radix branches, channels per branch, hidden = Cg/2 */
+  int32_t ldy, ldo;         /* channel strides of y and out */
+  int32_t Cy_phys, Co_phys; /* physical widths of y and out (pads written as zero in out) */
+  float mult;               /* radix multiplicity of identical branches (Arch B) or 1 (Arch A) */
+  int32_t norm_mode;        /* 0 LN (Arch B), 1 affine/BN-inference (Arch A) */
+  float eps;
+  int32_t act;              /* LeakyReLU (B) / ELU (A) */
+  float alpha;
+  int32_t use_sigmoid;      /* radix == 1 (ResNest.py:189-190) */
+} UssegSplitAttnDesc;
+/* parameter block for the tiny MLP, all fp32, per path p: w1[p][Cg][Hd], b1[p][Hd], gamma/beta/mean/var[p][Hd],
+ * w2[p][R][Hd][Cg], b2[p][R][Cg] */
+typedef struct UssegSplitAttnParams {
+  const float *w1, *b1, *gamma, *beta, *mean, *var, *w2, *b2;
+} UssegSplitAttnParams;
+typedef struct UssegSplitAttnGrads {
+  float *w1, *b1, *gamma, *beta, *w2, *b2;
+} UssegSplitAttnGrads;
+int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, float* g, usseg_stream_t stream);
+/* ws: fp32 workspace of usseg_splitattn_ws_floats(d) floats holding the saved MLP intermediates */
+int64_t usseg_splitattn_ws_floats(const UssegSplitAttnDesc* d);
+int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, float* s,
+                            float* ws, usseg_stream_t stream);
+int usseg_splitattn_apply_fwd(const UssegSplitAttnDesc* d, const void* y, const float* s, void* out,
+                              usseg_stream_t stream);
+/* backward: (1) ds[b][p][r][c] = sum_hw mult*y*dout (zeroed by caller) (2) MLP backward -> dg, param grads
+ * (3) dy = mult*s*dout + dg*mult/HW */
+int usseg_splitattn_apply_bwd_reduce(const UssegSplitAttnDesc* d, const void* y, const void* dout, int32_t lddo,
+                                     float* ds, usseg_stream_t stream);
+int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, const float* s,
+                            const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads,
+                            usseg_stream_t stream);
+int usseg_splitattn_apply_bwd_dy(const UssegSplitAttnDesc* d, const void* dout, int32_t lddo, const float* s,
+                                 const float* dg, void* dy, int32_t lddy, usseg_stream_t stream);
+
+/* ---- head softmax + loss ---------------------------------------------------------------------
+ * logits fp32 [M][ldl] (C classes) -> probs fp32 [M][C] (Decoder.py:121; TBI_ResNest.py:125).
+ * loss_kind 0: CategoricalCrossentropy(label_smoothing, reduction NONE) summed and divided by the GLOBAL batch
+ *              (VisionTransformer.py:205,225-227); *loss accumulates the scalar.
+ * loss_kind 1: my_loss_cat (TBI_ResNest.py:234-248) with precomputed per-pixel-per-class scale[HW][C];
+ *              loss_map [HW] accumulates (atomics).
+ * dlogits (bf16 [M][lddl], may be NULL) = d(sum loss)/d logits. */
+typedef struct UssegLossDesc {
+  int64_t M;            /* B*H*W pixels */
+  int32_t HW;           /* pixels per image */
+  int32_t C, ldl, lddl; /* classes, logits stride (floats), dlogits stride (bf16 elements) */
+  int32_t loss_kind;
+  float label_smoothing;
+  float clip_eps;       /* 1e-7 */
+  float inv_global_batch;
+} UssegLossDesc;
+int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, const float* y_true, const float* scale,
+                               float* probs, float* loss, void* dlogits, usseg_stream_t stream);
+/* my_loss_cat scale[hw][c] = 1/(sum_b y[b,hw,c] + 1)/(H*W)  (TBI_ResNest.py:240-241) */
+int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, int32_t C, float* scale, usseg_stream_t stream);
+
+/* ---- bias gradient: db[c] += sum_pixels dy[m][c] --------------------------------------------- */
+int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, usseg_stream_t stream);
+
+/* ---- optimiser: tf.clip_by_global_norm(1.0) + Adam (VisionTransformer.py:204,244-245; TBI_ResNest.py:28,46)
+ * sumsq: *out += sum g^2 over n floats (zeroed by caller).
+ * adam:  scale = clip_norm > 0 ? clip_norm / max(sqrt(*sumsq), clip_norm) : 1;  g' = g*scale*grad_scale;
+ *        Keras Adam with bias-corrected lr_t (host-computed from the device step counter is avoided: the caller
+ *        passes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) through a device scalar so a captured graph can be replayed). */
+int usseg_sumsq(const float* g, int64_t n, float* out, usseg_stream_t stream);
+int usseg_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
+                         const float* lr_t_dev, float beta1, float beta2, float eps, usseg_stream_t stream);
+/* device-side step counter: *step += 1; *lr_t = lr*sqrt(1-b2^step)/(1-b1^step) */
+int usseg_adam_advance(int32_t* step, float* lr_t_dev, float lr, float beta1, float beta2, usseg_stream_t stream);
+int usseg_fill_f32(float* p, int64_t n, float value, usseg_stream_t stream);
+int usseg_scale_f32(float* p, int64_t n, const float* sumsq, float clip_norm, usseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USSEG_H */

@@ -1,0 +1,352 @@
+"""Per-kernel parity tests (GPU): every C-ABI kernel against the fp64 CPU oracle on the same seeded inputs.
+
+Tolerance (stated once, used everywhere): inputs and weights are made exactly bf16-representable, the oracle runs
+in fp64 on those same values, and
+  * fp32 kernel outputs must match within REL_F32 = 1e-3 relative L2 (they land near 1e-6),
+  * bf16 kernel outputs must match the oracle ROUNDED TO bf16 within REL_BF16 = 1e-3 relative L2
+    (an exact kernel differs from the rounded oracle only where fp32 accumulation order flips a rounding).
+"""
+import math
+
+import pytest
+import torch
+
+import usseg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL_F32 = 1e-3
+REL_BF16 = 1e-3
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def rnd(gen, *shape, scale=1.0):
+    return bf(torch.randn(*shape, generator=gen, dtype=torch.float64) * scale)
+
+
+def to_dev_padded(x64, cp=None):
+    """fp64 NHWC [B,H,W,C] (bf16-representable) -> device bf16 [B,H,W,roundup(C,8)] with zero pads."""
+    B, H, W, C = x64.shape
+    cp = cp or (C + 7) // 8 * 8
+    out = torch.zeros(B, H, W, cp, dtype=torch.bfloat16)
+    out[..., :C] = x64.to(torch.bfloat16)
+    return out.to(DEV)
+
+
+def finalize(layer):
+    from ultrasound_modeling_amd.flat import FlatParams
+    return FlatParams(layer, DEV)
+
+
+@pytest.fixture(scope="module")
+def gen():
+    return torch.Generator().manual_seed(1234)
+
+
+# ------------------------------------------------------------------------------------------------ Conv2D
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, dil
+    (2, 8, 8, 8, 8, 3, 1),
+    (1, 5, 7, 1, 16, 3, 1),       # stem conv1 shape class: Cin 1 -> pad 8, ragged spatial size
+    (2, 16, 16, 16, 32, 3, 1),
+    (1, 12, 20, 32, 32, 3, 1),
+    (2, 9, 11, 30, 64, 3, 1),     # concats_2 stage 1 (Cin 30 -> pad 32)
+    (1, 16, 16, 63, 128, 3, 1),   # concats_2 stage 2, Cout > 64 -> BN=128 tile
+    (3, 7, 5, 40, 24, 1, 1),      # 1x1, odd everything
+    (1, 32, 32, 64, 16, 3, 2),    # dilated branches
+    (1, 24, 24, 128, 16, 3, 4),
+    (1, 20, 20, 72, 136, 3, 8),   # dilation larger than half the image, Cout spans two N tiles
+    (1, 1, 1, 10, 5, 1, 1),       # dense on a [B,1,1,C] tensor
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,dil", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(gen, B, H, W, Cin, Cout, k, dil):
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    layer = Conv2D(Cin, Cout, k, dil)
+    w = rnd(gen, k, k, Cin, Cout, scale=1.0 / math.sqrt(k * k * Cin))
+    b = rnd(gen, Cout, scale=0.5)
+    layer.kernel.data.copy_(w)
+    layer.bias.data.copy_(b)
+    finalize(layer)
+    x = rnd(gen, B, H, W, Cin)
+    xd = to_dev_padded(x)
+    ref = O.conv2d_same(x, w, b, dil)
+    # fp32 output
+    y32 = layer.forward(xd, out_f32=True)
+    torch.cuda.synchronize()
+    assert rel(y32[..., :Cout], ref) < REL_F32
+    # bf16 output: pad channels must be exactly zero
+    y16 = layer.forward(xd)
+    assert rel(y16[..., :Cout], bf(ref)) < REL_BF16
+    assert y16[..., Cout:].abs().max().item() == 0 if layer.cout_p > Cout else True
+    # fused LeakyReLU + residual epilogue
+    r = rnd(gen, B, H, W, Cout)
+    yr = layer.forward(xd, act=ops.ACT_LRELU, alpha=0.3, residual=to_dev_padded(r))
+    assert rel(yr[..., :Cout], bf(O.leaky_relu(ref) + r)) < REL_BF16
+    # backward: dgrad, wgrad, bias grad
+    layer.forward(xd)
+    dy = rnd(gen, B, H, W, Cout)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (O.conv2d_same(xr, wr, br, dil) * dy).sum().backward()
+    dx = layer.backward(to_dev_padded(dy))
+    torch.cuda.synchronize()
+    assert rel(dx[..., :Cin], bf(xr.grad)) < REL_BF16
+    if layer.cin_p > Cin:
+        assert dx[..., Cin:].abs().max().item() == 0
+    assert rel(layer.kernel.grad, wr.grad) < REL_F32
+    assert rel(layer.bias.grad, br.grad) < REL_F32
+    # gradients ACCUMULATE (second backward doubles them)
+    layer.backward(to_dev_padded(dy))
+    assert rel(layer.kernel.grad, 2 * wr.grad) < REL_F32
+
+
+def test_conv2d_channel_slices(gen):
+    """Producers write into / read from channel slices of concat buffers (ld > C)."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    B, H, W, Cin, Cout = 2, 10, 6, 16, 24
+    layer = Conv2D(Cin, Cout, 3, 2)
+    w, b = rnd(gen, 3, 3, Cin, Cout, scale=0.1), rnd(gen, Cout)
+    layer.kernel.data.copy_(w)
+    layer.bias.data.copy_(b)
+    finalize(layer)
+    x = rnd(gen, B, H, W, Cin)
+    xbuf = torch.full((B, H, W, 40), 7.0, dtype=torch.bfloat16, device=DEV)
+    xbuf[..., 8:24] = x.to(torch.bfloat16).to(DEV)
+    ybuf = torch.full((B, H, W, 64), -3.0, dtype=torch.bfloat16, device=DEV)
+    layer.forward(xbuf[..., 8:24], out=ybuf[..., 32:56])
+    ref = O.conv2d_same(x, w, b, 2)
+    assert rel(ybuf[..., 32:56], bf(ref)) < REL_BF16
+    assert (ybuf[..., :32] == -3.0).all() and (ybuf[..., 56:] == -3.0).all()
+    dy = rnd(gen, B, H, W, Cout)
+    dybuf = torch.zeros((B, H, W, 48), dtype=torch.bfloat16, device=DEV)
+    dybuf[..., 16:40] = dy.to(torch.bfloat16).to(DEV)
+    dxbuf = torch.ones((B, H, W, 32), dtype=torch.bfloat16, device=DEV)
+    layer.backward(dybuf[..., 16:40], dx=dxbuf[..., 8:24], accumulate_dx=True)
+    xr = x.clone().requires_grad_(True)
+    (O.conv2d_same(xr, w, b, 2) * dy).sum().backward()
+    assert rel(dxbuf[..., 8:24], bf(xr.grad + 1.0)) < 2 * REL_BF16
+    assert (dxbuf[..., :8] == 1.0).all() and (dxbuf[..., 24:] == 1.0).all()
+
+
+# ------------------------------------------------------------------------------------------------ Conv2DTranspose
+TCONV_CASES = [
+    (1, 4, 4, 8, 8, 3), (2, 5, 3, 16, 24, 3), (1, 8, 8, 72, 3, 3), (1, 16, 16, 160, 64, 3),
+    (1, 4, 4, 8, 8, 4), (2, 3, 5, 24, 16, 4), (1, 8, 8, 160, 3, 4), (1, 1, 1, 16, 8, 4),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", TCONV_CASES)
+def test_tconv2d_fwd_dgrad_wgrad(gen, B, H, W, Cin, Cout, k):
+    from ultrasound_modeling_amd.layers import Conv2DTranspose
+    layer = Conv2DTranspose(Cin, Cout, k)
+    w = rnd(gen, k, k, Cout, Cin, scale=1.0 / math.sqrt(k * k * Cin))
+    b = rnd(gen, Cout, scale=0.5)
+    layer.kernel.data.copy_(w)
+    layer.bias.data.copy_(b)
+    finalize(layer)
+    x = rnd(gen, B, H, W, Cin)
+    xd = to_dev_padded(x)
+    ref = O.conv2d_transpose_s2_same(x, w, b)
+    y32 = layer.forward(xd, out_f32=True)
+    assert rel(y32[..., :Cout], ref) < REL_F32
+    y16 = layer.forward(xd)
+    assert rel(y16[..., :Cout], bf(ref)) < REL_BF16
+    dy = rnd(gen, B, 2 * H, 2 * W, Cout)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (O.conv2d_transpose_s2_same(xr, wr, br) * dy).sum().backward()
+    dx = layer.backward(to_dev_padded(dy))
+    assert rel(dx[..., :Cin], bf(xr.grad)) < REL_BF16
+    assert rel(layer.kernel.grad, wr.grad) < REL_F32
+    assert rel(layer.bias.grad, br.grad) < REL_F32
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("B,H,W,C,G", [(2, 6, 5, 9, 3), (1, 8, 8, 30, 3), (2, 4, 4, 255, 3), (1, 9, 7, 64, 1),
+                                       (1, 3, 3, 512, 1), (2, 5, 5, 84, 3), (1, 4, 4, 8, 4), (1, 2, 2, 5, 1)])
+def test_layernorm_grouped_fwd_bwd(gen, B, H, W, C, G):
+    from ultrasound_modeling_amd import ops
+    x = rnd(gen, B, H, W, C)
+    gamma = (1 + 0.3 * torch.randn(C, generator=gen, dtype=torch.float64)).float().double()
+    beta = (0.2 * torch.randn(C, generator=gen, dtype=torch.float64)).float().double()
+    cp = (C + 7) // 8 * 8
+    pad = lambda v: torch.cat([v.float(), torch.zeros(cp - C)]).to(DEV)
+    xd = to_dev_padded(x)
+    Cg = C // G
+
+    def ref_fn(xx, g_, b_):
+        parts = [O.layer_norm(xx[..., i * Cg:(i + 1) * Cg], g_[i * Cg:(i + 1) * Cg], b_[i * Cg:(i + 1) * Cg]) for i in range(G)]
+        return O.leaky_relu(torch.cat(parts, dim=-1))
+    ref = ref_fn(x, gamma, beta)
+    y = ops.norm_act_fwd(xd, C, pad(gamma), pad(beta), torch.empty_like(xd), 0, G, 1e-3, ops.ACT_LRELU, 0.3)
+    assert rel(y[..., :C], bf(ref)) < REL_BF16
+    if cp > C:
+        assert y[..., C:].abs().max().item() == 0
+    dy = rnd(gen, B, H, W, C)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    (ref_fn(xr, gr, br) * dy).sum().backward()
+    dgam, dbet = torch.zeros(cp, device=DEV), torch.zeros(cp, device=DEV)
+    dx = ops.norm_act_bwd(xd, to_dev_padded(dy), C, pad(gamma), pad(beta), torch.empty_like(xd), dgam, dbet, 0, G, 1e-3, ops.ACT_LRELU, 0.3)
+    assert rel(dx[..., :C], bf(xr.grad)) < 2 * REL_BF16
+    assert rel(dgam[:C], gr.grad) < REL_F32
+    assert rel(dbet[:C], br.grad) < REL_F32
+
+
+@pytest.mark.parametrize("C,act", [(32, 1), (16, 1), (64, 3), (24, 2)])
+def test_batchnorm_inference_fwd_bwd(gen, C, act):
+    from ultrasound_modeling_amd import ops
+    B, H, W = 2, 7, 9
+    x = rnd(gen, B, H, W, C)
+    f = lambda t: t.float().double()
+    gamma, beta = f(1 + 0.3 * torch.randn(C, generator=gen)), f(0.2 * torch.randn(C, generator=gen))
+    mm, mv = f(0.1 * torch.randn(C, generator=gen)), f(1 + 0.5 * torch.rand(C, generator=gen))
+    actf = {1: O.leaky_relu, 2: torch.relu, 3: O.elu}[act]
+    alpha = {1: 0.3, 2: 0.0, 3: 1.0}[act]
+    d = lambda v: v.float().to(DEV)
+    xd = to_dev_padded(x)
+    ref = actf(O.batch_norm(x, gamma, beta, mm, mv, training=False))
+    y = ops.norm_act_fwd(xd, C, d(gamma), d(beta), torch.empty_like(xd), 1, 1, 1e-3, act, alpha, d(mm), d(mv))
+    assert rel(y, bf(ref)) < REL_BF16
+    dy = rnd(gen, B, H, W, C)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    (actf(O.batch_norm(xr, gr, br, mm, mv, training=False)) * dy).sum().backward()
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.norm_act_bwd(xd, to_dev_padded(dy), C, d(gamma), d(beta), torch.empty_like(xd), dgam, dbet, 1, 1, 1e-3, act, alpha, d(mm), d(mv))
+    assert rel(dx, bf(xr.grad)) < REL_BF16
+    assert rel(dgam, gr.grad) < REL_F32
+    assert rel(dbet, br.grad) < REL_F32
+
+
+# ------------------------------------------------------------------------------------------------ pooling / copies / cast
+def test_avgpool_copy_cast(gen):
+    from ultrasound_modeling_amd import ops
+    B, H, W, C = 2, 6, 10, 24
+    x = rnd(gen, B, H, W, C)
+    xd = to_dev_padded(x)
+    y = ops.avgpool2_fwd(xd, ops.new_act(B, H // 2, W // 2, C, DEV))
+    assert rel(y, bf(O.avg_pool2(x))) < REL_BF16
+    dy, add = rnd(gen, B, H // 2, W // 2, C), rnd(gen, B, H, W, C)
+    dx = ops.avgpool2_bwd(to_dev_padded(dy), ops.new_act(B, H, W, C, DEV), to_dev_padded(add))
+    ref = dy.repeat_interleave(2, 1).repeat_interleave(2, 2) * 0.25 + add
+    assert rel(dx, bf(ref)) < REL_BF16
+    # copy into a channel slice, then accumulate
+    dst = torch.zeros(B, H, W, 48, dtype=torch.bfloat16, device=DEV)
+    ops.copy_channels(xd, dst[..., 16:40])
+    assert torch.equal(dst[..., 16:40], xd) and dst[..., :16].abs().max() == 0
+    ops.copy_channels(xd, dst[..., 16:40], accumulate=True)
+    assert rel(dst[..., 16:40], bf(2 * x)) < REL_BF16
+    # raw row-major reshape re-injection (Decoder.py:140): [B,N,hidden] -> [B,2gh,2gw,hidden/4]
+    hid = rnd(gen, 2, 4 * 3, 64)
+    hd = hid.to(torch.bfloat16).to(DEV)
+    cat = torch.zeros(2, 8, 6, 24, dtype=torch.bfloat16, device=DEV)
+    ops.copy_channels(hd.reshape(2, 8, 6, 16), cat[..., 8:])
+    assert torch.equal(cat[..., 8:].cpu().double(), hid.reshape(2, 8, 6, 16))
+    # input cast fp64 / fp32 -> bf16 with channel padding
+    xin = torch.randn(2, 5, 7, 3, generator=gen, dtype=torch.float64)
+    for t in (xin, xin.float()):
+        c = ops.cast_input(t.to(DEV), 8)
+        assert torch.equal(c[..., :3].cpu(), t.to(torch.bfloat16)) and c[..., 3:].abs().max() == 0
+    assert torch.equal(ops.to_f32(c, 3).cpu(), c[..., :3].float().cpu())
+
+
+# ------------------------------------------------------------------------------------------------ split attention
+@pytest.mark.parametrize("B,H,W,P,Cg,radix", [(2, 6, 6, 3, 10, 3), (1, 4, 8, 3, 21, 3), (2, 4, 4, 4, 8, 4), (2, 3, 5, 3, 85, 3),
+                                              (1, 4, 4, 2, 6, 1)])
+def test_split_attention_shared_branches(gen, B, H, W, P, Cg, radix):
+    """Arch B form (ResNest.py:171-199 with identical radix branches): out = radix*y*softmax_c(dense2(...)), fwd + bwd."""
+    from ultrasound_modeling_amd import ops
+    Hd = Cg // 2
+    V = P * Cg
+    Vp = (V + 7) // 8 * 8
+    y = rnd(gen, B, H, W, V)
+    f = lambda *s, sc=1.0: (torch.randn(*s, generator=gen, dtype=torch.float64) * sc).float().double()
+    w1, b1 = f(P, Cg, Hd, sc=1 / math.sqrt(Cg)), f(P, Hd, sc=0.1)
+    ga, be = 1 + f(P, Hd, sc=0.2), f(P, Hd, sc=0.1)
+    w2, b2 = f(P, Hd, Cg, sc=1 / math.sqrt(Hd)), f(P, Cg, sc=0.1)
+    dout = rnd(gen, B, H, W, V)
+
+    def ref_fn(yy, w1_, b1_, ga_, be_, w2_, b2_):
+        outs = []
+        for p in range(P):
+            Pd = {"dense1.kernel": w1_[p].reshape(1, 1, Cg, Hd), "dense1.bias": b1_[p], "dense1_bn.gamma": ga_[p], "dense1_bn.beta": be_[p],
+                  "dense2.kernel": w2_[p].reshape(1, 1, Hd, Cg), "dense2.bias": b2_[p]}
+            yp = yy[..., p * Cg:(p + 1) * Cg]
+            outs.append(O.split_attention([yp] * radix, Pd, "", radix))
+        return torch.cat(outs, dim=-1)
+    leaves = [t.clone().requires_grad_(True) for t in (y, w1, b1, ga, be, w2, b2)]
+    ref = ref_fn(*leaves)
+    (ref * dout).sum().backward()
+
+    dev = lambda t: t.float().contiguous().to(DEV)
+    params = (dev(w1), dev(b1), dev(ga), dev(be), None, None, dev(w2), dev(b2))
+    yd = to_dev_padded(y)
+    d = ops.splitattn_desc(B, H * W, P, 1, Cg, Hd, Vp, Vp, Vp, Vp, float(radix), 0, 1e-3, ops.ACT_LRELU, 0.3, radix == 1)
+    out, g, s, ws = ops.splitattn_fwd(d, yd, params, ops.new_act(B, H, W, Vp, DEV))
+    assert rel(out[..., :V], bf(ref)) < REL_BF16
+    grads = tuple(torch.zeros_like(t) for t in (params[0], params[1], params[2], params[3], params[6], params[7]))
+    dy = ops.splitattn_bwd(d, yd, to_dev_padded(dout), params, grads, g, s, ws, torch.empty_like(yd))
+    assert rel(dy[..., :V], bf(leaves[0].grad)) < 2 * REL_BF16
+    for got, want in zip(grads, (leaves[1].grad, leaves[2].grad, leaves[3].grad, leaves[4].grad, leaves[5].grad, leaves[6].grad)):
+        assert rel(got, want) < 2e-3, (got.shape,)
+
+
+# ------------------------------------------------------------------------------------------------ loss / optimiser
+def test_softmax_cce_loss_fwd_bwd(gen):
+    from ultrasound_modeling_amd import ops
+    B, H, W, C = 2, 9, 11, 3
+    logits = torch.randn(B, H, W, C, generator=gen, dtype=torch.float64).float().double() * 3
+    logits[0, 0, 0] = torch.tensor([40.0, -40.0, 0.0])   # forces the 1e-7 clip branch
+    x_, y = O.synthetic_batch(B, 16, 16, 1, seed=3)
+    y = y[:, :H, :W].float().double()
+    lr = logits.clone().requires_grad_(True)
+    probs_ref = O.softmax_lastaxis(lr)
+    loss_ref = O.compute_loss(y, probs_ref, global_batch_size=4)
+    loss_ref.backward()
+    lg = torch.zeros(B, H, W, 4)
+    lg[..., :3] = logits.float()
+    lg = lg.to(DEV)
+    probs = torch.empty(B, H, W, C, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    dl = ops.new_act(B, H, W, 8, DEV)
+    ops.softmax_loss(lg, y.float().to(DEV), probs, loss, dl, HW=H * W, C_classes=C, inv_global_batch=0.25)
+    assert rel(probs, probs_ref.detach()) < 1e-5
+    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 1e-5
+    assert rel(dl[..., :3], bf(lr.grad)) < REL_BF16
+    assert dl[..., 3:].abs().max().item() == 0
+
+
+def test_clip_adam_matches_oracle(gen):
+    from ultrasound_modeling_amd import ops
+    n = 10007
+    p = torch.randn(n, generator=gen, dtype=torch.float64).float()
+    pad = (n + 7) // 8 * 8
+    P, G = torch.zeros(pad), torch.zeros(pad)
+    P[:n] = p
+    pd, gd, m, v = P.to(DEV), G.to(DEV), torch.zeros(pad, device=DEV), torch.zeros(pad, device=DEV)
+    step, lr_t, ss = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    po = [p.double().clone()]
+    mo, vo = [torch.zeros(n, dtype=torch.float64)], [torch.zeros(n, dtype=torch.float64)]
+    for it in range(1, 4):
+        g = torch.randn(n, generator=gen, dtype=torch.float64).float() * (5.0 if it != 2 else 1e-3)   # clipped / not clipped
+        gd[:n] = g.to(DEV)
+        ops.fill_f32(ss, 0.0)
+        ops.sumsq(gd, ss)
+        assert abs(ss.item() - (g.double() ** 2).sum().item()) / (g.double() ** 2).sum().item() < 1e-5
+        ops.adam_advance(step, lr_t, 1e-3, 0.9, 0.999)
+        ops.adam_clip_step(pd, gd, m, v, ss, 1.0, lr_t, 0.9, 0.999, 1e-7)
+        clipped, _ = O.clip_by_global_norm([g.double()])
+        O.adam_step(po, clipped, mo, vo, it, 1e-3)
+        assert rel(pd[:n], po[0]) < 1e-6
+    assert step.item() == 3

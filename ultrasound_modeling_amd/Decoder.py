@@ -1,0 +1,174 @@
+"""UNet-style decoder: the module surface of the reference's ``Decoder.py`` (DecoderBlock, DecoderCup).
+
+Same class names, constructor arguments, attribute names and call signatures as ``Decoder.py:7-146`` of
+silverlight6/Ultrasound_Modeling, on hand-written gfx950 kernels.  Concatenations never copy more than they
+must: every producer writes straight into its channel slice of the concat buffer (``tf.concat(axis=3)`` at
+Decoder.py:66,75,87,141); only tensors that already exist elsewhere (skip features, the re-injected hidden
+state) are copied in.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import (KERAS_LRELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, LayerNormalization,
+                     LeakyReLU)
+from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
+
+
+class DecoderBlock(nn.Module):
+    """Decoder.py:7-94: tconv3x3s2 -> concat skip -> 4 parallel convs (1x1, 3x3 d2/d4/d8)+BN -> LeakyReLU, twice."""
+
+    def __init__(self, out_channels, wDecay=None, in_channels=None, skip_channels=None):
+        super().__init__()
+        self.wDecay = wDecay
+        oc = out_channels
+        self.out_channels = oc
+        self.in_channels = in_channels if in_channels is not None else oc
+        self.skip_channels = oc if skip_channels is None else skip_channels
+        c1 = oc + self.skip_channels
+        dil = (1, 2, 4, 8)
+        for j in range(4):                                                            # :11-25
+            setattr(self, f"conv1_{j}", Conv2D(c1, oc // 4, 1 if j == 0 else 3, dil[j]))
+        self.pool = AveragePooling2D()                                                # dead in the reference (:26)
+        self.LeakyReLU1 = LeakyReLU()
+        for j in range(4):                                                            # :32-35
+            setattr(self, f"bn1_{j}", BatchNormalization(oc // 4))
+        for j in range(4):                                                            # :36-50
+            setattr(self, f"conv2_{j}", Conv2D(oc, oc // 4, 1 if j == 0 else 3, dil[j]))
+        for j in range(4):                                                            # :51-54
+            setattr(self, f"bn2_{j}", BatchNormalization(oc // 4))
+        self.up = Conv2DTranspose(self.in_channels, oc, 3)                            # :57
+
+    def forward(self, x, skip=None, out=None):
+        """x [B,h,w,in]; skip [B,2h,2w,skip] or None; ``out``: optional [B,2h,2w,oc] slice to write the result into."""
+        B, H, W, _, _ = ops.geom(x)
+        dev = x.device
+        oc, q = self.out_channels, self.out_channels // 4
+        a = KERAS_LRELU_ALPHA
+        has_skip = skip is not None
+        c1 = oc + (self.skip_channels if has_skip else 0)
+        assert has_skip or self.skip_channels == 0, "block was built for a skip connection"
+        cat = ops.new_act(B, 2 * H, 2 * W, c1, dev)
+        self.up.forward(x, out=cat[..., :oc])                                         # :63
+        if has_skip:
+            ops.copy_channels(skip, cat[..., oc:])                                    # :66
+        raw1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
+        act1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
+        for j in range(4):                                                            # :67-76
+            sl = slice(j * q, (j + 1) * q)
+            getattr(self, f"conv1_{j}").forward(cat, out=raw1[..., sl])
+            getattr(self, f"bn1_{j}").forward(raw1[..., sl], ACT_LRELU, a, out=act1[..., sl])
+        raw2 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
+        out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, oc, dev)
+        for j in range(4):                                                            # :79-88
+            sl = slice(j * q, (j + 1) * q)
+            getattr(self, f"conv2_{j}").forward(act1, out=raw2[..., sl])
+            getattr(self, f"bn2_{j}").forward(raw2[..., sl], ACT_LRELU, a, out=out[..., sl])
+        self._has_skip = has_skip
+        return out
+
+    def backward(self, dout):
+        """dout [B,2h,2w,oc] (may be a channel slice) -> (dx, dskip)."""
+        oc, q = self.out_channels, self.out_channels // 4
+        B, H2, W2, _, _ = ops.geom(dout)
+        dev = dout.device
+        draw2 = ops.new_act(B, H2, W2, oc, dev)
+        for j in range(4):
+            sl = slice(j * q, (j + 1) * q)
+            getattr(self, f"bn2_{j}").backward(dout[..., sl], dx=draw2[..., sl])
+        dact1 = ops.new_act(B, H2, W2, oc, dev)
+        for j in range(4):
+            sl = slice(j * q, (j + 1) * q)
+            getattr(self, f"conv2_{j}").backward(draw2[..., sl], dx=dact1, accumulate_dx=(j > 0))
+        draw1 = ops.new_act(B, H2, W2, oc, dev)
+        for j in range(4):
+            sl = slice(j * q, (j + 1) * q)
+            getattr(self, f"bn1_{j}").backward(dact1[..., sl], dx=draw1[..., sl])
+        c1 = oc + (self.skip_channels if self._has_skip else 0)
+        dcat = ops.new_act(B, H2, W2, c1, dev)
+        for j in range(4):
+            sl = slice(j * q, (j + 1) * q)
+            getattr(self, f"conv1_{j}").backward(draw1[..., sl], dx=dcat, accumulate_dx=(j > 0))
+        dx = self.up.backward(dcat[..., :oc])
+        dskip = dcat[..., oc:] if self._has_skip else None
+        return dx, dskip
+
+    def __call__(self, x, skip=None, *args, **kwargs):
+        return self.forward(x, skip)
+
+
+class DecoderCup(nn.Module):
+    """Decoder.py:98-146.  ``forward(hidden_states [B,N,hidden], features)`` -> class probabilities [B,H,W,classes] (fp32).
+
+    The literal 16x5 grid of Decoder.py:128,140 is generalised to ``grid=(H/16, W/16)``; with
+    H=256, W=80 it reproduces the reference's reshapes exactly.
+    """
+
+    def __init__(self, num_classes, wDecay=None, hidden_size=512, grid=(16, 5)):
+        super().__init__()
+        head_channels = 256
+        self.wDecay, self.num_classes, self.hidden_size, self.grid = wDecay, num_classes, hidden_size, tuple(grid)
+        self.conv_more = Conv2D(hidden_size, head_channels, 3)                        # :103
+        self.LeakyReLU1 = LeakyReLU()
+        self.bn1 = LayerNormalization(head_channels)                                  # :112
+        skip_channels = [256, 128, 64]
+        blocks, cin = [], head_channels
+        for i, sk in enumerate(skip_channels):                                        # :114-117
+            blocks.append(DecoderBlock(sk, wDecay, in_channels=cin))
+            cin = sk + hidden_size // (4 ** (i + 1))
+        self.blocks = nn.ModuleList(blocks)
+        self.head = Conv2DTranspose(cin, num_classes, 3)                              # :120 (softmax fused downstream)
+
+    def forward(self, hidden_states, features: Optional[List[torch.Tensor]] = None, return_logits=False):
+        assert features is not None, "this implementation is built for the skip-connected configuration the drivers use"
+        B = hidden_states.shape[0]
+        gh, gw = self.grid
+        hs = self.hidden_size
+        dev = hidden_states.device
+        y = hidden_states.reshape(B, gh, gw, hs)                                      # :128 (a view: same memory)
+        self._hidden_shape = hidden_states.shape
+        x = self.conv_more.forward(y)                                                 # :129
+        x = self.bn1.forward(x, ACT_LRELU, KERAS_LRELU_ALPHA)                         # :130-131
+        for i, blk in enumerate(self.blocks):                                         # :132
+            s = 2 ** (i + 1)
+            c0 = hs // (4 ** (i + 1))
+            cat = ops.new_act(B, gh * s, gw * s, blk.out_channels + c0, dev)
+            blk.forward(x, features[i], out=cat[..., :blk.out_channels])              # :137
+            x0 = y.reshape(B, gh * s, gw * s, c0)                                     # :140 raw row-major reinterpretation
+            ops.copy_channels(x0, cat[..., blk.out_channels:])                        # :141
+            x = cat
+        logits = self.head.forward(x, out_f32=True)                                   # :142 (fp32, stride 4)
+        self._logits = logits
+        if return_logits:
+            return logits
+        probs = torch.empty((B, logits.shape[1], logits.shape[2], self.num_classes), dtype=torch.float32, device=dev)
+        ops.softmax_loss(logits, None, probs, None, None, HW=logits.shape[1] * logits.shape[2], C_classes=self.num_classes)   # :121
+        return probs
+
+    def backward(self, dlogits):
+        """dlogits: bf16 [B,H,W,8] gradient w.r.t. the head's pre-softmax output -> (d_hidden [B,N,hidden], [d_x3,d_x2,d_x1])."""
+        B = dlogits.shape[0]
+        gh, gw = self.grid
+        hs = self.hidden_size
+        dev = dlogits.device
+        d = self.head.backward(dlogits)
+        d_hidden = ops.new_act(B, gh, gw, hs, dev)
+        dfeats = [None, None, None]
+        first = True
+        for i in reversed(range(3)):
+            blk = self.blocks[i]
+            s = 2 ** (i + 1)
+            c0 = hs // (4 ** (i + 1))
+            ops.copy_channels(d[..., blk.out_channels:], d_hidden.reshape(B, gh * s, gw * s, c0), accumulate=not first)
+            first = False
+            d, dfeats[i] = blk.backward(d[..., :blk.out_channels])
+        d = self.bn1.backward(d)
+        self.conv_more.backward(d, dx=d_hidden, accumulate_dx=True)
+        return d_hidden.reshape(self._hidden_shape), dfeats
+
+    def __call__(self, hidden_states, features=None, *args, **kwargs):
+        return self.forward(hidden_states, features)

@@ -1,0 +1,323 @@
+"""ResNeSt-style split-attention encoder: the module surface of the reference's ``ResNest.py``.
+
+Same class names, constructor arguments, attribute names, NHWC layout and return structure as
+``ResNest.py:4-203`` of silverlight6/Ultrasound_Modeling, on hand-written gfx950 kernels.
+
+How a ``residual_S`` stage is executed (ResNest.py:89-104):
+  * the ``kpaths`` cardinal blocks read the same input, so their 1x1 convs are ONE GEMM with
+    N = kpaths*cv11 output channels and their 3x3 convs are ONE grouped conv (groups = kpaths),
+    issued as a block-diagonal implicit GEMM inside the MFMA tile (group widths 3..85 are below the
+    MFMA K granule, so a per-group launch could not fill a tile);
+  * LayerNormalization runs per pixel and per group;
+  * the reference applies the SAME layers ``radix`` times to the same input (ResNest.py:138-145), so the
+    radix branches are identical tensors: the branch is computed once and the split attention becomes
+    out = radix * y * softmax_c(dense2(...)) - bit-for-bit the same function and the same
+    gradients (they flow ``radix`` times into the shared weights, which the factor reproduces);
+  * concats_2 (3x3) adds the shortcut branch in its epilogue.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import (KERAS_LN_EPS, KERAS_LRELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, LayerNormalization,
+                     LeakyReLU, _Workspace)
+from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
+
+
+def _span(t: torch.Tensor, n: int) -> torch.Tensor:
+    """1-D fp32 view of n floats starting at t's first element (reaches into the following flat-buffer entries)."""
+    return torch.as_strided(t, (n,), (1,))
+
+
+class split_attention(nn.Module):
+    """ResNest.py:153-199.  Holds dense1 / dense1_bn / dense2; executed by the owning cardinal group."""
+
+    def __init__(self, inchannel, radix, atrous=1, wDecay=None):
+        super().__init__()
+        self.inchannel, self.radix, self.atrous, self.wDecay = inchannel, radix, atrous, wDecay
+        self.dense1 = Conv2D(inchannel, inchannel // 2, 1)
+        self.dense1_bn = LayerNormalization(inchannel // 2)
+        self.dense1_act = LeakyReLU()
+        self.dense2 = Conv2D(inchannel // 2, inchannel, 1)
+        for c in (self.dense1, self.dense2):
+            c.on_finalize = lambda device: None   # 1x1 on [B,1,1,C]: runs inside the split-attention MLP kernel (fp32)
+
+    def forward(self, inputs: List[torch.Tensor]):
+        """Standalone call with a LIST of ``radix`` NHWC tensors (ResNest.py:171).  Uses the general R=len(inputs)
+        kernel path; inside ``residual_S`` the identical-branch shortcut is used instead."""
+        R = len(inputs)
+        B, H, W, Cp, _ = ops.geom(inputs[0])
+        Cg = self.inchannel
+        dev = inputs[0].device
+        ycat = ops.new_act(B, H, W, roundup(R * Cg, 8), dev, zero=True)
+        # channel layout (r, c): not 8-aligned in general, so assemble through fp32 (standalone path only)
+        stack = torch.cat([ops.to_f32(t, Cg) for t in inputs], dim=3)
+        ycat[..., :R * Cg] = stack.to(BF16)
+        out = ops.new_act(B, H, W, roundup(Cg, 8), dev)
+        d = ops.splitattn_desc(B, H * W, 1, R, Cg, Cg // 2, ycat.shape[3], out.shape[3], ycat.shape[3], out.shape[3], 1.0, 0,
+                               KERAS_LN_EPS, ACT_LRELU, KERAS_LRELU_ALPHA, R == 1)
+        w2 = self.dense2.kernel.data.reshape(1, Cg // 2, Cg).repeat(R, 1, 1).contiguous()   # the SAME dense2 for every r (:188)
+        b2 = self.dense2.bias.data.repeat(R).contiguous()
+        params = (self.dense1.kernel.data, self.dense1.bias.data, self.dense1_bn.gamma.data, self.dense1_bn.beta.data, None, None, w2, b2)
+        ops.splitattn_fwd(d, ycat, params, out)
+        return out
+
+    def __call__(self, inputs, *args, **kwargs):
+        return self.forward(inputs)
+
+
+class cardinal(nn.Module):
+    """ResNest.py:110-150."""
+
+    def __init__(self, ksize, outchannel, radix, kpaths, atrous=1, wDecay=None, in_channels=None):
+        super().__init__()
+        self.outchannel, self.ksize, self.radix, self.kpaths, self.atrous, self.wDecay = outchannel, ksize, radix, kpaths, atrous, wDecay
+        self.in_channels = in_channels if in_channels is not None else outchannel   # stage input = outchannel (= stage_out/2)
+        self.cv11 = int(outchannel / radix / kpaths)    # ResNest.py:120
+        self.cvkk = int(outchannel / kpaths)            # ResNest.py:121
+        self.conv1 = Conv2D(self.in_channels, self.cv11, 1, atrous)
+        self.conv1_bn = LayerNormalization(self.cv11)
+        self.conv1_act = LeakyReLU()
+        self.conv2 = Conv2D(self.cv11, self.cvkk, ksize, atrous)
+        self.conv2_bn = LayerNormalization(self.cvkk)
+        self.conv2_act = LeakyReLU()
+        self.split = split_attention(self.cvkk, radix, atrous, wDecay)
+        for c in (self.conv1, self.conv2):
+            c.on_finalize = lambda device: None   # packed by the owning _CardinalGroup
+        self._solo = None
+
+    def forward(self, x):
+        if self._solo is None:
+            self._solo = _CardinalGroup([self], self.radix)
+            self._solo.on_finalize(x.device)
+        return self._solo.forward(x)
+
+    def backward(self, dy, dx_residual=None):
+        return self._solo.backward(dy, dx_residual)
+
+    def __call__(self, x, *args, **kwargs):
+        return self.forward(x)
+
+
+class _CardinalGroup:
+    """Executes P cardinal blocks that share their input as grouped kernels (see module docstring)."""
+
+    def __init__(self, cards: List[cardinal], radix: int):
+        self.cards, self.P, self.radix = cards, len(cards), radix
+        c0 = cards[0]
+        self.cin, self.cv11, self.cvkk, self.k, self.dil = c0.in_channels, c0.cv11, c0.cvkk, c0.ksize, c0.atrous
+        self.hid = self.cvkk // 2
+        self.U, self.V = self.P * self.cv11, self.P * self.cvkk
+        self.Up, self.Vp = roundup(self.U, 8), roundup(self.V, 8)
+        self.cin_p = roundup(self.cin, 8)
+
+    # variables that must be back to back in the flat buffer (per-path vectors are read as one [P*...] vector)
+    def adjacent_params(self):
+        cs = self.cards
+        groups = [[c.conv1.bias for c in cs], [c.conv1_bn.gamma for c in cs], [c.conv1_bn.beta for c in cs],
+                  [c.conv2.bias for c in cs], [c.conv2_bn.gamma for c in cs], [c.conv2_bn.beta for c in cs],
+                  [c.split.dense1.kernel for c in cs], [c.split.dense1.bias for c in cs],
+                  [c.split.dense1_bn.gamma for c in cs], [c.split.dense1_bn.beta for c in cs],
+                  [c.split.dense2.kernel for c in cs], [c.split.dense2.bias for c in cs]]
+        return [(g, 0) for g in groups]
+
+    def on_finalize(self, device):
+        T = self.k * self.k
+        self.w1_f = torch.zeros((roundup(self.Up, 16), self.cin_p), dtype=BF16, device=device)
+        self.w1_d = torch.zeros((roundup(self.cin_p, 16), self.Up), dtype=BF16, device=device)
+        self.w2_f = torch.zeros((roundup(self.Vp, 16), T * self.Up), dtype=BF16, device=device)
+        self.w2_d = torch.zeros((roundup(self.Up, 16), T * self.Vp), dtype=BF16, device=device)
+        c0 = self.cards[0]
+        sp = lambda p, n: (_span(p.data, n), _span(p.grad, n))
+        self.b1, self.db1 = sp(c0.conv1.bias, self.Up)
+        self.g1, self.dg1 = sp(c0.conv1_bn.gamma, self.U)
+        self.be1, self.dbe1 = sp(c0.conv1_bn.beta, self.U)
+        self.b2, self.db2 = sp(c0.conv2.bias, self.Vp)
+        self.g2, self.dg2 = sp(c0.conv2_bn.gamma, self.V)
+        self.be2, self.dbe2 = sp(c0.conv2_bn.beta, self.V)
+        s = c0.split
+        names = (s.dense1.kernel, s.dense1.bias, s.dense1_bn.gamma, s.dense1_bn.beta, s.dense2.kernel, s.dense2.bias)
+        self.mlp_p = tuple(p.data for p in names)
+        self.mlp_g = tuple(p.grad for p in names)
+        # adjacency sanity: path p's variable must start right after path p-1's
+        for a, b in zip(self.cards[:-1], self.cards[1:]):
+            assert b.conv1.bias.data_ptr() == a.conv1.bias.data_ptr() + 4 * self.cv11, "cardinal params are not adjacent"
+            assert b.split.dense2.kernel.data_ptr() == a.split.dense2.kernel.data_ptr() + 4 * self.hid * self.cvkk
+        self.repack()
+
+    def repack(self):
+        T = self.k * self.k
+        for p, c in enumerate(self.cards):
+            k1, k2 = c.conv1.kernel.data, c.conv2.kernel.data
+            # conv1 [1,1,cin,cv11]: fwd rows n = p*cv11+j, K = ci ; dgrad rows = ci, K = p*cv11+j
+            ops.pack_weight(k1, 0, 1, self.cv11, 1, self.cv11, self.cin, self.w1_f, self.cin_p, self.cin_p, p * self.cv11, 0)
+            ops.pack_weight(k1, 0, self.cv11, 1, 1, self.cin, self.cv11, self.w1_d, self.Up, self.Up, 0, p * self.cv11)
+            # conv2 [k,k,cv11,cvkk] on the diagonal block (p,p)
+            sT = self.cv11 * self.cvkk
+            ops.pack_weight(k2, sT, 1, self.cvkk, T, self.cvkk, self.cv11, self.w2_f, T * self.Up, self.Up, p * self.cvkk, p * self.cv11)
+            ops.pack_weight(k2, sT, self.cvkk, 1, T, self.cv11, self.cvkk, self.w2_d, T * self.Vp, self.Vp, p * self.cv11, p * self.cvkk)
+
+    def _sa_desc(self, B, HW):
+        use_sigmoid = self.radix == 1   # ResNest.py:189-190
+        return ops.splitattn_desc(B, HW, self.P, 1, self.cvkk, self.hid, self.Vp, self.Vp, self.Vp, self.Vp, float(self.radix), 0,
+                                  KERAS_LN_EPS, ACT_LRELU, KERAS_LRELU_ALPHA, use_sigmoid)
+
+    def forward(self, x, out=None):
+        B, H, W, C, _ = ops.geom(x)
+        dev = x.device
+        a = KERAS_LRELU_ALPHA
+        u_raw = ops.conv2d_fwd(x, self.w1_f, self.b1, 1, 1, ops.new_act(B, H, W, self.Up, dev))                 # :139
+        u = ops.norm_act_fwd(u_raw, self.U, self.g1, self.be1, torch.empty_like(u_raw), 0, self.P, KERAS_LN_EPS, ACT_LRELU, a)  # :140-141
+        v_raw = ops.conv2d_fwd(u, self.w2_f, self.b2, self.k, self.dil, ops.new_act(B, H, W, self.Vp, dev))    # :142
+        y = ops.norm_act_fwd(v_raw, self.V, self.g2, self.be2, torch.empty_like(v_raw), 0, self.P, KERAS_LN_EPS, ACT_LRELU, a)  # :143-144
+        out = out if out is not None else ops.new_act(B, H, W, self.Vp, dev)
+        d = self._sa_desc(B, H * W)
+        params = self.mlp_p[:4] + (None, None) + self.mlp_p[4:]
+        _, g, s, ws = ops.splitattn_fwd(d, y, params, out)                                                        # :171-199
+        self._saved = (x, u_raw, u, v_raw, y, g, s, ws)
+        return out
+
+    def backward(self, dout, dx_residual=None):
+        x, u_raw, u, v_raw, y, g, s, ws = self._saved
+        B, H, W, _, _ = ops.geom(x)
+        dev = x.device
+        a = KERAS_LRELU_ALPHA
+        T = self.k * self.k
+        d = self._sa_desc(B, H * W)
+        params = self.mlp_p[:4] + (None, None) + self.mlp_p[4:]
+        dy = ops.splitattn_bwd(d, y, dout, params, self.mlp_g, g, s, ws, torch.empty_like(y))
+        dv = ops.norm_act_bwd(v_raw, dy, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, 0, self.P,
+                              KERAS_LN_EPS, ACT_LRELU, a)
+        # grouped 3x3: dense wgrad into scratch, keep the diagonal blocks
+        scratch = _Workspace.get(dev, T * self.Up * self.Vp)
+        ops.fill_f32(scratch, 0.0)
+        ops.conv2d_wgrad(u, dv, self.k, self.dil, scratch)
+        sT = self.cv11 * self.cvkk
+        for p, c in enumerate(self.cards):
+            ops.unpack_wgrad(scratch, self.Up, self.Vp, T, self.cvkk, self.cv11, p * self.cvkk, p * self.cv11, c.conv2.kernel.grad,
+                             sT, 1, self.cvkk)
+        ops.colsum(dv, self.db2, self.V)
+        du = ops.conv2d_dgrad(dv, self.w2_d, self.k, self.dil, torch.empty_like(u))
+        du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, 0, self.P,
+                                  KERAS_LN_EPS, ACT_LRELU, a)
+        scratch = _Workspace.get(dev, self.cin_p * self.Up)
+        ops.fill_f32(scratch, 0.0)
+        ops.conv2d_wgrad(x, du_raw, 1, 1, scratch)
+        for p, c in enumerate(self.cards):
+            ops.unpack_wgrad(scratch, self.cin_p, self.Up, 1, self.cv11, self.cin, p * self.cv11, 0, c.conv1.kernel.grad, 0, 1, self.cv11)
+        ops.colsum(du_raw, self.db1, self.U)
+        return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
+
+
+class residual_S(nn.Module):
+    """ResNest.py:61-107."""
+
+    def __init__(self, ksize, outchannel, radix, kpaths, atrous=1, wDecay=None, in_channels=None):
+        super().__init__()
+        self.kpaths, self.atrous, self.ksize, self.outchannel, self.radix, self.wDecay = kpaths, atrous, ksize, outchannel, radix, wDecay
+        self.in_channels = in_channels if in_channels is not None else outchannel // 2
+        self.cardinal_blocks = nn.ModuleList(
+            [cardinal(ksize, outchannel // 2, radix, kpaths, atrous, wDecay, in_channels=self.in_channels) for _ in range(kpaths)])
+        cvkk = self.cardinal_blocks[0].cvkk
+        self.concats_2 = Conv2D(kpaths * cvkk, outchannel, ksize, atrous)
+        self.convtmp_sc = Conv2D(self.in_channels, outchannel, 1, atrous)
+        self.convtmp_scbn = LayerNormalization(outchannel)
+        self.convtmp_scact = LeakyReLU()
+        self._group = _CardinalGroup(list(self.cardinal_blocks), radix)
+
+    def adjacent_params(self):
+        return self._group.adjacent_params()
+
+    def on_finalize(self, device):
+        self._group.on_finalize(device)
+
+    def repack(self):
+        self._group.repack()
+
+    def forward(self, x, out=None):
+        concats_1 = self._group.forward(x)                                                          # :91-96
+        sc_raw = self.convtmp_sc.forward(x)                                                          # :99
+        sc = self.convtmp_scbn.forward(sc_raw, ACT_LRELU, KERAS_LRELU_ALPHA)                        # :100-101
+        return self.concats_2.forward(concats_1, out=out, residual=sc)                               # :98,:102
+
+    def backward(self, dout, need_dx=True):
+        d_c1 = self.concats_2.backward(dout)
+        dsc_raw = self.convtmp_scbn.backward(dout)
+        dx_a = self._group.backward(d_c1)
+        return self.convtmp_sc.backward(dsc_raw, need_dx=need_dx, dx_residual=dx_a)
+
+    def __call__(self, x, *args, **kwargs):
+        return self.forward(x)
+
+
+class ResNest(nn.Module):
+    """ResNest.py:4-58.  ``forward(x)`` returns ``(x_4, [x_3, x_2, x_1])`` (NHWC, bf16)."""
+
+    def __init__(self, height, width, channel, ksize, radix=4, kpaths=4, wDecay=None):
+        super().__init__()
+        self.height, self.width, self.channel = height, width, channel
+        self.ksize, self.radix, self.kpaths, self.wDecay = ksize, radix, kpaths, wDecay
+        self.conv1 = Conv2D(channel, 16, 3)
+        self.conv1_act = LeakyReLU()
+        self.convtmp_1 = Conv2D(16, 32, 3)
+        self.convtmp_1bn = BatchNormalization(32)
+        self.convtmp_1act = LeakyReLU()
+        self.convtmp_2 = Conv2D(32, 32, 3)
+        self.convtmp_2bn = BatchNormalization(32)
+        self.convtmp_2act = LeakyReLU()
+        self.conv1_pool = AveragePooling2D()
+        self.conv2_pool = AveragePooling2D()
+        self.conv3_pool = AveragePooling2D()
+        self.conv4_pool = AveragePooling2D()
+        self.conv_1 = residual_S(ksize, 64, radix, kpaths, wDecay=wDecay, in_channels=32)
+        self.conv_2 = residual_S(ksize, 128, radix, kpaths, wDecay=wDecay, in_channels=64)
+        self.conv_3 = residual_S(ksize, 256, radix, kpaths, wDecay=wDecay, in_channels=128)
+        self.conv_4 = residual_S(ksize, 512, radix, kpaths, wDecay=wDecay, in_channels=256)
+
+    def forward(self, x):
+        """x: NHWC float32/float64 [B,H,W,channel] (cast to bf16 here, ResNest.py:39) or an already-cast bf16 tensor."""
+        if x.dtype != BF16:
+            x = ops.cast_input(x.contiguous(), roundup(self.channel, 8))
+        a = KERAS_LRELU_ALPHA
+        self._y1 = self.conv1.forward(x, act=ACT_LRELU, alpha=a)                                  # :39-40
+        t = self.convtmp_1.forward(self._y1)                                                     # :41
+        t = self.convtmp_1bn.forward(t, ACT_LRELU, a)                                            # :42-43
+        t = self.convtmp_2.forward(t)                                                            # :44
+        t = self.convtmp_2bn.forward(t, ACT_LRELU, a)                                            # :45-46
+        t = self.conv1_pool.forward(t)                                                           # :47
+        x_1 = self.conv_1.forward(t)                                                             # :48
+        x_2 = self.conv_2.forward(self.conv2_pool.forward(x_1))                                  # :49-50
+        x_3 = self.conv_3.forward(self.conv3_pool.forward(x_2))                                  # :51-52
+        x_4 = self.conv_4.forward(self.conv4_pool.forward(x_3))                                  # :53-54
+        return x_4, [x_3, x_2, x_1]                                                              # :55
+
+    def backward(self, d_x4, d_feats):
+        """Gradients w.r.t. (x_4, [x_3, x_2, x_1]) -> accumulates all parameter gradients (input gradient not needed)."""
+        d_x3, d_x2, d_x1 = d_feats
+        d = self.conv_4.backward(d_x4)
+        d = self.conv4_pool.backward(d, add=d_x3)
+        d = self.conv_3.backward(d)
+        d = self.conv3_pool.backward(d, add=d_x2)
+        d = self.conv_2.backward(d)
+        d = self.conv2_pool.backward(d, add=d_x1)
+        d = self.conv_1.backward(d)
+        d = self.conv1_pool.backward(d)
+        d = self.convtmp_2bn.backward(d)
+        d = self.convtmp_2.backward(d)
+        d = self.convtmp_1bn.backward(d)
+        d = self.convtmp_1.backward(d)
+        d = ops.act_bwd(self._y1, d, torch.empty_like(d), ACT_LRELU, KERAS_LRELU_ALPHA)   # LeakyReLU': sign(y) == sign(pre)
+        self.conv1.backward(d, need_dx=False)
+        return None
+
+    def repack(self):
+        for m in self.modules():
+            if m is not self and isinstance(m, (Conv2D, residual_S)) and getattr(m, "wp_f", 1) is not None:
+                m.repack()
+
+    def __call__(self, x, *args, **kwargs):
+        return self.forward(x)

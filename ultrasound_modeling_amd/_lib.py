@@ -1,0 +1,120 @@
+"""ctypes binding of libusseg_hip.so (the C ABI declared in include/usseg.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+Nothing here imports the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libusseg_hip.so")
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class UssegError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32), ("Cout", c_i32), ("ldx", c_i32),
+                ("ldy", c_i32), ("ksize", c_i32), ("dilation", c_i32), ("act", c_i32), ("alpha", c_f32),
+                ("flags", c_i32)]
+
+
+class NormDesc(C.Structure):
+    _fields_ = [("M", c_i64), ("C", c_i32), ("Cphys", c_i32), ("ldx", c_i32), ("ldy", c_i32), ("G", c_i32),
+                ("mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32)]
+
+
+class SplitAttnDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("HW", c_i32), ("P", c_i32), ("R", c_i32), ("Cg", c_i32), ("Hd", c_i32),
+                ("ldy", c_i32), ("ldo", c_i32), ("Cy_phys", c_i32), ("Co_phys", c_i32), ("mult", c_f32),
+                ("norm_mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32), ("use_sigmoid", c_i32)]
+
+
+class SplitAttnParams(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("w1", "b1", "gamma", "beta", "mean", "var", "w2", "b2")]
+
+
+class SplitAttnGrads(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("w1", "b1", "gamma", "beta", "w2", "b2")]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("M", c_i64), ("HW", c_i32), ("C", c_i32), ("ldl", c_i32), ("lddl", c_i32), ("loss_kind", c_i32),
+                ("label_smoothing", c_f32), ("clip_eps", c_f32), ("inv_global_batch", c_f32)]
+
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU = 0, 1, 2, 3
+OUT_F32, ACCUMULATE = 1, 2
+
+P = C.POINTER
+_PROTOS = {
+    # name: (restype, argtypes)
+    "usseg_last_error": (C.c_char_p, []),
+    "usseg_version": (C.c_int, []),
+    "usseg_conv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_conv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp]),
+    "usseg_tconv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_tconv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_tconv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp]),
+    "usseg_pack_weight": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "usseg_unpack_wgrad": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_i64,
+                                     c_f32, c_i32, c_vp]),
+    "usseg_norm_act_fwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_norm_act_bwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_channel_stats": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "usseg_act_fwd": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
+    "usseg_act_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
+    "usseg_avgpool2_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_avgpool2_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_copy_channels": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
+    "usseg_cast_input": (C.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_vp]),
+    "usseg_cast_bf16_to_f32": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_splitattn_gap": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp]),
+    "usseg_splitattn_ws_floats": (c_i64, [P(SplitAttnDesc)]),
+    "usseg_splitattn_mlp_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, P(SplitAttnParams), c_vp, c_vp, c_vp]),
+    "usseg_splitattn_apply_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp, c_vp]),
+    "usseg_splitattn_apply_bwd_reduce": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_splitattn_mlp_bwd": (C.c_int, [P(SplitAttnDesc), c_vp, P(SplitAttnParams), c_vp, c_vp, c_vp, c_vp,
+                                          P(SplitAttnGrads), c_vp]),
+    "usseg_splitattn_apply_bwd_dy": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "usseg_softmax_loss_fwd_bwd": (C.c_int, [P(LossDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_loss_cat_scale": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_sumsq": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "usseg_adam_clip_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_f32, c_f32, c_f32, c_vp]),
+    "usseg_adam_advance": (C.c_int, [c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),
+    "usseg_fill_f32": (C.c_int, [c_vp, c_i64, c_f32, c_vp]),
+    "usseg_scale_f32": (C.c_int, [c_vp, c_i64, c_vp, c_f32, c_vp]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libusseg_hip.so (built by ``__graft_entry__.build()`` / ``make -C ultrasound_modeling_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UssegError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                         f"g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().usseg_last_error().decode("utf-8", "replace")
+        raise UssegError(f"{what}: usseg error {rc}: {msg}")

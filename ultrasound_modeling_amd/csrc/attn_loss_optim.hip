@@ -1,0 +1,560 @@
+// Split-attention (global average pool, tiny per-(image,path) MLP, channel re-weighting), head softmax + loss,
+// and the optimiser (global-norm clip + Adam) for gfx950.  The big tensors are streamed 16 bytes per lane; the
+// MLP is a few hundred FLOPs per workgroup and runs in fp32 out of LDS.
+#include "common.h"
+
+static inline int lanes_per_pixel(int chunks) {
+  int l = 1;
+  while (l < chunks) l <<= 1;
+  return l;
+}
+
+__device__ __forceinline__ void wave_chunk_atomic2(float* acc8, int LPP, int chunk, bool chunk_ok, float* dst, int C, float scale) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = acc8[j];
+    for (int msk = LPP; msk < 64; msk <<= 1) v += __shfl_xor(v, msk, 64);
+    acc8[j] = v;
+  }
+  const int lane = threadIdx.x & 63;
+  if (lane < LPP && chunk_ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = chunk * 8 + j;
+      if (c < C) atomicAdd(dst + c, acc8[j] * scale);
+    }
+  }
+}
+
+// g[b][c] += sum_hw y[b,hw,c]   (and, with dout != NULL, ds[b][cy] += mult * sum_hw y[b,hw,cy] * dout[b,hw,co(cy)])
+__global__ __launch_bounds__(256) void sa_reduce_kernel(const bf16_t* y, const bf16_t* dout, int HW, int Cy, int ldy, int lddo, int R, int Cg,
+                                                         int LPP, float scale, float* out) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ppw = 64 / LPP, chunk = lane & (LPP - 1), slot = lane / LPP;
+  const bool chunk_ok = chunk * 8 < Cy;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  // output-channel index of each of this lane's y channels (only needed for R > 1)
+  int co[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int cy = chunk * 8 + j;
+    int pr = cy / Cg;  // = p*R + r
+    co[j] = (pr / R) * Cg + (cy - pr * Cg);
+  }
+  const int64_t ppb = 4 * ppw;
+  const bf16_t* yb = y + (int64_t)b * HW * ldy;
+  const bf16_t* db = dout ? dout + (int64_t)b * HW * lddo : nullptr;
+  for (int64_t base = (int64_t)blockIdx.x * ppb; base < HW; base += (int64_t)gridDim.x * ppb) {
+    int64_t m = base + wv * ppw + slot;
+    if (chunk_ok && m < HW) {
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(yb + m * ldy + chunk * 8), v);
+      if (db) {
+        if (R == 1) {
+          float d[8];
+          unpack8(*reinterpret_cast<const uint4*>(db + m * lddo + chunk * 8), d);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[j] += v[j] * d[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (chunk * 8 + j < Cy) s[j] += v[j] * bf2f(db[m * lddo + co[j]]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+      }
+    }
+  }
+  wave_chunk_atomic2(s, LPP, chunk, chunk_ok, out + (int64_t)b * Cy, Cy, scale);
+}
+
+static int sa_check(const UssegSplitAttnDesc* d) {
+  USSEG_CHECK_ARG(d, "null descriptor");
+  USSEG_CHECK_ARG(d->B > 0 && d->HW > 0 && d->P > 0 && d->R > 0 && d->Cg > 0 && d->Hd > 0, "splitattn: bad sizes");
+  USSEG_CHECK_ARG(d->Cg <= 128 && d->Hd <= 64 && d->R <= 4, "splitattn: Cg <= 128, Hd <= 64, R <= 4");
+  USSEG_CHECK_ARG(d->Cy_phys % 8 == 0 && d->Co_phys % 8 == 0 && d->Cy_phys >= d->P * d->R * d->Cg && d->Co_phys >= d->P * d->Cg,
+                  "splitattn: physical widths");
+  USSEG_CHECK_ARG(d->Cy_phys <= 512 && d->ldy % 8 == 0 && d->ldo % 8 == 0, "splitattn: strides");
+  return USSEG_OK;
+}
+
+extern "C" int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, float* g, usseg_stream_t stream) {
+  int rc = sa_check(d);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(y && g, "null pointer");
+  int Cy = d->P * d->R * d->Cg;
+  int LPP = lanes_per_pixel(roundup(Cy, 8) / 8);
+  int ppb = 4 * (64 / LPP);
+  int gx = (int)cdiv64(d->HW, (int64_t)ppb * 8);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(sa_reduce_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)nullptr, d->HW, Cy,
+                     d->ldy, 0, d->R, d->Cg, LPP, 1.0f, g);
+  return usseg_check_launch("splitattn_gap");
+}
+
+extern "C" int usseg_splitattn_apply_bwd_reduce(const UssegSplitAttnDesc* d, const void* y, const void* dout, int32_t lddo, float* ds,
+                                                usseg_stream_t stream) {
+  int rc = sa_check(d);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(y && dout && ds && lddo % 8 == 0, "null pointer");
+  int Cy = d->P * d->R * d->Cg;
+  int LPP = lanes_per_pixel(roundup(Cy, 8) / 8);
+  int ppb = 4 * (64 / LPP);
+  int gx = (int)cdiv64(d->HW, (int64_t)ppb * 8);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(sa_reduce_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)dout, d->HW, Cy,
+                     d->ldy, lddo, d->R, d->Cg, LPP, d->mult, ds);
+  return usseg_check_launch("splitattn_apply_bwd_reduce");
+}
+
+// ---- the tiny MLP: one 128-thread workgroup per (image b, path p) ----------------------------------------
+struct SaMlp {
+  UssegSplitAttnDesc d;
+  UssegSplitAttnParams p;
+  UssegSplitAttnGrads gr;
+  const float* g; float* s; float* ws; const float* ds; float* dg;
+};
+
+extern "C" int64_t usseg_splitattn_ws_floats(const UssegSplitAttnDesc* d) {
+  if (!d) return 0;
+  return (int64_t)d->B * d->P * (d->Cg + 2 * d->Hd);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
+  const UssegSplitAttnDesc& d = a.d;
+  const int b = blockIdx.x / d.P, p = blockIdx.x - b * d.P;
+  const int tid = threadIdx.x;
+  const int Cg = d.Cg, Hd = d.Hd, R = d.R;
+  __shared__ float gin[128], h1[64], xh[64], av[64], red[4], dz[4 * 128], da[64], dh[64];
+  const int Cy = d.P * R * Cg;
+  float* wsb = a.ws + (int64_t)(b * d.P + p) * (Cg + 2 * Hd);
+  const float* w1 = a.p.w1 + (int64_t)p * Cg * Hd;
+  const float* w2 = a.p.w2 + (int64_t)p * R * Hd * Cg;
+  const float gscale = d.mult / (float)d.HW;
+
+  // gin[c] = mult/HW * sum_r g[b][(p*R+r)*Cg + c]     (ResNest.py:173-180)
+  for (int c = tid; c < Cg; c += 128) {
+    float v = 0.f;
+    for (int r = 0; r < R; ++r) v += a.g[(int64_t)b * Cy + (p * R + r) * Cg + c];
+    gin[c] = v * gscale;
+  }
+  __syncthreads();
+  // dense1 (ResNest.py:182)
+  for (int j = tid; j < Hd; j += 128) {
+    float v = a.p.b1[p * Hd + j];
+    for (int c = 0; c < Cg; ++c) v += gin[c] * w1[c * Hd + j];
+    h1[j] = v;
+  }
+  __syncthreads();
+  // norm (LN over Hd, ResNest.py:183 / BN inference, TBI_ResNest.py:190) + act
+  if (tid == 0) {
+    if (d.norm_mode == 0) {
+      float mu = 0.f;
+      for (int j = 0; j < Hd; ++j) mu += h1[j];
+      mu /= (float)Hd;
+      float var = 0.f;
+      for (int j = 0; j < Hd; ++j) var += (h1[j] - mu) * (h1[j] - mu);
+      var /= (float)Hd;
+      red[0] = mu;
+      red[1] = rsqrtf(var + d.eps);
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < Hd; j += 128) {
+    float x;
+    if (d.norm_mode == 0) x = (h1[j] - red[0]) * red[1];
+    else x = (h1[j] - a.p.mean[p * Hd + j]) * rsqrtf(a.p.var[p * Hd + j] + d.eps);
+    xh[j] = x;
+    av[j] = apply_act(a.p.gamma[p * Hd + j] * x + a.p.beta[p * Hd + j], d.act, d.alpha);
+  }
+  __syncthreads();
+
+  if (!BWD) {
+    for (int c = tid; c < Cg; c += 128) wsb[c] = gin[c];
+    for (int j = tid; j < Hd; j += 128) { wsb[Cg + j] = h1[j]; wsb[Cg + Hd + j] = av[j]; }
+    // dense2 per radix branch + softmax over channels (ResNest.py:187-192; TBI_ResNest.py:194-200)
+    for (int r = 0; r < R; ++r) {
+      float* z = dz;  // reuse as scratch
+      for (int c = tid; c < Cg; c += 128) {
+        float v = a.p.b2[(p * R + r) * Cg + c];
+        const float* w = w2 + (int64_t)r * Hd * Cg;
+        for (int j = 0; j < Hd; ++j) v += av[j] * w[j * Cg + c];
+        z[c] = v;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float mx = -INFINITY;
+        for (int c = 0; c < Cg; ++c) mx = fmaxf(mx, z[c]);
+        float sum = 0.f;
+        for (int c = 0; c < Cg; ++c) sum += __expf(z[c] - mx);
+        red[2] = mx;
+        red[3] = 1.f / sum;
+      }
+      __syncthreads();
+      for (int c = tid; c < Cg; c += 128) {
+        float sv = d.use_sigmoid ? 1.f / (1.f + __expf(-z[c])) : __expf(z[c] - red[2]) * red[3];
+        a.s[((int64_t)(b * d.P + p) * R + r) * Cg + c] = sv;
+      }
+      __syncthreads();
+    }
+  } else {
+    // softmax / sigmoid backward -> dz[r][c]
+    for (int r = 0; r < R; ++r) {
+      const float* sv = a.s + ((int64_t)(b * d.P + p) * R + r) * Cg;
+      const float* dsv = a.ds + (int64_t)b * Cy + (p * R + r) * Cg;
+      if (tid == 0) {
+        float dot = 0.f;
+        if (!d.use_sigmoid)
+          for (int c = 0; c < Cg; ++c) dot += dsv[c] * sv[c];
+        red[2] = dot;
+      }
+      __syncthreads();
+      for (int c = tid; c < Cg; c += 128) {
+        float v = d.use_sigmoid ? dsv[c] * sv[c] * (1.f - sv[c]) : sv[c] * (dsv[c] - red[2]);
+        dz[r * 128 + c] = v;
+        atomicAdd(a.gr.b2 + (p * R + r) * Cg + c, v);
+      }
+      __syncthreads();
+    }
+    // dW2[p][r][j][c] += a[j]*dz[r][c];  da[j] = sum_{r,c} w2*dz
+    for (int idx = tid; idx < R * Hd * Cg; idx += 128) {
+      int c = idx % Cg;
+      int j = (idx / Cg) % Hd;
+      int r = idx / (Cg * Hd);
+      atomicAdd(a.gr.w2 + (int64_t)p * R * Hd * Cg + idx, av[j] * dz[r * 128 + c]);
+    }
+    for (int j = tid; j < Hd; j += 128) {
+      float v = 0.f;
+      for (int r = 0; r < R; ++r)
+        for (int c = 0; c < Cg; ++c) v += w2[((int64_t)r * Hd + j) * Cg + c] * dz[r * 128 + c];
+      da[j] = v;
+    }
+    __syncthreads();
+    // act + norm backward
+    for (int j = tid; j < Hd; j += 128) {
+      float ga = a.p.gamma[p * Hd + j];
+      float pre = ga * xh[j] + a.p.beta[p * Hd + j];
+      float dpre = da[j] * act_grad(pre, d.act, d.alpha);
+      atomicAdd(a.gr.gamma + p * Hd + j, dpre * xh[j]);
+      atomicAdd(a.gr.beta + p * Hd + j, dpre);
+      dh[j] = dpre * ga;  // d xhat
+    }
+    __syncthreads();
+    if (d.norm_mode == 0) {
+      if (tid == 0) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < Hd; ++j) { s1 += dh[j]; s2 += dh[j] * xh[j]; }
+        red[2] = s1 / (float)Hd;
+        red[3] = s2 / (float)Hd;
+      }
+      __syncthreads();
+      for (int j = tid; j < Hd; j += 128) dh[j] = red[1] * (dh[j] - red[2] - xh[j] * red[3]);
+    } else {
+      for (int j = tid; j < Hd; j += 128) dh[j] = dh[j] * rsqrtf(a.p.var[p * Hd + j] + d.eps);
+    }
+    __syncthreads();
+    for (int j = tid; j < Hd; j += 128) atomicAdd(a.gr.b1 + p * Hd + j, dh[j]);
+    for (int idx = tid; idx < Cg * Hd; idx += 128) {
+      int j = idx % Hd, c = idx / Hd;
+      atomicAdd(a.gr.w1 + (int64_t)p * Cg * Hd + idx, gin[c] * dh[j]);
+    }
+    // d g_sum[b][(p*R+r)*Cg + c] = mult/HW * sum_j w1[c][j] dh[j]
+    for (int c = tid; c < Cg; c += 128) {
+      float v = 0.f;
+      for (int j = 0; j < Hd; ++j) v += w1[c * Hd + j] * dh[j];
+      v *= gscale;
+      for (int r = 0; r < R; ++r) a.dg[(int64_t)b * Cy + (p * R + r) * Cg + c] = v;
+    }
+  }
+}
+
+extern "C" int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, float* s, float* ws,
+                                       usseg_stream_t stream) {
+  int rc = sa_check(d);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(g && p && s && ws && p->w1 && p->b1 && p->gamma && p->beta && p->w2 && p->b2, "null pointer");
+  USSEG_CHECK_ARG(d->norm_mode == 0 || (p->mean && p->var), "affine norm needs mean/var");
+  SaMlp a = {};
+  a.d = *d; a.p = *p; a.g = g; a.s = s; a.ws = ws;
+  hipLaunchKernelGGL(sa_mlp_kernel<false>, dim3(d->B * d->P), dim3(128), 0, (hipStream_t)stream, a);
+  return usseg_check_launch("splitattn_mlp_fwd");
+}
+
+extern "C" int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, const float* s,
+                                       const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads,
+                                       usseg_stream_t stream) {
+  int rc = sa_check(d);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(g && p && s && ds && dg && grads, "null pointer");
+  USSEG_CHECK_ARG(grads->w1 && grads->b1 && grads->gamma && grads->beta && grads->w2 && grads->b2, "null grad pointer");
+  SaMlp a = {};
+  a.d = *d; a.p = *p; a.gr = *grads; a.g = g; a.s = const_cast<float*>(s); a.ws = const_cast<float*>(ws); a.ds = ds; a.dg = dg;
+  hipLaunchKernelGGL(sa_mlp_kernel<true>, dim3(d->B * d->P), dim3(128), 0, (hipStream_t)stream, a);
+  return usseg_check_launch("splitattn_mlp_bwd");
+}
+
+// out[b,hw,p*Cg+c] = mult * sum_r y[b,hw,(p*R+r)*Cg+c] * s[b][p][r][c]   (ResNest.py:194-197)
+// BWD: dy[b,hw,cy] = mult * s[b][cy] * dout[b,hw,co(cy)] + dg[b][cy]
+template <bool BWD>
+__global__ __launch_bounds__(256) void sa_apply_kernel(const bf16_t* in, const float* s, const float* dg, int B, int HW, int P, int R, int Cg,
+                                                        int ldi, int ldo, int CHo, float mult, bf16_t* out) {
+  // CHo = chunks of the OUTPUT row (fwd: Co_phys/8, bwd: Cy_phys/8)
+  const int64_t total = (int64_t)B * HW * CHo;
+  const int Cy = P * R * Cg, Co = P * Cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t pix = i / CHo;
+    int c0 = (int)(i - pix * CHo) * 8;
+    int b = (int)(pix / HW);
+    float o[8];
+    if (!BWD) {
+      if (R == 1) {
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(in + pix * ldi + c0), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Co) ? mult * v[j] * s[(int64_t)b * Cy + c0 + j] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int c = c0 + j;
+          float acc = 0.f;
+          if (c < Co) {
+            int p = c / Cg, cc = c - p * Cg;
+            for (int r = 0; r < R; ++r) {
+              int cy = (p * R + r) * Cg + cc;
+              acc += bf2f(in[pix * ldi + cy]) * s[(int64_t)b * Cy + cy];
+            }
+          }
+          o[j] = mult * acc;
+        }
+      }
+    } else {
+      if (R == 1) {
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(in + pix * ldi + c0), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o[j] = (c0 + j < Cy) ? mult * v[j] * s[(int64_t)b * Cy + c0 + j] + dg[(int64_t)b * Cy + c0 + j] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int cy = c0 + j;
+          float v = 0.f;
+          if (cy < Cy) {
+            int pr = cy / Cg;
+            int co = (pr / R) * Cg + (cy - pr * Cg);
+            v = mult * bf2f(in[pix * ldi + co]) * s[(int64_t)b * Cy + cy] + dg[(int64_t)b * Cy + cy];
+          }
+          o[j] = v;
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(out + pix * ldo + c0) = pack8(o);
+  }
+}
+
+extern "C" int usseg_splitattn_apply_fwd(const UssegSplitAttnDesc* d, const void* y, const float* s, void* out, usseg_stream_t stream) {
+  int rc = sa_check(d);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(y && s && out, "null pointer");
+  int64_t total = (int64_t)d->B * d->HW * (d->Co_phys / 8);
+  int64_t g = cdiv64(total, 256 * 4);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(sa_apply_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, s, (const float*)nullptr,
+                     d->B, d->HW, d->P, d->R, d->Cg, d->ldy, d->ldo, d->Co_phys / 8, d->mult, (bf16_t*)out);
+  return usseg_check_launch("splitattn_apply_fwd");
+}
+
+extern "C" int usseg_splitattn_apply_bwd_dy(const UssegSplitAttnDesc* d, const void* dout, int32_t lddo, const float* s, const float* dg,
+                                            void* dy, int32_t lddy, usseg_stream_t stream) {
+  int rc = sa_check(d);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(dout && s && dg && dy && lddo % 8 == 0 && lddy % 8 == 0, "null pointer");
+  int64_t total = (int64_t)d->B * d->HW * (d->Cy_phys / 8);
+  int64_t g = cdiv64(total, 256 * 4);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(sa_apply_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, s, dg, d->B, d->HW,
+                     d->P, d->R, d->Cg, lddo, lddy, d->Cy_phys / 8, d->mult, (bf16_t*)dy);
+  return usseg_check_launch("splitattn_apply_bwd_dy");
+}
+
+// ------------------------------------------------------------------------------------------ head softmax + loss
+__global__ __launch_bounds__(256) void softmax_loss_kernel(const UssegLossDesc d, const float* logits, const float* y_true, const float* scale,
+                                                            float* probs, float* loss, bf16_t* dlogits) {
+  __shared__ float red[4];
+  float lsum = 0.f;
+  const int C = d.C;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < d.M; m += (int64_t)gridDim.x * 256) {
+    float z[8], p[8], yt[8];
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) { z[c] = logits[m * d.ldl + c]; mx = fmaxf(mx, z[c]); }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) { p[c] = __expf(z[c] - mx); sum += p[c]; }
+    float inv = 1.f / sum;
+    for (int c = 0; c < C; ++c) { p[c] *= inv; probs[m * C + c] = p[c]; }
+    if (!y_true) continue;
+    for (int c = 0; c < C; ++c) yt[c] = y_true[m * C + c];
+    float dLdp[8];
+    if (d.loss_kind == 0) {
+      // CategoricalCrossentropy(label_smoothing) on probabilities (VisionTransformer.py:205)
+      float S = 0.f;
+      for (int c = 0; c < C; ++c) S += p[c];
+      float u[8], ubar = 0.f, l = 0.f;
+      for (int c = 0; c < C; ++c) {
+        float ys = yt[c] * (1.f - d.label_smoothing) + d.label_smoothing / (float)C;
+        float q = p[c] / S;
+        float qc = fminf(fmaxf(q, d.clip_eps), 1.f - d.clip_eps);
+        l -= ys * __logf(qc);
+        u[c] = (q > d.clip_eps && q < 1.f - d.clip_eps) ? -ys / qc : 0.f;
+        ubar += u[c] * q;
+      }
+      lsum += l * d.inv_global_batch;
+      for (int c = 0; c < C; ++c) dLdp[c] = (u[c] - ubar) / S * d.inv_global_batch;
+    } else {
+      // my_loss_cat (TBI_ResNest.py:234-248): -sum_b y*log(p+1e-7)*scale[hw][c]; the [H,W] map is summed for the gradient
+      int hw = (int)(m % d.HW);
+      float l = 0.f;
+      for (int c = 0; c < C; ++c) {
+        float sc = scale[(int64_t)hw * C + c];
+        l -= yt[c] * __logf(p[c] + 1e-7f) * sc;
+        dLdp[c] = -yt[c] * sc / (p[c] + 1e-7f);
+      }
+      atomicAdd(loss + hw, l);
+    }
+    if (dlogits) {
+      float dot = 0.f;
+      for (int c = 0; c < C; ++c) dot += dLdp[c] * p[c];
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = (c < C) ? p[c] * (dLdp[c] - dot) : 0.f;
+      *reinterpret_cast<uint4*>(dlogits + m * d.lddl) = pack8(o);
+    }
+  }
+  if (y_true && d.loss_kind == 0) {
+    for (int msk = 32; msk >= 1; msk >>= 1) lsum += __shfl_xor(lsum, msk, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+extern "C" int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, const float* y_true, const float* scale, float* probs,
+                                          float* loss, void* dlogits, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && logits && probs, "null pointer");
+  USSEG_CHECK_ARG(d->C >= 1 && d->C <= 8 && d->ldl >= d->C, "softmax_loss: 1 <= C <= 8");
+  USSEG_CHECK_ARG(!y_true || loss, "loss pointer required with y_true");
+  USSEG_CHECK_ARG(!dlogits || (d->lddl == 8), "dlogits stride must be 8");
+  USSEG_CHECK_ARG(d->loss_kind == 0 || (d->loss_kind == 1 && scale), "loss_kind 1 needs scale");
+  if (d->M <= 0) return USSEG_OK;
+  int64_t g = cdiv64(d->M, 256 * 4);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(softmax_loss_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *d, logits, y_true, scale, probs, loss,
+                     (bf16_t*)dlogits);
+  return usseg_check_launch("softmax_loss");
+}
+
+__global__ __launch_bounds__(256) void loss_cat_scale_kernel(const float* y, int B, int HW, int C, float* scale) {
+  int64_t total = (int64_t)HW * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += y[(int64_t)b * total + i];
+    scale[i] = 1.f / (s + 1.f) / (float)HW;
+  }
+}
+extern "C" int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, int32_t C, float* scale, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(y_true && scale && B > 0 && HW > 0 && C > 0, "loss_cat_scale: bad args");
+  int64_t g = cdiv64((int64_t)HW * C, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(loss_cat_scale_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y_true, B, HW, C, scale);
+  return usseg_check_launch("loss_cat_scale");
+}
+
+// ------------------------------------------------------------------------------------------ optimiser
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  int64_t n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 v = g4[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+  for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int usseg_sumsq(const float* g, int64_t n, float* out, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(g && out && n >= 0 && ((uintptr_t)g % 16) == 0, "sumsq: bad args (g must be 16-byte aligned)");
+  if (n == 0) return USSEG_OK;
+  int64_t grid = cdiv64(n, 256 * 16);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  return usseg_check_launch("sumsq");
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
+                                                    const float* lr_t_dev, float b1, float b2, float eps) {
+  float scale = 1.f;
+  if (clip_norm > 0.f) scale = clip_norm / fmaxf(sqrtf(*sumsq), clip_norm);  // tf.clip_by_global_norm
+  const float lr_t = *lr_t_dev;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * scale;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+extern "C" int usseg_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
+                                    const float* lr_t_dev, float beta1, float beta2, float eps, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(p && g && m && v && lr_t_dev && (clip_norm <= 0.f || sumsq), "adam: null pointer");
+  if (n <= 0) return USSEG_OK;
+  int64_t grid = cdiv64(n, 256 * 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, clip_norm, lr_t_dev, beta1,
+                     beta2, eps);
+  return usseg_check_launch("adam");
+}
+
+__global__ void adam_advance_kernel(int32_t* step, float* lr_t, float lr, float b1, float b2) {
+  int t = *step + 1;
+  *step = t;
+  *lr_t = lr * sqrtf(1.f - powf(b2, (float)t)) / (1.f - powf(b1, (float)t));
+}
+extern "C" int usseg_adam_advance(int32_t* step, float* lr_t_dev, float lr, float beta1, float beta2, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(step && lr_t_dev, "adam_advance: null pointer");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, lr_t_dev, lr, beta1, beta2);
+  return usseg_check_launch("adam_advance");
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+extern "C" int usseg_fill_f32(float* p, int64_t n, float value, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(p || n == 0, "fill: null pointer");
+  if (n <= 0) return USSEG_OK;
+  int64_t grid = cdiv64(n, 256 * 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  return usseg_check_launch("fill");
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* p, int64_t n, const float* sumsq, float clip_norm) {
+  float scale = clip_norm / fmaxf(sqrtf(*sumsq), clip_norm);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] *= scale;
+}
+extern "C" int usseg_scale_f32(float* p, int64_t n, const float* sumsq, float clip_norm, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(p && sumsq && clip_norm > 0.f, "scale: bad args");
+  if (n <= 0) return USSEG_OK;
+  int64_t grid = cdiv64(n, 256 * 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, n, sumsq, clip_norm);
+  return usseg_check_launch("scale");
+}

@@ -1,0 +1,62 @@
+// Internal helpers shared by the gfx950 kernels of libusseg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/usseg.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // one 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+  switch (act) {
+    case USSEG_ACT_LRELU: return v >= 0.f ? v : alpha * v;
+    case USSEG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case USSEG_ACT_ELU: return v > 0.f ? v : alpha * (__expf(v) - 1.f);
+    default: return v;
+  }
+}
+// derivative of act at pre-activation value v
+__device__ __forceinline__ float act_grad(float v, int act, float alpha) {
+  switch (act) {
+    case USSEG_ACT_LRELU: return v >= 0.f ? 1.f : alpha;
+    case USSEG_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+    case USSEG_ACT_ELU: return v > 0.f ? 1.f : alpha * __expf(v);
+    default: return 1.f;
+  }
+}
+
+void usseg_set_error(const char* fmt, ...);
+#define USSEG_CHECK_ARG(cond, ...)                 \
+  do {                                             \
+    if (!(cond)) {                                 \
+      usseg_set_error(__VA_ARGS__);                \
+      return USSEG_ERR_BAD_ARG;                    \
+    }                                              \
+  } while (0)
+int usseg_check_launch(const char* what);
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

@@ -1,0 +1,351 @@
+// Gather implicit-GEMM on bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate, for gfx950.
+//
+// One kernel serves Conv2D fwd, Conv2D dgrad, Conv2DTranspose fwd (4 parity classes) and Conv2DTranspose dgrad:
+//   Y[b, gy*osy+oay, gx*osx+oax, n] = epi( sum_{tap i} sum_{c<Cin} X[b, gy*isy+dy_i, gx*isx+dx_i, c] * Wp[n][w_i*Cin + c] )
+// GEMM view: rows m = (b,gy,gx) pixels, cols n = output channels, K = (tap, channel) walked in 16-byte
+// (8-channel) chunks, so any Cin that is a multiple of 8 works and taps that fall outside the image are
+// zero-filled while staging (the im2col matrix never exists in memory).
+//
+// Tile: 128 pixels x (16*NT) channels per 256-thread workgroup, K step 32.  Each of the 4 waves owns 32 pixels
+// x all 16*NT channels.  Operands are staged global -> VGPR -> LDS (80-byte padded rows), double buffered, with
+// the next step's global loads issued before the current step's MFMAs (one barrier per K step).
+// The MFMA is issued as D^T = W * X^T so that each lane ends up with 4 CONSECUTIVE channels of one pixel:
+// the epilogue (bias, activation, residual) then stores 8 bytes per lane and 32 bytes per pixel per tile.
+#include "common.h"
+
+struct IgemmParams {
+  const bf16_t* x;
+  const bf16_t* w;
+  void* y;
+  const float* bias;
+  const bf16_t* res;
+  int32_t B, Hg, Wg;
+  int64_t M;
+  int32_t Hi, Wi, ldx, isy, isx;
+  int32_t Ho, Wo, ldy, osy, osx, oay, oax;
+  int32_t ldr;
+  int32_t cpt;      // 16-byte chunks per tap = Cin/8
+  int32_t ntaps;
+  int32_t nchunks;  // ntaps * cpt
+  int32_t Nw;       // rows of the packed weight matrix
+  int32_t Kw;       // its row stride (elements)
+  int32_t Nout;     // channels to store
+  int32_t act;
+  float alpha;
+  int32_t out_f32;
+  int32_t accumulate;
+  int16_t tap_dy[16], tap_dx[16], tap_w[16];
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int BM = 128, BN = 16 * NT, LDSS = 40;  // LDS row stride in elements (64 B data + 16 B pad)
+  constexpr int WCH = (BN * 4 + 255) / 256;         // weight chunks per thread per K step
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2][(BM + BN) * LDSS];
+  __shared__ int s_tap[48];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  if (tid < 16) {
+    s_tap[tid] = p.tap_dy[tid];
+    s_tap[16 + tid] = p.tap_dx[tid];
+    s_tap[32 + tid] = p.tap_w[tid];
+  }
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int HWg = p.Hg * p.Wg;
+
+  // --- per-thread staging coordinates: chunk column q (0..3) of rows r0 and r0+64
+  const int q = tid & 3;
+  const int r0 = tid >> 2;
+  int py[2], px[2], pb[2];
+  bool pv[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int64_t m = m0 + r0 + 64 * h;
+    pv[h] = m < p.M;
+    int mm = pv[h] ? (int)m : 0;
+    int b = mm / HWg;
+    int rem = mm - b * HWg;
+    int gy = rem / p.Wg;
+    int gx = rem - gy * p.Wg;
+    pb[h] = b * p.Hi;
+    py[h] = gy * p.isy;
+    px[h] = gx * p.isx;
+  }
+  // (tap, chunk-in-tap) of this thread's chunk column, advanced by 4 chunks per K step
+  int ti = q / p.cpt;
+  int c8 = q - ti * p.cpt;
+  const int nks = (p.nchunks + 3) >> 2;
+  const int Cin = p.cpt * 8;
+
+  uint4 ra[2], rw[WCH];
+  __syncthreads();  // tap table visible
+
+  auto load_step = [&]() {
+    const bool tv = ti < p.ntaps;
+    int dy = 0, dx = 0, tw = 0;
+    if (tv) { dy = s_tap[ti]; dx = s_tap[16 + ti]; tw = s_tap[32 + ti]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      int iy = py[h] + dy, ix = px[h] + dx;
+      if (tv && pv[h] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
+        const bf16_t* src = p.x + ((int64_t)(pb[h] + iy) * p.Wi + ix) * p.ldx + c8 * 8;
+        v = *reinterpret_cast<const uint4*>(src);
+      }
+      ra[h] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+      int idx = tid + 256 * j;
+      int n = idx >> 2;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < BN * 4 && tv && (n0 + n) < p.Nw) {
+        const bf16_t* src = p.w + (int64_t)(n0 + n) * p.Kw + tw * Cin + c8 * 8;
+        v = *reinterpret_cast<const uint4*>(src);
+      }
+      rw[j] = v;
+    }
+    // advance to the next K step
+    c8 += 4;
+    while (c8 >= p.cpt) { c8 -= p.cpt; ++ti; }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      *reinterpret_cast<uint4*>(&lds[buf][(r0 + 64 * h) * LDSS + q * 8]) = ra[h];
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+      int idx = tid + 256 * j;
+      if (idx < BN * 4) *reinterpret_cast<uint4*>(&lds[buf][(BM + (idx >> 2)) * LDSS + q * 8]) = rw[j];
+    }
+  };
+
+  f32x4_t acc[2][NT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  load_step();
+  store_step(0);
+  __syncthreads();
+
+  const int frow = lane & 15, fk = (lane >> 4) * 8;
+  for (int ks = 0; ks < nks; ++ks) {
+    const int cur = ks & 1;
+    const bool more = (ks + 1) < nks;
+    if (more) load_step();
+    bf16x8_t xf[2], wf[NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+      xf[a] = *reinterpret_cast<const bf16x8_t*>(&lds[cur][(wv * 32 + a * 16 + frow) * LDSS + fk]);
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+      wf[b] = *reinterpret_cast<const bf16x8_t*>(&lds[cur][(BM + b * 16 + frow) * LDSS + fk]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    if (more) store_step(cur ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue: lane holds Y[pixel = lane&15][n = 4*(lane>>4) + j]
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    int64_t m = m0 + wv * 32 + a * 16 + frow;
+    if (m >= p.M) continue;
+    int mm = (int)m;
+    int b = mm / HWg;
+    int rem = mm - b * HWg;
+    int gy = rem / p.Wg;
+    int gx = rem - gy * p.Wg;
+    int64_t opix = ((int64_t)(b * p.Ho + gy * p.osy + p.oay)) * p.Wo + gx * p.osx + p.oax;
+#pragma unroll
+    for (int bt = 0; bt < NT; ++bt) {
+      int n = n0 + bt * 16 + (lane >> 4) * 4;
+      if (n >= p.Nout) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
+      if (p.bias) {
+        float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (p.act != USSEG_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act, p.alpha);
+      }
+      if (p.res) {
+        uint2 rr = *reinterpret_cast<const uint2*>(p.res + opix * p.ldr + n);
+        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+      }
+      if (p.out_f32) {
+        float* dst = reinterpret_cast<float*>(p.y) + opix * p.ldy + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < p.Nout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+      } else {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + opix * p.ldy + n;
+        if (p.accumulate) {
+          uint2 o = *reinterpret_cast<const uint2*>(dst);
+          v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
+          v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(dst) = o;
+      }
+    }
+  }
+}
+
+static int launch_igemm(const IgemmParams& p, hipStream_t s) {
+  if (p.M <= 0) return USSEG_OK;
+  dim3 block(256);
+  int64_t gx = cdiv64(p.M, 128);
+  USSEG_CHECK_ARG(gx < (1ll << 31), "igemm: too many pixel tiles");
+  if (p.Nout <= 16) {
+    hipLaunchKernelGGL(igemm_kernel<1>, dim3((unsigned)gx, 1), block, 0, s, p);
+  } else if (p.Nout <= 32) {
+    hipLaunchKernelGGL(igemm_kernel<2>, dim3((unsigned)gx, 1), block, 0, s, p);
+  } else if (p.Nout <= 64) {
+    hipLaunchKernelGGL(igemm_kernel<4>, dim3((unsigned)gx, 1), block, 0, s, p);
+  } else {
+    hipLaunchKernelGGL(igemm_kernel<8>, dim3((unsigned)gx, (unsigned)((p.Nout + 127) / 128)), block, 0, s, p);
+  }
+  return usseg_check_launch("igemm");
+}
+
+static int check_desc(const UssegConvDesc* d, bool tconv) {
+  USSEG_CHECK_ARG(d != nullptr, "null descriptor");
+  USSEG_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0, "bad B/H/W");
+  USSEG_CHECK_ARG(d->Cin > 0 && d->Cin % 8 == 0 && d->ldx % 8 == 0 && d->ldx >= d->Cin, "Cin/ldx must be multiples of 8");
+  USSEG_CHECK_ARG(d->Cout > 0 && d->ldy >= d->Cout, "bad Cout/ldy");
+  if (!(d->flags & USSEG_OUT_F32)) USSEG_CHECK_ARG(d->Cout % 8 == 0 && d->ldy % 8 == 0, "bf16 Cout/ldy must be multiples of 8");
+  else USSEG_CHECK_ARG(d->ldy % 4 == 0, "f32 ldy must be a multiple of 4");
+  if (tconv) USSEG_CHECK_ARG(d->ksize == 3 || d->ksize == 4, "tconv ksize must be 3 or 4");
+  else USSEG_CHECK_ARG((d->ksize == 1 || d->ksize == 3) && d->dilation >= 1, "conv ksize must be 1 or 3");
+  return USSEG_OK;
+}
+
+extern "C" int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const void* wp, const float* bias,
+                                const void* residual, int32_t ldr, void* y, usseg_stream_t stream) {
+  int rc = check_desc(d, false);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(x && wp && y, "null pointer");
+  IgemmParams p = {};
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.y = y; p.bias = bias; p.res = (const bf16_t*)residual; p.ldr = ldr;
+  p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
+  p.Hi = d->H; p.Wi = d->W; p.ldx = d->ldx; p.isy = p.isx = 1;
+  p.Ho = d->H; p.Wo = d->W; p.ldy = d->ldy; p.osy = p.osx = 1; p.oay = p.oax = 0;
+  p.cpt = d->Cin / 8;
+  const int k = d->ksize, half = k / 2;
+  p.ntaps = k * k;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) {
+      int t = kh * k + kw;
+      p.tap_dy[t] = (int16_t)((kh - half) * d->dilation);
+      p.tap_dx[t] = (int16_t)((kw - half) * d->dilation);
+      p.tap_w[t] = (int16_t)t;
+    }
+  p.nchunks = p.ntaps * p.cpt;
+  p.Nw = roundup(d->Cout, 16); p.Kw = p.ntaps * d->Cin; p.Nout = d->Cout;
+  p.act = d->act; p.alpha = d->alpha; p.out_f32 = (d->flags & USSEG_OUT_F32) ? 1 : 0;
+  p.accumulate = (d->flags & USSEG_ACCUMULATE) ? 1 : 0;
+  return launch_igemm(p, (hipStream_t)stream);
+}
+
+extern "C" int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp, const void* residual,
+                                  int32_t ldr, void* dx, usseg_stream_t stream) {
+  int rc = check_desc(d, false);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(dy && wp && dx, "null pointer");
+  USSEG_CHECK_ARG(!(d->flags & USSEG_OUT_F32) && d->Cout % 8 == 0, "dgrad needs bf16 dy with Cout % 8 == 0");
+  IgemmParams p = {};
+  p.x = (const bf16_t*)dy; p.w = (const bf16_t*)wp; p.y = dx; p.bias = nullptr; p.res = (const bf16_t*)residual; p.ldr = ldr;
+  p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
+  p.Hi = d->H; p.Wi = d->W; p.ldx = d->ldy; p.isy = p.isx = 1;
+  p.Ho = d->H; p.Wo = d->W; p.ldy = d->ldx; p.osy = p.osx = 1; p.oay = p.oax = 0;
+  p.cpt = d->Cout / 8;
+  const int k = d->ksize, half = k / 2;
+  p.ntaps = k * k;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) {
+      int t = kh * k + kw;  // y[p] uses x[p + off_t]  =>  dx[q] gathers dy[q - off_t] with the same W[t]
+      p.tap_dy[t] = (int16_t)(-(kh - half) * d->dilation);
+      p.tap_dx[t] = (int16_t)(-(kw - half) * d->dilation);
+      p.tap_w[t] = (int16_t)t;
+    }
+  p.nchunks = p.ntaps * p.cpt;
+  p.Nw = roundup(d->Cin, 16); p.Kw = p.ntaps * d->Cout; p.Nout = d->Cin;
+  p.act = USSEG_ACT_NONE; p.alpha = 0.f; p.out_f32 = 0; p.accumulate = (d->flags & USSEG_ACCUMULATE) ? 1 : 0;
+  return launch_igemm(p, (hipStream_t)stream);
+}
+
+// Conv2DTranspose stride 2 'same': out[2i + kh - pad] += x[i] * w[kh], pad = 0 (k=3, crop end) / 1 (k=4).
+extern "C" int usseg_tconv2d_fwd(const UssegConvDesc* d, const void* x, const void* wp, const float* bias, void* y,
+                                 usseg_stream_t stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(x && wp && y, "null pointer");
+  const int k = d->ksize, pad = (k == 4) ? 1 : 0;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      IgemmParams p = {};
+      p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.y = y; p.bias = bias; p.res = nullptr; p.ldr = 0;
+      p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
+      p.Hi = d->H; p.Wi = d->W; p.ldx = d->ldx; p.isy = p.isx = 1;
+      p.Ho = 2 * d->H; p.Wo = 2 * d->W; p.ldy = d->ldy; p.osy = p.osx = 2; p.oay = a; p.oax = b;
+      p.cpt = d->Cin / 8;
+      int nt = 0;
+      for (int kh = 0; kh < k; ++kh) {
+        if (((kh - pad) & 1) != a) continue;      // 2*i + kh - pad == 2*gy + a
+        int dyo = (a - (kh - pad)) / 2;           // i = gy + dyo
+        for (int kw = 0; kw < k; ++kw) {
+          if (((kw - pad) & 1) != b) continue;
+          int dxo = (b - (kw - pad)) / 2;
+          p.tap_dy[nt] = (int16_t)dyo; p.tap_dx[nt] = (int16_t)dxo; p.tap_w[nt] = (int16_t)(kh * k + kw);
+          ++nt;
+        }
+      }
+      p.ntaps = nt;
+      p.nchunks = nt * p.cpt;
+      p.Nw = roundup(d->Cout, 16); p.Kw = k * k * d->Cin; p.Nout = d->Cout;
+      p.act = d->act; p.alpha = d->alpha; p.out_f32 = (d->flags & USSEG_OUT_F32) ? 1 : 0; p.accumulate = 0;
+      rc = launch_igemm(p, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  return USSEG_OK;
+}
+
+// dx[i] = sum_k dy[2i + kh - pad] * w[kh]: a stride-2 gather over dy (2H x 2W).
+extern "C" int usseg_tconv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp, const void* residual,
+                                   int32_t ldr, void* dx, usseg_stream_t stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(dy && wp && dx, "null pointer");
+  USSEG_CHECK_ARG(!(d->flags & USSEG_OUT_F32) && d->Cout % 8 == 0, "tconv dgrad needs bf16 dy with Cout % 8 == 0");
+  const int k = d->ksize, pad = (k == 4) ? 1 : 0;
+  IgemmParams p = {};
+  p.x = (const bf16_t*)dy; p.w = (const bf16_t*)wp; p.y = dx; p.bias = nullptr; p.res = (const bf16_t*)residual; p.ldr = ldr;
+  p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
+  p.Hi = 2 * d->H; p.Wi = 2 * d->W; p.ldx = d->ldy; p.isy = p.isx = 2;
+  p.Ho = d->H; p.Wo = d->W; p.ldy = d->ldx; p.osy = p.osx = 1; p.oay = p.oax = 0;
+  p.cpt = d->Cout / 8;
+  p.ntaps = k * k;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) {
+      int t = kh * k + kw;
+      p.tap_dy[t] = (int16_t)(kh - pad); p.tap_dx[t] = (int16_t)(kw - pad); p.tap_w[t] = (int16_t)t;
+    }
+  p.nchunks = p.ntaps * p.cpt;
+  p.Nw = roundup(d->Cin, 16); p.Kw = p.ntaps * d->Cout; p.Nout = d->Cin;
+  p.act = USSEG_ACT_NONE; p.out_f32 = 0; p.accumulate = (d->flags & USSEG_ACCUMULATE) ? 1 : 0;
+  return launch_igemm(p, (hipStream_t)stream);
+}

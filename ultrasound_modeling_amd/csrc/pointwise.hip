@@ -1,0 +1,513 @@
+// HBM-bound kernels of the hot path for gfx950: normalisation+activation (LayerNorm per pixel / BatchNorm
+// inference affine) forward and backward, activation, 2x2 average pooling, channel-slice copies, input cast,
+// column sums, operand packing.  All activations are bf16 NHWC rows read and written 16 bytes (8 channels) per
+// lane; all arithmetic is fp32.
+//
+// "Row-chunk" mapping used by every kernel with a per-pixel or per-channel reduction: a pixel's Cphys/8 chunks
+// are spread over LPP = pow2 lanes of one wave (64/LPP pixels per wave, 4 waves per workgroup), so per-pixel
+// reductions are xor-shuffles inside LPP lanes and a lane keeps the SAME 8 channels for its whole grid-stride
+// loop, which makes per-channel sums register accumulators that are combined once at the end.
+#include "common.h"
+
+static inline int lanes_per_pixel(int chunks) {
+  int l = 1;
+  while (l < chunks) l <<= 1;
+  return l;
+}
+static inline unsigned grid_for(int64_t work_items, int per_block, int cap = 2048) {
+  int64_t g = cdiv64(work_items, per_block);
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// sum over the lanes that hold the same chunk (lane = chunk + LPP*slot) then one atomic per wave per channel
+__device__ __forceinline__ void wave_chunk_atomic(float* acc8, int LPP, int chunk, bool chunk_ok, float* dst, int C) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = acc8[j];
+    for (int msk = LPP; msk < 64; msk <<= 1) v += __shfl_xor(v, msk, 64);
+    acc8[j] = v;
+  }
+  const int lane = threadIdx.x & 63;
+  if (lane < LPP && chunk_ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = chunk * 8 + j;
+      if (c < C) atomicAdd(dst + c, acc8[j]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ norm + act
+struct NormParams {
+  const bf16_t* x; const bf16_t* dy; bf16_t* y; bf16_t* dx;
+  const float *gamma, *beta, *mean, *var;
+  float *dgamma, *dbeta;
+  int64_t M;
+  int32_t C, Cphys, ldx, ldy, lddy, lddx, G, Cg, mode, act, LPP;
+  float eps, alpha;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int LPP = p.LPP, ppw = 64 / LPP;
+  const int chunk = lane & (LPP - 1), slot = lane / LPP;
+  const int CH = p.Cphys >> 3;
+  const bool chunk_ok = chunk < CH;
+  const int c0 = chunk * 8;
+  // per-lane channel constants
+  float ga[8], be[8], mu_c[8], rs_c[8];
+  int grp[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int c = c0 + j;
+    bool ok = chunk_ok && c < p.C;
+    ga[j] = ok ? p.gamma[c] : 0.f;
+    be[j] = ok ? p.beta[c] : 0.f;
+    grp[j] = ok ? c / p.Cg : -1;
+    if (p.mode == 1) {
+      mu_c[j] = ok ? p.mean[c] : 0.f;
+      rs_c[j] = ok ? rsqrtf(p.var[c] + p.eps) : 0.f;
+    } else {
+      mu_c[j] = 0.f; rs_c[j] = 0.f;
+    }
+  }
+  float dga[8], dbe[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { dga[j] = 0.f; dbe[j] = 0.f; }
+  const float inv_cg = 1.f / (float)p.Cg;
+
+  const int64_t ppb = 4 * ppw;
+  for (int64_t base = (int64_t)blockIdx.x * ppb; base < p.M; base += (int64_t)gridDim.x * ppb) {
+    const int64_t m = base + wv * ppw + slot;
+    const bool valid = chunk_ok && m < p.M;
+    float xv[8];
+    if (valid) {
+      uint4 raw = *reinterpret_cast<const uint4*>(p.x + m * p.ldx + c0);
+      unpack8(raw, xv);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = 0.f;
+    }
+    float xh[8];  // normalised value
+    float rstd_g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.mode == 0) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) s[gi] += (grp[j] == gi) ? xv[j] : 0.f;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+        if (gi < p.G)
+          for (int msk = 1; msk < LPP; msk <<= 1) s[gi] += __shfl_xor(s[gi], msk, 64);
+      float d[8];
+      float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float mean = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) mean = (grp[j] == gi) ? s[gi] * inv_cg : mean;
+        d[j] = (grp[j] >= 0) ? xv[j] - mean : 0.f;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) ss[gi] += (grp[j] == gi) ? d[j] * d[j] : 0.f;
+      }
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+        if (gi < p.G) {
+          for (int msk = 1; msk < LPP; msk <<= 1) ss[gi] += __shfl_xor(ss[gi], msk, 64);
+          rstd_g[gi] = rsqrtf(ss[gi] * inv_cg + p.eps);
+        }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float r = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) r = (grp[j] == gi) ? rstd_g[gi] : r;
+        xh[j] = d[j] * r;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xh[j] = (xv[j] - mu_c[j]) * rs_c[j];
+    }
+
+    if (!BWD) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (grp[j] >= 0) ? apply_act(ga[j] * xh[j] + be[j], p.act, p.alpha) : 0.f;
+      if (valid) *reinterpret_cast<uint4*>(p.y + m * p.ldy + c0) = pack8(o);
+    } else {
+      float dyv[8];
+      if (valid) {
+        uint4 raw = *reinterpret_cast<const uint4*>(p.dy + m * p.lddy + c0);
+        unpack8(raw, dyv);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dyv[j] = 0.f;
+      }
+      float dxh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float pre = ga[j] * xh[j] + be[j];
+        float dh = (grp[j] >= 0) ? dyv[j] * act_grad(pre, p.act, p.alpha) : 0.f;
+        dga[j] += dh * xh[j];
+        dbe[j] += dh;
+        dxh[j] = dh * ga[j];
+      }
+      float o[8];
+      if (p.mode == 0) {
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            s1[gi] += (grp[j] == gi) ? dxh[j] : 0.f;
+            s2[gi] += (grp[j] == gi) ? dxh[j] * xh[j] : 0.f;
+          }
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+          if (gi < p.G)
+            for (int msk = 1; msk < LPP; msk <<= 1) {
+              s1[gi] += __shfl_xor(s1[gi], msk, 64);
+              s2[gi] += __shfl_xor(s2[gi], msk, 64);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a1 = 0.f, a2 = 0.f, r = 0.f;
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            a1 = (grp[j] == gi) ? s1[gi] * inv_cg : a1;
+            a2 = (grp[j] == gi) ? s2[gi] * inv_cg : a2;
+            r = (grp[j] == gi) ? rstd_g[gi] : r;
+          }
+          o[j] = r * (dxh[j] - a1 - xh[j] * a2);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = dxh[j] * rs_c[j];
+      }
+      if (valid) *reinterpret_cast<uint4*>(p.dx + m * p.lddx + c0) = pack8(o);
+    }
+  }
+  if (BWD) {
+    wave_chunk_atomic(dga, LPP, chunk, chunk_ok, p.dgamma, p.C);
+    wave_chunk_atomic(dbe, LPP, chunk, chunk_ok, p.dbeta, p.C);
+  }
+}
+
+static int norm_common(const UssegNormDesc* d, NormParams& p) {
+  USSEG_CHECK_ARG(d, "null descriptor");
+  USSEG_CHECK_ARG(d->C > 0 && d->Cphys % 8 == 0 && d->Cphys >= d->C && d->Cphys <= 512, "norm: C/Cphys out of range (Cphys <= 512, multiple of 8)");
+  USSEG_CHECK_ARG(d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->Cphys && d->ldy >= d->Cphys, "norm: bad strides");
+  USSEG_CHECK_ARG(d->mode == 0 || d->mode == 1, "norm: mode must be 0 (LN) or 1 (affine)");
+  int G = d->mode == 0 ? d->G : 1;
+  USSEG_CHECK_ARG(G >= 1 && G <= 4 && d->C % G == 0, "norm: 1 <= G <= 4 and C % G == 0");
+  p.M = d->M; p.C = d->C; p.Cphys = d->Cphys; p.G = G; p.Cg = d->mode == 0 ? d->C / G : d->C;
+  p.mode = d->mode; p.act = d->act; p.eps = d->eps; p.alpha = d->alpha;
+  p.LPP = lanes_per_pixel(d->Cphys / 8);
+  return USSEG_OK;
+}
+
+extern "C" int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const float* gamma, const float* beta,
+                                  const float* mean, const float* var, void* y, usseg_stream_t stream) {
+  NormParams p = {};
+  int rc = norm_common(d, p);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(x && y && gamma && beta && (d->mode == 0 || (mean && var)), "norm fwd: null pointer");
+  p.x = (const bf16_t*)x; p.y = (bf16_t*)y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
+  p.ldx = d->ldx; p.ldy = d->ldy;
+  if (p.M <= 0) return USSEG_OK;
+  int ppb = 4 * (64 / p.LPP);
+  hipLaunchKernelGGL(norm_act_kernel<false>, dim3(grid_for(p.M, ppb * 4)), dim3(256), 0, (hipStream_t)stream, p);
+  return usseg_check_launch("norm_act_fwd");
+}
+
+extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma,
+                                  const float* beta, const float* mean, const float* var, void* dx, float* dgamma,
+                                  float* dbeta, usseg_stream_t stream) {
+  NormParams p = {};
+  int rc = norm_common(d, p);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(x && dy && dx && gamma && beta && dgamma && dbeta && (d->mode == 0 || (mean && var)), "norm bwd: null pointer");
+  p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
+  p.dgamma = dgamma; p.dbeta = dbeta;
+  p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->ldx;
+  if (p.M <= 0) return USSEG_OK;
+  int ppb = 4 * (64 / p.LPP);
+  hipLaunchKernelGGL(norm_act_kernel<true>, dim3(grid_for(p.M, ppb * 8, 1024)), dim3(256), 0, (hipStream_t)stream, p);
+  return usseg_check_launch("norm_act_bwd");
+}
+
+// ------------------------------------------------------------------------------------------ column sums
+// MODE 0: out[c] += sum_m a[m][c]; MODE 1: out[c] += sum a, out2[c] += sum a^2
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* a, int64_t M, int C, int ld, int LPP, float* out, float* out2) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ppw = 64 / LPP, chunk = lane & (LPP - 1), slot = lane / LPP;
+  const bool chunk_ok = chunk * 8 < C;
+  float s[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; s2[j] = 0.f; }
+  const int64_t ppb = 4 * ppw;
+  for (int64_t base = (int64_t)blockIdx.x * ppb; base < M; base += (int64_t)gridDim.x * ppb) {
+    int64_t m = base + wv * ppw + slot;
+    if (chunk_ok && m < M) {
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(a + m * ld + chunk * 8), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += v[j]; if (MODE == 1) s2[j] += v[j] * v[j]; }
+    }
+  }
+  wave_chunk_atomic(s, LPP, chunk, chunk_ok, out, C);
+  if (MODE == 1) wave_chunk_atomic(s2, LPP, chunk, chunk_ok, out2, C);
+}
+
+extern "C" int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dy && db && C > 0 && ld % 8 == 0 && C <= 1024, "colsum: bad args");
+  if (M <= 0) return USSEG_OK;
+  // wide rows: process in slabs of 512 channels
+  for (int c0 = 0; c0 < C; c0 += 512) {
+    int cw = C - c0 < 512 ? C - c0 : 512;
+    int cwp = roundup(cw, 8);
+    int LPP = lanes_per_pixel(cwp / 8);
+    int ppb = 4 * (64 / LPP);
+    hipLaunchKernelGGL(colsum_kernel<0>, dim3(grid_for(M, ppb * 8, 512)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy + c0, M, cw, ld, LPP, db + c0, (float*)nullptr);
+  }
+  return usseg_check_launch("colsum");
+}
+
+extern "C" int usseg_channel_stats(const void* x, int64_t M, int32_t C, int32_t ldx, float* sum, float* sumsq,
+                                   usseg_stream_t stream) {
+  USSEG_CHECK_ARG(x && sum && sumsq && C > 0 && C <= 512 && ldx % 8 == 0, "channel_stats: bad args");
+  if (M <= 0) return USSEG_OK;
+  int LPP = lanes_per_pixel(roundup(C, 8) / 8);
+  int ppb = 4 * (64 / LPP);
+  hipLaunchKernelGGL(colsum_kernel<1>, dim3(grid_for(M, ppb * 8, 512)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, M, C, ldx, LPP, sum, sumsq);
+  return usseg_check_launch("channel_stats");
+}
+
+// ------------------------------------------------------------------------------------------ elementwise (chunk per thread)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t* x, int64_t M, int CH, int ldx, int ldy, int act, float alpha, bf16_t* y) {
+  const int64_t total = M * CH;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t m = i / CH;
+    int c0 = (int)(i - m * CH) * 8;
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c0), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], act, alpha);
+    *reinterpret_cast<uint4*>(y + m * ldy + c0) = pack8(v);
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* x, const bf16_t* dy, int64_t M, int CH, int ldx, int lddy, int lddx,
+                                                       int act, float alpha, bf16_t* dx) {
+  const int64_t total = M * CH;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t m = i / CH;
+    int c0 = (int)(i - m * CH) * 8;
+    float v[8], g[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c0), v);
+    unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + c0), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= act_grad(v[j], act, alpha);
+    *reinterpret_cast<uint4*>(dx + m * lddx + c0) = pack8(g);
+  }
+}
+extern "C" int usseg_act_fwd(const void* x, int64_t M, int32_t C, int32_t ldx, int32_t ldy, int32_t act, float alpha, void* y,
+                             usseg_stream_t stream) {
+  USSEG_CHECK_ARG(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "act_fwd: bad args");
+  if (M <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(M * (C / 8), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, M, C / 8, ldx, ldy, act, alpha, (bf16_t*)y);
+  return usseg_check_launch("act_fwd");
+}
+extern "C" int usseg_act_bwd(const void* x, const void* dy, int64_t M, int32_t C, int32_t ldx, int32_t lddy, int32_t lddx,
+                             int32_t act, float alpha, void* dx, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(x && dy && dx && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "act_bwd: bad args");
+  if (M <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(M * (C / 8), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)dy, M, C / 8, ldx, lddy, lddx, act, alpha, (bf16_t*)dx);
+  return usseg_check_launch("act_bwd");
+}
+
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16_t* x, int B, int Ho, int Wo, int CH, int ldx, int ldy, bf16_t* y) {
+  const int64_t total = (int64_t)B * Ho * Wo * CH;
+  const int Wi = 2 * Wo, Hi = 2 * Ho;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t pix = i / CH;
+    int c0 = (int)(i - pix * CH) * 8;
+    int ox = (int)(pix % Wo);
+    int64_t t = pix / Wo;
+    int oy = (int)(t % Ho);
+    int b = (int)(t / Ho);
+    const bf16_t* s = x + (((int64_t)b * Hi + 2 * oy) * Wi + 2 * ox) * ldx + c0;
+    float a[8], v[8];
+    unpack8(*reinterpret_cast<const uint4*>(s), a);
+    unpack8(*reinterpret_cast<const uint4*>(s + ldx), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += v[j];
+    unpack8(*reinterpret_cast<const uint4*>(s + (int64_t)Wi * ldx), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += v[j];
+    unpack8(*reinterpret_cast<const uint4*>(s + (int64_t)Wi * ldx + ldx), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (a[j] + v[j]) * 0.25f;
+    *reinterpret_cast<uint4*>(y + pix * ldy + c0) = pack8(a);
+  }
+}
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16_t* dy, int B, int H, int W, int CH, int lddy, int lddx,
+                                                            const bf16_t* add, int ldadd, bf16_t* dx) {
+  const int64_t total = (int64_t)B * H * W * CH;
+  const int Ho = H / 2, Wo = W / 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t pix = i / CH;
+    int c0 = (int)(i - pix * CH) * 8;
+    int x_ = (int)(pix % W);
+    int64_t t = pix / W;
+    int y_ = (int)(t % H);
+    int b = (int)(t / H);
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + (((int64_t)b * Ho + (y_ >> 1)) * Wo + (x_ >> 1)) * lddy + c0), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= 0.25f;
+    if (add) {
+      float a[8];
+      unpack8(*reinterpret_cast<const uint4*>(add + pix * ldadd + c0), a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += a[j];
+    }
+    *reinterpret_cast<uint4*>(dx + pix * lddx + c0) = pack8(v);
+  }
+}
+extern "C" int usseg_avgpool2_fwd(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy, void* y,
+                                  usseg_stream_t stream) {
+  USSEG_CHECK_ARG(x && y && H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "avgpool2_fwd: bad args");
+  int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
+  if (total <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(grid_for(total, 256 * 2, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, B, H / 2, W / 2, C / 8, ldx, ldy, (bf16_t*)y);
+  return usseg_check_launch("avgpool2_fwd");
+}
+extern "C" int usseg_avgpool2_bwd(const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t lddy, int32_t lddx,
+                                  const void* add, int32_t ldadd, void* dx, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dy && dx && H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "avgpool2_bwd: bad args");
+  int64_t total = (int64_t)B * H * W * (C / 8);
+  if (total <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total, 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, B, H, W, C / 8, lddy, lddx, (const bf16_t*)add, ldadd, (bf16_t*)dx);
+  return usseg_check_launch("avgpool2_bwd");
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const bf16_t* src, int64_t M, int CH, int lds_, bf16_t* dst, int ldd, int accumulate) {
+  const int64_t total = M * CH;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t m = i / CH;
+    int c0 = (int)(i - m * CH) * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(src + m * lds_ + c0);
+    if (accumulate) {
+      float a[8], b[8];
+      unpack8(v, a);
+      unpack8(*reinterpret_cast<const uint4*>(dst + m * ldd + c0), b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += b[j];
+      v = pack8(a);
+    }
+    *reinterpret_cast<uint4*>(dst + m * ldd + c0) = v;
+  }
+}
+extern "C" int usseg_copy_channels(const void* src, int64_t M, int32_t C, int32_t lds_, void* dst, int32_t ldd, int32_t accumulate,
+                                   usseg_stream_t stream) {
+  USSEG_CHECK_ARG(src && dst && C % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "copy_channels: bad args");
+  if (M <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(M * (C / 8), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, M, C / 8, lds_, (bf16_t*)dst, ldd, accumulate);
+  return usseg_check_launch("copy_channels");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_input_kernel(const T* src, int64_t M, int C, bf16_t* dst, int Cphys) {
+  const int CH = Cphys / 8;
+  const int64_t total = M * CH;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t m = i / CH;
+    int c0 = (int)(i - m * CH) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? (float)src[m * C + c0 + j] : 0.f;
+    *reinterpret_cast<uint4*>(dst + m * Cphys + c0) = pack8(v);
+  }
+}
+extern "C" int usseg_cast_input(const void* src, int32_t src_is_f64, int64_t M, int32_t C, void* dst, int32_t Cphys,
+                                usseg_stream_t stream) {
+  USSEG_CHECK_ARG(src && dst && C > 0 && Cphys % 8 == 0 && Cphys >= C, "cast_input: bad args");
+  if (M <= 0) return USSEG_OK;
+  dim3 grid(grid_for(M * (Cphys / 8), 256 * 2, 4096));
+  if (src_is_f64)
+    hipLaunchKernelGGL(cast_input_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)src, M, C, (bf16_t*)dst, Cphys);
+  else
+    hipLaunchKernelGGL(cast_input_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, M, C, (bf16_t*)dst, Cphys);
+  return usseg_check_launch("cast_input");
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* src, int64_t M, int C, int lds_, float* dst) {
+  const int64_t total = M * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t m = i / C;
+    int c = (int)(i - m * C);
+    dst[i] = bf2f(src[m * lds_ + c]);
+  }
+}
+extern "C" int usseg_cast_bf16_to_f32(const void* src, int64_t M, int32_t C, int32_t lds_, float* dst, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(src && dst && C > 0, "cast_bf16_to_f32: bad args");
+  if (M <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(M * C, 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, M, C, lds_, dst);
+  return usseg_check_launch("cast_bf16_to_f32");
+}
+
+// ------------------------------------------------------------------------------------------ operand packing
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, int64_t sT, int64_t sN, int64_t sK, int T, int Nn, int Kk,
+                                                           bf16_t* dst, int Kw, int tap_stride, int n_off, int k_off) {
+  const int64_t total = (int64_t)T * Nn * Kk;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int k = (int)(i % Kk);
+    int64_t r = i / Kk;
+    int n = (int)(r % Nn);
+    int t = (int)(r / Nn);
+    dst[(int64_t)(n_off + n) * Kw + (int64_t)t * tap_stride + k_off + k] = f2bf(src[t * sT + n * sN + k * sK]);
+  }
+}
+extern "C" int usseg_pack_weight(const float* src, int64_t sT, int64_t sN, int64_t sK, int32_t T, int32_t Nn, int32_t Kk, void* dst,
+                                 int32_t Kw, int32_t tap_stride, int32_t n_off, int32_t k_off, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(src && dst && T > 0 && Nn > 0 && Kk > 0 && k_off + Kk <= tap_stride && T * tap_stride <= Kw, "pack_weight: bad args");
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((int64_t)T * Nn * Kk, 256, 1024)), dim3(256), 0, (hipStream_t)stream, src, sT,
+                     sN, sK, T, Nn, Kk, (bf16_t*)dst, Kw, tap_stride, n_off, k_off);
+  return usseg_check_launch("pack_weight");
+}
+
+// scratch is [T][Mrows][Ncols] with m = input-channel (K side of the forward operand), n = output channel
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* scratch, int Mrows, int Ncols, int T, int Nn, int Kk, int n_off,
+                                                            int k_off, float* dst, int64_t sT, int64_t sN, int64_t sK, float scale,
+                                                            int accumulate) {
+  const int64_t total = (int64_t)T * Nn * Kk;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int n = (int)(i % Nn);
+    int64_t r = i / Nn;
+    int k = (int)(r % Kk);
+    int t = (int)(r / Kk);
+    float v = scale * scratch[((int64_t)t * Mrows + k_off + k) * Ncols + n_off + n];
+    float* d = dst + t * sT + n * sN + k * sK;
+    *d = accumulate ? *d + v : v;
+  }
+}
+extern "C" int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t Ncols, int32_t T, int32_t Nn, int32_t Kk, int32_t n_off,
+                                  int32_t k_off, float* dst, int64_t sT, int64_t sN, int64_t sK, float scale, int32_t accumulate,
+                                  usseg_stream_t stream) {
+  USSEG_CHECK_ARG(scratch && dst && T > 0 && Nn > 0 && Kk > 0 && n_off + Nn <= Ncols && k_off + Kk <= Mrows, "unpack_wgrad: bad args");
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for((int64_t)T * Nn * Kk, 256, 1024)), dim3(256), 0, (hipStream_t)stream, scratch,
+                     Mrows, Ncols, T, Nn, Kk, n_off, k_off, dst, sT, sN, sK, scale, accumulate);
+  return usseg_check_launch("unpack_wgrad");
+}

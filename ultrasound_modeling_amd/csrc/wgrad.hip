@@ -1,0 +1,177 @@
+// Weight-gradient GEMM on bf16 MFMA for gfx950:
+//   dW[t][m][n] += sum_{pixels (b,gy,gx)} A[b, gy*asy+ady_t, gx*asx+adx_t, m] * Bm[b, gy*bsy+bdy_t, gx*bsx+bdx_t, n]
+// (Conv2D: A = x shifted by the tap, Bm = dy.  Conv2DTranspose: A = x, Bm = dy read with stride 2.)
+// The contraction runs over PIXELS, which is the slow (row) axis of both NHWC operands, so both MFMA operands
+// need a transpose: tiles are staged row-major [32 pixels][64 channels] in LDS and the fragments are read with
+// ds_read_b64_tr_b16 (hardware 4x16 transpose), two reads per 8-deep K fragment.
+// Grid: x = pixel split (split-K), y = (m-tile, n-tile), z = tap.  Each workgroup reduces its pixel range into a
+// 64x64 fp32 tile (4 waves as 2x2, 2x2 MFMA 16x16x32 tiles each) and adds it to the fp32 scratch with atomics.
+#include "common.h"
+
+struct WgradParams {
+  const bf16_t* a;
+  const bf16_t* b;
+  float* out;  // [ntaps][Ma][Nb]
+  int32_t B, Hg, Wg;
+  int64_t M;
+  int32_t Ha, Wa, lda, asy, asx;
+  int32_t Hb, Wb, ldb, bsy, bsx;
+  int32_t Ma, Nb;
+  int32_t mtiles, ntiles;
+  int64_t chunk;  // pixels per split (multiple of 32)
+  int16_t ady[16], adx[16], bdy[16], bdx[16];
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  constexpr int BK = 32, TS = 72;  // LDS row stride in elements (128 B data + 16 B pad)
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][BK * TS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t = blockIdx.z;
+  const int mt = blockIdx.y / p.ntiles, nt = blockIdx.y - mt * p.ntiles;
+  const int m0 = mt * 64, n0 = nt * 64;
+  const int64_t k_begin = (int64_t)blockIdx.x * p.chunk;
+  int64_t k_end = k_begin + p.chunk;
+  if (k_end > p.M) k_end = p.M;
+  if (k_begin >= k_end) return;
+  const int ady = p.ady[t], adx = p.adx[t], bdy = p.bdy[t], bdx = p.bdx[t];
+  const int HWg = p.Hg * p.Wg;
+
+  const int pr = tid >> 3, cc = tid & 7;  // staging: pixel row in tile, 8-channel chunk
+  const bool a_ok = (m0 + cc * 8) < p.Ma, b_ok = (n0 + cc * 8) < p.Nb;
+  uint4 ra, rb;
+  auto load_step = [&](int64_t kbase) {
+    int64_t m = kbase + pr;
+    ra = make_uint4(0, 0, 0, 0);
+    rb = ra;
+    if (m < k_end) {
+      int mm = (int)m;
+      int b = mm / HWg;
+      int rem = mm - b * HWg;
+      int gy = rem / p.Wg, gx = rem - gy * p.Wg;
+      int ay = gy * p.asy + ady, ax = gx * p.asx + adx;
+      int by = gy * p.bsy + bdy, bx = gx * p.bsx + bdx;
+      bool in_a = (unsigned)ay < (unsigned)p.Ha && (unsigned)ax < (unsigned)p.Wa;
+      bool in_b = (unsigned)by < (unsigned)p.Hb && (unsigned)bx < (unsigned)p.Wb;
+      if (in_a && in_b) {  // a product with a zero operand contributes nothing: skip both loads
+        if (a_ok) ra = *reinterpret_cast<const uint4*>(p.a + ((int64_t)(b * p.Ha + ay) * p.Wa + ax) * p.lda + m0 + cc * 8);
+        if (b_ok) rb = *reinterpret_cast<const uint4*>(p.b + ((int64_t)(b * p.Hb + by) * p.Wb + bx) * p.ldb + n0 + cc * 8);
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+    *reinterpret_cast<uint4*>(&lds[buf][0][pr * TS + cc * 8]) = ra;
+    *reinterpret_cast<uint4*>(&lds[buf][1][pr * TS + cc * 8]) = rb;
+  };
+
+  const int wm = wv >> 1, wn = wv & 1;  // wave's 32x32 sub-tile
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addressing: 16-lane group g reads K rows 8g..8g+7 (two reads of 4 rows); lane 4q+pp of the
+  // group supplies the address of row q, columns 4pp..4pp+3 and receives column (lane&15), rows 0..3.
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  auto frag = [&](const bf16_t* tile, int col0) -> bf16x8_t {
+    const bf16_t* a0 = tile + (8 * g + tq) * TS + col0 + 4 * tp;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * TS));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  load_step(k_begin);
+  store_step(0);
+  __syncthreads();
+  int it = 0;
+  for (int64_t kb = k_begin; kb < k_end; kb += BK, ++it) {
+    const int cur = it & 1;
+    const bool more = (kb + BK) < k_end;
+    if (more) load_step(kb + BK);
+    bf16x8_t af[2], bfr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      af[i] = frag(&lds[cur][0][0], wm * 32 + i * 16);
+      bfr[i] = frag(&lds[cur][1][0], wn * 32 + i * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (more) store_step(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[row = m_local = 4*(lane>>4)+j][col = n_local = lane&15]
+  float* out = p.out + (int64_t)t * p.Ma * p.Nb;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int n = n0 + wn * 32 + j * 16 + li;
+      if (n >= p.Nb) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = m0 + wm * 32 + i * 16 + g * 4 + r;
+        if (m < p.Ma) atomicAdd(out + (int64_t)m * p.Nb + n, acc[i][j][r]);
+      }
+    }
+}
+
+static int launch_wgrad(WgradParams& p, int ntaps, hipStream_t s) {
+  p.mtiles = (p.Ma + 63) / 64;
+  p.ntiles = (p.Nb + 63) / 64;
+  int64_t tiles = (int64_t)p.mtiles * p.ntiles * ntaps;
+  // enough splits to give every CU a few workgroups, but at least 256 pixels of work per split
+  int64_t want = (2048 + tiles - 1) / tiles;
+  int64_t max_splits = cdiv64(p.M, 256);
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  p.chunk = cdiv64(cdiv64(p.M, want), 32) * 32;
+  int64_t splits = cdiv64(p.M, p.chunk);
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)splits, (unsigned)(p.mtiles * p.ntiles), (unsigned)ntaps), dim3(256), 0, s, p);
+  return usseg_check_launch("wgrad");
+}
+
+extern "C" int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && x && dy && dw, "null pointer");
+  USSEG_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "channels must be multiples of 8");
+  USSEG_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "conv ksize must be 1 or 3");
+  WgradParams p = {};
+  p.a = (const bf16_t*)x; p.b = (const bf16_t*)dy; p.out = dw;
+  p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
+  p.Ha = d->H; p.Wa = d->W; p.lda = d->ldx; p.asy = p.asx = 1;
+  p.Hb = d->H; p.Wb = d->W; p.ldb = d->ldy; p.bsy = p.bsx = 1;
+  p.Ma = d->Cin; p.Nb = d->Cout;
+  const int k = d->ksize, half = k / 2;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) {
+      int t = kh * k + kw;
+      p.ady[t] = (int16_t)((kh - half) * d->dilation); p.adx[t] = (int16_t)((kw - half) * d->dilation);
+      p.bdy[t] = 0; p.bdx[t] = 0;
+    }
+  return launch_wgrad(p, k * k, (hipStream_t)stream);
+}
+
+extern "C" int usseg_tconv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && x && dy && dw, "null pointer");
+  USSEG_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "channels must be multiples of 8");
+  USSEG_CHECK_ARG(d->ksize == 3 || d->ksize == 4, "tconv ksize must be 3 or 4");
+  const int k = d->ksize, pad = (k == 4) ? 1 : 0;
+  WgradParams p = {};
+  p.a = (const bf16_t*)x; p.b = (const bf16_t*)dy; p.out = dw;
+  p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
+  p.Ha = d->H; p.Wa = d->W; p.lda = d->ldx; p.asy = p.asx = 1;
+  p.Hb = 2 * d->H; p.Wb = 2 * d->W; p.ldb = d->ldy; p.bsy = p.bsx = 2;
+  p.Ma = d->Cin; p.Nb = d->Cout;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) {
+      int t = kh * k + kw;
+      p.ady[t] = 0; p.adx[t] = 0;
+      p.bdy[t] = (int16_t)(kh - pad); p.bdx[t] = (int16_t)(kw - pad);
+    }
+  return launch_wgrad(p, k * k, (hipStream_t)stream);
+}

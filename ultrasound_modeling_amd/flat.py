@@ -1,0 +1,119 @@
+"""Flat parameter / gradient storage and the clip-by-global-norm + Adam step.
+
+All trainable variables of a model live in ONE fp32 device buffer (and their gradients, Adam moments in
+three more of the same shape), so that
+  * the global gradient norm, the clip and the Adam update are one kernel each
+    (VisionTransformer.py:244-245; TBI_ResNest.py:46),
+  * the data-parallel gradient exchange is ONE RCCL all-reduce over the flat gradient buffer
+    (MainParallel.py:130 -> apply_gradients under MirroredStrategy),
+  * kernels accumulate parameter gradients straight into the flat gradient buffer.
+Every variable starts on a 32-byte boundary and is followed by zero padding up to a multiple of 8 floats, so
+kernels may read per-channel vectors up to the physical (padded) channel count.  Modules may ask for several
+variables to be laid out back to back ("adjacent groups", used by the grouped split-attention kernels).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+class FlatParams:
+    def __init__(self, module: nn.Module, device):
+        self.device = torch.device(device)
+        named = list(module.named_parameters())
+        self.names = [n for n, _ in named]
+        params = [p for _, p in named]
+        pid = {id(p): i for i, p in enumerate(params)}
+        offsets: Dict[int, int] = {}
+        off = 0
+        # adjacency groups first
+        for m in module.modules():
+            fn = getattr(m, "adjacent_params", None)
+            if fn is None:
+                continue
+            for group, extra_pad in fn():
+                for p in group:
+                    assert id(p) in pid and id(p) not in offsets, "parameter in two adjacency groups"
+                    offsets[id(p)] = off
+                    off += p.numel()
+                off = _pad8(off + extra_pad)
+        for p in params:
+            if id(p) in offsets:
+                continue
+            offsets[id(p)] = off
+            off = _pad8(off + p.numel())
+        self.total = _pad8(off)
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.flat)
+        self.params = params
+        self.offsets = [offsets[id(p)] for p in params]
+        for p, o in zip(params, self.offsets):
+            n = p.numel()
+            view = self.flat[o:o + n].view(p.shape)
+            view.copy_(p.data.to(torch.float32))
+            p.data = view
+            p.requires_grad_(False)
+            p.grad = self.grad[o:o + n].view(p.shape)
+        for m in module.modules():
+            for k, b in list(m._buffers.items()):
+                if b is not None:
+                    m._buffers[k] = b.to(self.device)
+        self.n_trainable = sum(p.numel() for p in params)
+        for m in module.modules():
+            fn = getattr(m, "on_finalize", None)
+            if fn is not None:
+                fn(self.device)
+
+    def zero_grad(self):
+        ops.fill_f32(self.grad, 0.0)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {n: p.data.detach().clone() for n, p in zip(self.names, self.params)}
+
+
+class AdamClip:
+    """tf.clip_by_global_norm(grads, clip) followed by tf.optimizers.Adam(lr) (Keras defaults: b1 .9, b2 .999, eps 1e-7).
+
+    ``clip_norm=None`` disables clipping (TBI_ResNest.py:46 applies raw gradients).
+    The step counter and the bias-corrected learning rate live on the device so that a captured HIP graph of the
+    whole training step can be replayed.
+    """
+
+    def __init__(self, flat: FlatParams, lr: float = 1e-3, clip_norm: Optional[float] = 1.0, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.flat, self.lr, self.clip_norm = flat, float(lr), clip_norm
+        self.b1, self.b2, self.eps = beta1, beta2, eps
+        dev = flat.device
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_t_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def global_norm_sq(self):
+        ops.fill_f32(self.sumsq, 0.0)
+        ops.sumsq(self.flat.grad, self.sumsq)
+        return self.sumsq
+
+    def clip_local(self):
+        """Per-replica clip, BEFORE the data-parallel all-reduce (VisionTransformer.py:244 precedes :245)."""
+        if self.clip_norm is not None:
+            self.global_norm_sq()
+            ops.scale_by_clip(self.flat.grad, self.sumsq, float(self.clip_norm))
+
+    def apply(self, already_clipped: bool = False):
+        ops.adam_advance(self.step_dev, self.lr_t_dev, self.lr, self.b1, self.b2)
+        clip = 0.0
+        if self.clip_norm is not None and not already_clipped:
+            self.global_norm_sq()
+            clip = float(self.clip_norm)
+        ops.adam_clip_step(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq, clip, self.lr_t_dev, self.b1, self.b2,
+                           self.eps)

@@ -1,0 +1,273 @@
+"""Keras-shaped layers (NHWC, Keras weight layouts and names) on top of the gfx950 kernels.
+
+These mirror the tf.keras.layers the reference instantiates (Conv2D, Conv2DTranspose, LayerNormalization,
+BatchNormalization, LeakyReLU/ELU/ReLU, AveragePooling2D) with explicit ``forward`` / ``backward`` methods: the
+reference's GradientTape (VisionTransformer.py:237-243) is replaced by each layer saving what its backward needs
+and the model calling ``backward`` in reverse order; parameter gradients are accumulated by the kernels directly
+into the flat gradient buffer (flat.py).
+
+Activations are bf16 ``[B,H,W,Cphys]`` with Cphys = roundup(C, 8) and zero pad channels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_ELU, ACT_LRELU, ACT_NONE, ACT_RELU, BF16, roundup
+
+KERAS_LRELU_ALPHA = 0.3   # tf.keras.layers.LeakyReLU() default
+KERAS_ELU_ALPHA = 1.0
+KERAS_BN_EPS = 1e-3
+KERAS_LN_EPS = 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ workspace
+class _Workspace:
+    """Grow-only fp32 scratch shared by all layers of a device (wgrad scratch)."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, device, nfloats: int) -> torch.Tensor:
+        key = str(device)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nfloats:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("workspace grew during graph capture: run one eager step first")
+            buf = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
+            cls._bufs[key] = buf
+        return buf[:nfloats]
+
+
+# ------------------------------------------------------------------------------------------------ initialisers
+def he_normal_(t: torch.Tensor, fan_in: int, gen: Optional[torch.Generator] = None):
+    """tf.keras.initializers.HeNormal: truncated normal (+-2 sigma), variance 2/fan_in."""
+    std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
+    torch.nn.init.trunc_normal_(t, 0.0, 1.0, -2.0, 2.0, generator=gen)
+    return t.mul_(std)
+
+
+def glorot_uniform_(t: torch.Tensor, fan_in: int, fan_out: int, gen: Optional[torch.Generator] = None):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return t.uniform_(-lim, lim, generator=gen)
+
+
+# ------------------------------------------------------------------------------------------------ activations (markers)
+class LeakyReLU(nn.Module):
+    """tf.keras.layers.LeakyReLU(): fused into the producing kernel by the parent; standalone call is supported."""
+    act, alpha = ACT_LRELU, KERAS_LRELU_ALPHA
+
+    def forward(self, x):
+        self._x = x
+        return ops.act_fwd(x, torch.empty_like(x), self.act, self.alpha)
+
+    def backward(self, dy):
+        return ops.act_bwd(self._x, dy, torch.empty_like(dy), self.act, self.alpha)
+
+
+class ELU(LeakyReLU):
+    act, alpha = ACT_ELU, KERAS_ELU_ALPHA
+
+
+class ReLU(LeakyReLU):
+    act, alpha = ACT_RELU, 0.0
+
+
+class AveragePooling2D(nn.Module):
+    """tf.keras.layers.AveragePooling2D(pool_size=2, strides=2)."""
+
+    def forward(self, x, out=None):
+        B, H, W, C, _ = ops.geom(x)
+        out = out if out is not None else ops.new_act(B, H // 2, W // 2, C, x.device)
+        self._shape = (B, H, W, C)
+        return ops.avgpool2_fwd(x, out)
+
+    def backward(self, dy, add=None, dx=None):
+        B, H, W, C = self._shape
+        dx = dx if dx is not None else ops.new_act(B, H, W, C, dy.device)
+        return ops.avgpool2_bwd(dy, dx, add)
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+class Conv2D(nn.Module):
+    """tf.keras.layers.Conv2D(filters, k, strides=1, padding='SAME', dilation_rate=d), kernel [k,k,Cin,Cout]."""
+    transposed = False
+
+    def __init__(self, in_channels: int, filters: int, kernel_size: int, dilation_rate: int = 1, init: str = "he"):
+        super().__init__()
+        k = kernel_size
+        self.cin, self.cout, self.k, self.dil = in_channels, filters, k, dilation_rate
+        self.cin_p, self.cout_p = roundup(in_channels, 8), roundup(filters, 8)
+        self.kernel = nn.Parameter(torch.empty(self._kshape()))
+        self.bias = nn.Parameter(torch.zeros(filters))
+        fan_in, fan_out = self._fans()
+        if init == "he":
+            he_normal_(self.kernel.data, fan_in)
+        else:
+            glorot_uniform_(self.kernel.data, fan_in, fan_out)
+        self.wp_f = self.wp_d = None
+
+    def _kshape(self):
+        return (self.k, self.k, self.cin, self.cout)
+
+    def _fans(self):
+        return self.k * self.k * self.cin, self.k * self.k * self.cout
+
+    # strides (in floats) of the Keras kernel seen as [tap][in][out]
+    def _strides_tio(self):
+        return self.cin * self.cout, self.cout, 1
+
+    def on_finalize(self, device):
+        T = self.k * self.k
+        self.wp_f = torch.zeros((roundup(self.cout_p, 16), T * self.cin_p), dtype=BF16, device=device)
+        self.wp_d = torch.zeros((roundup(self.cin_p, 16), T * self.cout_p), dtype=BF16, device=device)
+        self.repack()
+
+    def repack(self):
+        """fp32 master kernel -> bf16 packed operands for the forward and the backward-data GEMMs."""
+        T = self.k * self.k
+        sT, sI, sO = self._strides_tio()
+        # forward: rows n = out channel, K = tap*cin_p + ci
+        ops.pack_weight(self.kernel.data, sT, sO, sI, T, self.cout, self.cin, self.wp_f, T * self.cin_p, self.cin_p)
+        # dgrad: rows n = in channel, K = tap*cout_p + co
+        ops.pack_weight(self.kernel.data, sT, sI, sO, T, self.cin, self.cout, self.wp_d, T * self.cout_p, self.cout_p)
+
+    def forward(self, x, out=None, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False, use_bias=True):
+        B, H, W, C, _ = ops.geom(x)
+        assert C == self.cin_p, f"expected {self.cin_p} physical input channels, got {C}"
+        if out is None:
+            out = (torch.empty((B, H, W, roundup(self.cout, 4)), dtype=torch.float32, device=x.device)
+                   if out_f32 else ops.new_act(B, H, W, self.cout_p, x.device))
+        self._x = x
+        return ops.conv2d_fwd(x, self.wp_f, self.bias.data if use_bias else None, self.k, self.dil, out, act, alpha, residual, out_f32)
+
+    def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False):
+        """dy: gradient w.r.t. the conv output (before any fused activation).  Accumulates kernel/bias grads."""
+        x = self._x
+        self._wgrad(x, dy)
+        ops.colsum(dy, self.bias.grad, self.cout)
+        if not need_dx:
+            return None
+        B, H, W, _, _ = ops.geom(x)
+        dx = dx if dx is not None else ops.new_act(B, H, W, self.cin_p, dy.device)
+        return ops.conv2d_dgrad(dy, self.wp_d, self.k, self.dil, dx, dx_residual, accumulate_dx)
+
+    def _wgrad(self, x, dy):
+        T = self.k * self.k
+        if self.cin_p == self.cin and self.cout_p == self.cout:
+            ops.conv2d_wgrad(x, dy, self.k, self.dil, self.kernel.grad)   # Keras layout == [T][Cin][Cout]: accumulate in place
+            return
+        scratch = _Workspace.get(dy.device, T * self.cin_p * self.cout_p)
+        ops.fill_f32(scratch, 0.0)
+        ops.conv2d_wgrad(x, dy, self.k, self.dil, scratch)
+        sT, sI, sO = self._strides_tio()
+        ops.unpack_wgrad(scratch, self.cin_p, self.cout_p, T, self.cout, self.cin, 0, 0, self.kernel.grad, sT, sO, sI)
+
+
+class Conv2DTranspose(Conv2D):
+    """tf.keras.layers.Conv2DTranspose(filters, k, strides=2, padding='same'), kernel [k,k,Cout,Cin], k in (3,4)."""
+    transposed = True
+
+    def __init__(self, in_channels: int, filters: int, kernel_size: int, init: str = "he"):
+        super().__init__(in_channels, filters, kernel_size, 1, init)
+
+    def _kshape(self):
+        return (self.k, self.k, self.cout, self.cin)
+
+    def _fans(self):  # Keras computes fans from shape[-2] (in) / shape[-1] (out) of [k,k,Cout,Cin]
+        return self.k * self.k * self.cout, self.k * self.k * self.cin
+
+    def _strides_tio(self):
+        return self.cin * self.cout, 1, self.cin
+
+    def forward(self, x, out=None, act=ACT_NONE, alpha=0.0, out_f32=False, use_bias=True):
+        B, H, W, C, _ = ops.geom(x)
+        assert C == self.cin_p
+        if out is None:
+            out = (torch.empty((B, 2 * H, 2 * W, roundup(self.cout, 4)), dtype=torch.float32, device=x.device)
+                   if out_f32 else ops.new_act(B, 2 * H, 2 * W, self.cout_p, x.device))
+        self._x = x
+        return ops.tconv2d_fwd(x, self.wp_f, self.bias.data if use_bias else None, self.k, out, act, alpha, out_f32)
+
+    def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False):
+        x = self._x
+        T = self.k * self.k
+        scratch = _Workspace.get(dy.device, T * self.cin_p * self.cout_p)
+        ops.fill_f32(scratch, 0.0)
+        ops.tconv2d_wgrad(x, dy, self.k, scratch)
+        sT, sI, sO = self._strides_tio()
+        ops.unpack_wgrad(scratch, self.cin_p, self.cout_p, T, self.cout, self.cin, 0, 0, self.kernel.grad, sT, sO, sI)
+        ops.colsum(dy, self.bias.grad, self.cout)
+        if not need_dx:
+            return None
+        B, H, W, _, _ = ops.geom(x)
+        dx = dx if dx is not None else ops.new_act(B, H, W, self.cin_p, dy.device)
+        return ops.tconv2d_dgrad(dy, self.wp_d, self.k, dx, dx_residual, accumulate_dx)
+
+
+# ------------------------------------------------------------------------------------------------ normalisation
+class LayerNormalization(nn.Module):
+    """tf.keras.layers.LayerNormalization(axis=-1, epsilon=1e-3): per pixel over channels; optional fused activation."""
+    mode = 0
+
+    def __init__(self, channels: int, epsilon: float = KERAS_LN_EPS):
+        super().__init__()
+        self.C, self.eps = channels, epsilon
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+
+    def _stats(self):
+        return None, None
+
+    def forward(self, x, act=ACT_NONE, alpha=0.0, out=None):
+        out = out if out is not None else torch.empty_like(x)
+        self._x, self._act = x, (act, alpha)
+        mean, var = self._stats()
+        return ops.norm_act_fwd(x, self.C, self.gamma.data, self.beta.data, out, self.mode, 1, self.eps, act, alpha, mean, var)
+
+    def backward(self, dy, dx=None):
+        x = self._x
+        act, alpha = self._act
+        dx = dx if dx is not None else torch.empty_like(x)
+        mean, var = self._stats()
+        return ops.norm_act_bwd(x, dy, self.C, self.gamma.data, self.beta.data, dx, self.gamma.grad, self.beta.grad, self.mode,
+                                1, self.eps, act, alpha, mean, var)
+
+
+class BatchNormalization(LayerNormalization):
+    """tf.keras.layers.BatchNormalization(axis=-1, momentum=0.99, epsilon=1e-3).
+
+    As the reference is driven the layer runs in INFERENCE mode: a per-channel affine with the
+    moving statistics, gamma/beta trainable.  ``training_mode=True`` switches to batch statistics (two-pass) and
+    updates the moving statistics with momentum 0.99.
+    """
+    mode = 1
+
+    def __init__(self, channels: int, epsilon: float = KERAS_BN_EPS, momentum: float = 0.99):
+        super().__init__(channels, epsilon)
+        self.momentum = momentum
+        self.training_mode = False
+        cp = roundup(channels, 8)
+        self.register_buffer("moving_mean_p", torch.zeros(cp))
+        self.register_buffer("moving_variance_p", torch.ones(cp))
+
+    @property
+    def moving_mean(self):
+        return self.moving_mean_p[:self.C]
+
+    @property
+    def moving_variance(self):
+        return self.moving_variance_p[:self.C]
+
+    def _stats(self):
+        if self.training_mode:
+            return self._bmean, self._bvar
+        return self.moving_mean_p, self.moving_variance_p
+
+    def forward(self, x, act=ACT_NONE, alpha=0.0, out=None):
+        if self.training_mode:
+            raise NotImplementedError("BatchNormalization training mode is handled by bn_train_forward (see DESIGN.md)")
+        return super().forward(x, act, alpha, out)

@@ -1,0 +1,300 @@
+"""Thin torch-tensor front end of the C ABI (include/usseg.h).
+
+torch is used for device memory and the current HIP stream only; every function here enqueues
+hand-written gfx950 kernels from libusseg_hip.so and raises if the library is missing.
+
+Activation tensors are bf16 ``[B,H,W,Cphys]`` (NHWC) or channel-slice views of such tensors
+(``t[..., a:b]`` with a, b multiples of 8); the channel stride ``ld`` is taken from the view.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import (ACCUMULATE, ACT_ELU, ACT_LRELU, ACT_NONE, ACT_RELU, OUT_F32, ConvDesc, LossDesc, NormDesc,
+                   SplitAttnDesc, SplitAttnGrads, SplitAttnParams)
+
+BF16 = torch.bfloat16
+
+
+def roundup(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def geom(t: torch.Tensor) -> Tuple[int, int, int, int, int]:
+    """(B,H,W,C,ld) of an NHWC tensor or channel-slice view; validates the layout."""
+    assert t.dim() == 4, f"expected NHWC tensor, got shape {tuple(t.shape)}"
+    B, H, W, Cc = t.shape
+    assert t.stride(3) == 1 or Cc == 1, "channels must be contiguous"
+    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else (t.stride(0) if B > 1 else Cc))
+    if W > 1 and H > 1:
+        assert t.stride(1) == W * ld, "rows must be dense"
+    if B > 1:
+        assert t.stride(0) == H * W * ld, "images must be dense"
+    return B, H, W, Cc, ld
+
+
+def new_act(B: int, H: int, W: int, Cphys: int, device, zero: bool = False) -> torch.Tensor:
+    f = torch.zeros if zero else torch.empty
+    return f((B, H, W, Cphys), dtype=BF16, device=device)
+
+
+def _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation=1, act=ACT_NONE, alpha=0.0, flags=0) -> ConvDesc:
+    return ConvDesc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation, act, alpha, flags)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def conv2d_fwd(x, wp, bias, ksize, dilation, out, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False):
+    B, H, W, Cin, ldx = geom(x)
+    Bo, Ho, Wo, Cout, ldy = geom(out)
+    assert (Bo, Ho, Wo) == (B, H, W)
+    assert x.dtype == BF16 and out.dtype == (torch.float32 if out_f32 else BF16)
+    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation, act, alpha, OUT_F32 if out_f32 else 0)
+    ldr = geom(residual)[4] if residual is not None else 0
+    L.check(L.load().usseg_conv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), _ptr(bias), _ptr(residual), ldr,
+                                      out.data_ptr(), _stream()), "conv2d_fwd")
+    return out
+
+
+def conv2d_dgrad(dy, wp_d, ksize, dilation, dx, residual=None, accumulate=False):
+    B, H, W, Cout, ldy = geom(dy)
+    _, _, _, Cin, ldx = geom(dx)
+    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation, flags=ACCUMULATE if accumulate else 0)
+    ldr = geom(residual)[4] if residual is not None else 0
+    L.check(L.load().usseg_conv2d_dgrad(C.byref(d), dy.data_ptr(), wp_d.data_ptr(), _ptr(residual), ldr, dx.data_ptr(),
+                                        _stream()), "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(x, dy, ksize, dilation, dw: torch.Tensor):
+    """dw (fp32, [ntaps, Cin_phys, Cout_phys], pre-zeroed or holding a running sum) += x^T dy."""
+    B, H, W, Cin, ldx = geom(x)
+    _, _, _, Cout, ldy = geom(dy)
+    assert dw.dtype == torch.float32 and dw.numel() == ksize * ksize * Cin * Cout
+    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation)
+    L.check(L.load().usseg_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _stream()), "conv2d_wgrad")
+    return dw
+
+
+def tconv2d_fwd(x, wp, bias, ksize, out, act=ACT_NONE, alpha=0.0, out_f32=False):
+    B, H, W, Cin, ldx = geom(x)
+    Bo, Ho, Wo, Cout, ldy = geom(out)
+    assert (Bo, Ho, Wo) == (B, 2 * H, 2 * W)
+    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, 1, act, alpha, OUT_F32 if out_f32 else 0)
+    L.check(L.load().usseg_tconv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), _ptr(bias), out.data_ptr(), _stream()),
+            "tconv2d_fwd")
+    return out
+
+
+def tconv2d_dgrad(dy, wp_d, ksize, dx, residual=None, accumulate=False):
+    B, H2, W2, Cout, ldy = geom(dy)
+    Bx, H, W, Cin, ldx = geom(dx)
+    assert (H2, W2) == (2 * H, 2 * W)
+    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, 1, flags=ACCUMULATE if accumulate else 0)
+    ldr = geom(residual)[4] if residual is not None else 0
+    L.check(L.load().usseg_tconv2d_dgrad(C.byref(d), dy.data_ptr(), wp_d.data_ptr(), _ptr(residual), ldr, dx.data_ptr(),
+                                         _stream()), "tconv2d_dgrad")
+    return dx
+
+
+def tconv2d_wgrad(x, dy, ksize, dw: torch.Tensor):
+    """dw (fp32, [ntaps, Cin_phys, Cout_phys]) += sum_i x[i] (x) dy[2i+k-pad]."""
+    B, H, W, Cin, ldx = geom(x)
+    _, _, _, Cout, ldy = geom(dy)
+    assert dw.dtype == torch.float32 and dw.numel() == ksize * ksize * Cin * Cout
+    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, 1)
+    L.check(L.load().usseg_tconv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _stream()), "tconv2d_wgrad")
+    return dw
+
+
+def pack_weight(src: torch.Tensor, sT, sN, sK, T, Nn, Kk, dst: torch.Tensor, Kw, tap_stride, n_off=0, k_off=0):
+    assert src.dtype == torch.float32 and dst.dtype == BF16
+    L.check(L.load().usseg_pack_weight(src.data_ptr(), sT, sN, sK, T, Nn, Kk, dst.data_ptr(), Kw, tap_stride, n_off, k_off,
+                                       _stream()), "pack_weight")
+
+
+def unpack_wgrad(scratch, Mrows, Ncols, T, Nn, Kk, n_off, k_off, dst, sT, sN, sK, scale=1.0, accumulate=True):
+    L.check(L.load().usseg_unpack_wgrad(scratch.data_ptr(), Mrows, Ncols, T, Nn, Kk, n_off, k_off, dst.data_ptr(), sT, sN, sK,
+                                        scale, 1 if accumulate else 0, _stream()), "unpack_wgrad")
+
+
+# ------------------------------------------------------------------------------------------------ norm / act / pool
+def _norm_desc(x, C_logical, out_ld, G, mode, eps, act, alpha) -> NormDesc:
+    B, H, W, Cphys, ldx = geom(x)
+    return NormDesc(B * H * W, C_logical, Cphys, ldx, out_ld, G, mode, eps, act, alpha)
+
+
+def norm_act_fwd(x, C_logical, gamma, beta, out, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None, var=None):
+    d = _norm_desc(x, C_logical, geom(out)[4], G, mode, eps, act, alpha)
+    L.check(L.load().usseg_norm_act_fwd(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean), _ptr(var),
+                                        out.data_ptr(), _stream()), "norm_act_fwd")
+    return out
+
+
+def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None,
+                 var=None):
+    B, H, W, Cphys, ldx = geom(x)
+    lddy = geom(dy)[4]
+    assert geom(dx)[4] == ldx, "dx must have the stride of x"
+    d = NormDesc(B * H * W, C_logical, Cphys, ldx, lddy, G, mode, eps, act, alpha)
+    L.check(L.load().usseg_norm_act_bwd(C.byref(d), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean),
+                                        _ptr(var), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _stream()), "norm_act_bwd")
+    return dx
+
+
+def channel_stats(x, C_logical, s, s2):
+    B, H, W, _, ldx = geom(x)
+    L.check(L.load().usseg_channel_stats(x.data_ptr(), B * H * W, C_logical, ldx, s.data_ptr(), s2.data_ptr(), _stream()),
+            "channel_stats")
+
+
+def act_fwd(x, out, act, alpha):
+    B, H, W, Cc, ldx = geom(x)
+    L.check(L.load().usseg_act_fwd(x.data_ptr(), B * H * W, Cc, ldx, geom(out)[4], act, alpha, out.data_ptr(), _stream()), "act_fwd")
+    return out
+
+
+def act_bwd(x, dy, dx, act, alpha):
+    B, H, W, Cc, ldx = geom(x)
+    L.check(L.load().usseg_act_bwd(x.data_ptr(), dy.data_ptr(), B * H * W, Cc, ldx, geom(dy)[4], geom(dx)[4], act, alpha,
+                                   dx.data_ptr(), _stream()), "act_bwd")
+    return dx
+
+
+def avgpool2_fwd(x, out):
+    B, H, W, Cc, ldx = geom(x)
+    L.check(L.load().usseg_avgpool2_fwd(x.data_ptr(), B, H, W, Cc, ldx, geom(out)[4], out.data_ptr(), _stream()), "avgpool2_fwd")
+    return out
+
+
+def avgpool2_bwd(dy, dx, add=None):
+    B, H, W, Cc, lddx = geom(dx)
+    ldadd = geom(add)[4] if add is not None else 0
+    L.check(L.load().usseg_avgpool2_bwd(dy.data_ptr(), B, H, W, Cc, geom(dy)[4], lddx, _ptr(add), ldadd, dx.data_ptr(),
+                                        _stream()), "avgpool2_bwd")
+    return dx
+
+
+def copy_channels(src, dst, accumulate=False):
+    B, H, W, Cc, lds = geom(src)
+    Bd, Hd, Wd, Cd, ldd = geom(dst)
+    assert B * H * W == Bd * Hd * Wd and Cc == Cd
+    L.check(L.load().usseg_copy_channels(src.data_ptr(), B * H * W, Cc, lds, dst.data_ptr(), ldd, 1 if accumulate else 0,
+                                         _stream()), "copy_channels")
+    return dst
+
+
+def cast_input(x: torch.Tensor, Cphys: int) -> torch.Tensor:
+    """fp32/fp64 NHWC device tensor -> bf16 [B,H,W,Cphys] (zero pad channels)."""
+    assert x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, torch.float64)
+    B, H, W, Cc = x.shape
+    out = new_act(B, H, W, Cphys, x.device)
+    L.check(L.load().usseg_cast_input(x.data_ptr(), 1 if x.dtype == torch.float64 else 0, B * H * W, Cc, out.data_ptr(), Cphys,
+                                      _stream()), "cast_input")
+    return out
+
+
+def to_f32(x: torch.Tensor, C_logical: Optional[int] = None) -> torch.Tensor:
+    B, H, W, Cc, ld = geom(x)
+    Cl = C_logical or Cc
+    out = torch.empty((B, H, W, Cl), dtype=torch.float32, device=x.device)
+    L.check(L.load().usseg_cast_bf16_to_f32(x.data_ptr(), B * H * W, Cl, ld, out.data_ptr(), _stream()), "cast_bf16_to_f32")
+    return out
+
+
+def colsum(dy, db: torch.Tensor, C_logical: Optional[int] = None):
+    B, H, W, Cc, ld = geom(dy)
+    L.check(L.load().usseg_colsum(dy.data_ptr(), B * H * W, C_logical or Cc, ld, db.data_ptr(), _stream()), "colsum")
+
+
+# ------------------------------------------------------------------------------------------------ optimiser helpers
+def fill_f32(t: torch.Tensor, value: float = 0.0):
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    L.check(L.load().usseg_fill_f32(t.data_ptr(), t.numel(), value, _stream()), "fill_f32")
+
+
+def sumsq(g: torch.Tensor, out: torch.Tensor):
+    L.check(L.load().usseg_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "sumsq")
+
+
+def scale_by_clip(g: torch.Tensor, sumsq_t: torch.Tensor, clip_norm: float):
+    L.check(L.load().usseg_scale_f32(g.data_ptr(), g.numel(), sumsq_t.data_ptr(), clip_norm, _stream()), "scale_f32")
+
+
+def adam_clip_step(p, g, m, v, sumsq_t, clip_norm, lr_t_dev, b1, b2, eps):
+    L.check(L.load().usseg_adam_clip_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_t),
+                                          clip_norm, lr_t_dev.data_ptr(), b1, b2, eps, _stream()), "adam_clip_step")
+
+
+def adam_advance(step_dev, lr_t_dev, lr, b1, b2):
+    L.check(L.load().usseg_adam_advance(step_dev.data_ptr(), lr_t_dev.data_ptr(), lr, b1, b2, _stream()), "adam_advance")
+
+
+# ------------------------------------------------------------------------------------------------ split attention
+def splitattn_desc(B, HW, P, R, Cg, Hd, ldy, ldo, Cy_phys, Co_phys, mult, norm_mode, eps, act, alpha, use_sigmoid) -> SplitAttnDesc:
+    return SplitAttnDesc(B, HW, P, R, Cg, Hd, ldy, ldo, Cy_phys, Co_phys, mult, norm_mode, eps, act, alpha, 1 if use_sigmoid else 0)
+
+
+def _sa_params(w1, b1, gamma, beta, mean, var, w2, b2) -> SplitAttnParams:
+    return SplitAttnParams(_ptr(w1), _ptr(b1), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), _ptr(w2), _ptr(b2))
+
+
+def splitattn_fwd(d: SplitAttnDesc, y, params, out):
+    """params = (w1,b1,gamma,beta,mean,var,w2,b2) fp32 tensors laid out per path.  Returns (out, g, s, ws)."""
+    dev = y.device
+    Cy = d.P * d.R * d.Cg
+    g = torch.zeros((d.B, Cy), dtype=torch.float32, device=dev)
+    s = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
+    ws = torch.empty(d.B * d.P * (d.Cg + 2 * d.Hd), dtype=torch.float32, device=dev)
+    lib = L.load()
+    L.check(lib.usseg_splitattn_gap(C.byref(d), y.data_ptr(), g.data_ptr(), _stream()), "splitattn_gap")
+    sp = _sa_params(*params)
+    L.check(lib.usseg_splitattn_mlp_fwd(C.byref(d), g.data_ptr(), C.byref(sp), s.data_ptr(), ws.data_ptr(), _stream()), "splitattn_mlp_fwd")
+    L.check(lib.usseg_splitattn_apply_fwd(C.byref(d), y.data_ptr(), s.data_ptr(), out.data_ptr(), _stream()), "splitattn_apply_fwd")
+    return out, g, s, ws
+
+
+def splitattn_bwd(d: SplitAttnDesc, y, dout, params, grads, g, s, ws, dy):
+    """grads = (dw1,db1,dgamma,dbeta,dw2,db2) accumulated with atomics.  Writes dy (stride of dy tensor)."""
+    dev = y.device
+    Cy = d.P * d.R * d.Cg
+    ds = torch.zeros((d.B, Cy), dtype=torch.float32, device=dev)
+    dg = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
+    lib = L.load()
+    lddo = geom(dout)[4]
+    L.check(lib.usseg_splitattn_apply_bwd_reduce(C.byref(d), y.data_ptr(), dout.data_ptr(), lddo, ds.data_ptr(), _stream()),
+            "splitattn_apply_bwd_reduce")
+    sp = _sa_params(*params)
+    sg = SplitAttnGrads(*[_ptr(t) for t in grads])
+    L.check(lib.usseg_splitattn_mlp_bwd(C.byref(d), g.data_ptr(), C.byref(sp), s.data_ptr(), ws.data_ptr(), ds.data_ptr(), dg.data_ptr(),
+                                        C.byref(sg), _stream()), "splitattn_mlp_bwd")
+    L.check(lib.usseg_splitattn_apply_bwd_dy(C.byref(d), dout.data_ptr(), lddo, s.data_ptr(), dg.data_ptr(), dy.data_ptr(), geom(dy)[4],
+                                             _stream()), "splitattn_apply_bwd_dy")
+    return dy
+
+
+# ------------------------------------------------------------------------------------------------ head softmax + loss
+def softmax_loss(logits, y_true, probs, loss, dlogits, *, HW, C_classes, loss_kind=0, label_smoothing=0.1, clip_eps=1e-7,
+                 inv_global_batch=1.0, scale=None):
+    """logits fp32 [..., ldl]; y_true fp32 [..., C] or None; probs fp32 [..., C]; dlogits bf16 [..., 8] or None."""
+    M = probs.numel() // C_classes
+    ldl = logits.shape[-1]
+    d = LossDesc(M, HW, C_classes, ldl, 8, loss_kind, label_smoothing, clip_eps, inv_global_batch)
+    L.check(L.load().usseg_softmax_loss_fwd_bwd(C.byref(d), logits.data_ptr(), _ptr(y_true), _ptr(scale), probs.data_ptr(), _ptr(loss),
+                                                _ptr(dlogits), _stream()), "softmax_loss")
+
+
+def loss_cat_scale(y_true, scale):
+    B, H, W, Cc = y_true.shape
+    L.check(L.load().usseg_loss_cat_scale(y_true.data_ptr(), B, H * W, Cc, scale.data_ptr(), _stream()), "loss_cat_scale")
