@@ -55,6 +55,33 @@ KERAS = dict(
 
 
 # ----------------------------------------------------------------------------
+# optional emulation of the product's bf16 storage (diagnostic for tests only; default off = exact fp64)
+# ----------------------------------------------------------------------------
+STORAGE_DTYPE = None   # set to torch.bfloat16 to round every stored activation (and its gradient) and conv weights
+
+
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt, round_grad):
+        ctx.dt, ctx.round_grad = dt, round_grad
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dt).to(g.dtype) if ctx.round_grad else g), None, None
+
+
+def _q(x: Tensor) -> Tensor:
+    """Round a stored activation (forward) and its gradient (backward) to STORAGE_DTYPE; identity when unset."""
+    return x if STORAGE_DTYPE is None else _RoundSTE.apply(x, STORAGE_DTYPE, True)
+
+
+def _qw(w: Tensor) -> Tensor:
+    """Round a conv weight to STORAGE_DTYPE for the matmul only (fp32 master weights keep the full gradient)."""
+    return w if STORAGE_DTYPE is None else _RoundSTE.apply(w, STORAGE_DTYPE, False)
+
+
+# ----------------------------------------------------------------------------
 # primitives
 # ----------------------------------------------------------------------------
 def _nchw(x: Tensor) -> Tensor:
@@ -74,10 +101,10 @@ def conv2d_same(x: Tensor, w: Tensor, b: Optional[Tensor] = None, dilation: int 
     """
     kh, kw = w.shape[0], w.shape[1]
     assert kh % 2 == 1 and kw % 2 == 1
-    wt = w.permute(3, 2, 0, 1)  # -> [Cout,Cin,kh,kw]
+    wt = _qw(w).permute(3, 2, 0, 1)  # -> [Cout,Cin,kh,kw]
     y = F.conv2d(_nchw(x), wt, b, stride=1,
                  padding=(dilation * (kh - 1) // 2, dilation * (kw - 1) // 2), dilation=dilation)
-    return _nhwc(y)
+    return _q(_nhwc(y))
 
 
 def conv2d_transpose_s2_same(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
@@ -90,29 +117,29 @@ def conv2d_transpose_s2_same(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -
     k = w.shape[0]
     assert w.shape[1] == k and k in (3, 4)
     B, H, W, _ = x.shape
-    wt = w.permute(3, 2, 0, 1)  # [Cin,Cout,kh,kw] (torch conv_transpose2d layout)
+    wt = _qw(w).permute(3, 2, 0, 1)  # [Cin,Cout,kh,kw] (torch conv_transpose2d layout)
     if k == 3:
         y = F.conv_transpose2d(_nchw(x), wt, b, stride=2, padding=0)[..., : 2 * H, : 2 * W]
     else:
         y = F.conv_transpose2d(_nchw(x), wt, b, stride=2, padding=1)
-    return _nhwc(y)
+    return _q(_nhwc(y))
 
 
 def leaky_relu(x: Tensor) -> Tensor:
     """tf.keras.layers.LeakyReLU() (alpha 0.3) - ResNest.py:16,20,24,87,126,133,165; Decoder.py:31,111."""
-    return torch.where(x >= 0, x, KERAS["leaky_relu_alpha"] * x)
+    return _q(torch.where(x >= 0, x, KERAS["leaky_relu_alpha"] * x))
 
 
 def elu(x: Tensor) -> Tensor:
     """tf.keras.layers.ELU() - TBI_ResNest.py:84,87,91,145,165,170,191."""
-    return torch.where(x > 0, x, KERAS["elu_alpha"] * torch.expm1(torch.clamp(x, max=0.0)))
+    return _q(torch.where(x > 0, x, KERAS["elu_alpha"] * torch.expm1(torch.clamp(x, max=0.0))))
 
 
 def avg_pool2(x: Tensor) -> Tensor:
     """AveragePooling2D(pool_size=2, strides=2), VALID - ResNest.py:25-28; TBI_ResNest.py:92-107."""
     B, H, W, C = x.shape
     assert H % 2 == 0 and W % 2 == 0
-    return x.reshape(B, H // 2, 2, W // 2, 2, C).mean(dim=(2, 4))
+    return _q(x.reshape(B, H // 2, 2, W // 2, 2, C).mean(dim=(2, 4)))
 
 
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: Optional[float] = None) -> Tensor:
@@ -173,10 +200,12 @@ def split_attention(inputs: Sequence[Tensor], P: Params, prefix: str, radix: int
     times the SAME dense2 followed by a softmax over the CHANNEL axis (sigmoid if radix==1),
     output = sum_r inputs[r] * z.
     """
+    global STORAGE_DTYPE
     holder = inputs[0]
     for t in inputs[1:]:
         holder = holder + t                                            # :173-177
     y = holder.mean(dim=(1, 2))[:, None, None, :]                      # :179-180
+    saved_storage, STORAGE_DTYPE = STORAGE_DTYPE, None                 # the product runs this tiny MLP in fp32
     y = conv2d_same(y, P[prefix + "dense1.kernel"], P[prefix + "dense1.bias"])       # :182
     y = layer_norm(y, P[prefix + "dense1_bn.gamma"], P[prefix + "dense1_bn.beta"])   # :183
     y = leaky_relu(y)                                                  # :184
@@ -185,7 +214,8 @@ def split_attention(inputs: Sequence[Tensor], P: Params, prefix: str, radix: int
         z = conv2d_same(y, P[prefix + "dense2.kernel"], P[prefix + "dense2.bias"])   # :188
         z = torch.sigmoid(z) if radix == 1 else softmax_lastaxis(z)    # :189-192
         out = inputs[r] * z if out is None else out + inputs[r] * z    # :194-197
-    return out
+    STORAGE_DTYPE = saved_storage
+    return _q(out)
 
 
 def cardinal(x: Tensor, P: Params, prefix: str, radix: int, as_executed: bool = True) -> Tensor:
@@ -216,7 +246,7 @@ def residual_S(x: Tensor, P: Params, prefix: str, radix: int, kpaths: int,
     concats_2 = conv2d_same(concats_1, P[prefix + "concats_2.kernel"], P[prefix + "concats_2.bias"])  # :98
     sc = conv2d_same(x, P[prefix + "convtmp_sc.kernel"], P[prefix + "convtmp_sc.bias"])  # :99
     sc = leaky_relu(layer_norm(sc, P[prefix + "convtmp_scbn.gamma"], P[prefix + "convtmp_scbn.beta"]))  # :100-101
-    return sc + concats_2                                               # :102
+    return _q(sc + concats_2)                                           # :102
 
 
 def _bn(x, P, name, training=None):

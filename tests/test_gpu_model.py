@@ -1,0 +1,136 @@
+"""End-to-end parity (GPU): the nn.Module surface (ResNest / DecoderCup / VisionTransformer.train_step) against the
+fp64 oracle with IDENTICAL weights and inputs.
+
+Stated tolerances.  Per-kernel error is pinned at 1e-3 in test_gpu_ops.py.  Here whole networks run with bf16
+storage of every activation and bf16 MFMA operands (fp32 accumulate, fp32 master weights), so rounding compounds
+over ~60 layers; the bars below are relative L2 errors against the fp64 oracle:
+  stage outputs (one residual_S)   3e-2      probabilities            2e-2
+  loss                              5e-3      parameter gradients      median 3e-2, 90th percentile 8e-2
+A few ill-conditioned tensors (one split-attention MLP whose gradient is a difference of nearly equal terms)
+deviate by up to ~0.3 from fp64 under ANY bf16 storage: the oracle run with bf16 storage emulation
+(usseg_oracle.STORAGE_DTYPE) shows the same deviation on the same tensors (tools/diag_grad_noise.py).  The
+kernel-correctness bar is therefore taken against that emulation: every gradient tensor within 1e-1 of it.
+They are bf16-depth tolerances, not kernel tolerances; a wrong kernel shows up as an O(1) error.
+"""
+import pytest
+import torch
+
+import usseg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _f32(P):
+    """Oracle parameters exactly as the product stores them (fp32 masters)."""
+    return {k: v.float().double() for k, v in P.items()}
+
+
+@pytest.fixture(scope="module")
+def small_model():
+    from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
+    P = _f32(O.init_vision_transformer_params(channel=1, seed=3, perturb=True))
+    net = VisionTransformer(batch_size=2, img_size=(64, 64), in_channels=1, learning_rate=1e-3)
+    net.load_params(P)
+    return net, P
+
+
+def test_surface_and_shapes(small_model):
+    net, P = small_model
+    assert len(net.visionModel.layers) > 50
+    own = dict(net.named_parameters())
+    assert set(own) == set(O.trainable_names(P))
+    assert net.flat.n_trainable == 6270904
+    x, y = O.synthetic_batch(2, 64, 64, 1, seed=0)
+    x4, feats = net.transformer.embeddings.hybrid_model(x.to(DEV))      # fp64 NHWC input, as Dataset_2.py:91 hands over
+    assert tuple(x4.shape) == (2, 4, 4, 512)
+    assert [tuple(f.shape) for f in feats] == [(2, 8, 8, 256), (2, 16, 16, 128), (2, 32, 32, 64)]
+    probs, attn = net(x.to(DEV))
+    assert tuple(probs.shape) == (2, 64, 64, 3) and probs.dtype == torch.float32
+    assert torch.allclose(probs.sum(-1), torch.ones(2, 64, 64, device=DEV), atol=1e-5)
+
+
+def test_encoder_stage_parity(small_model):
+    net, P = small_model
+    enc = net.transformer.embeddings.hybrid_model
+    pre = "transformer.embeddings.hybrid_model."
+    x, _ = O.synthetic_batch(2, 64, 64, 1, seed=1)
+    xb = x.to(torch.bfloat16).double()
+    x4r, featr = O.resnest_forward(xb, P, 3, 3, pre, as_executed=True)
+    x4, feats = enc(x.to(DEV))
+    for got, want, name in [(feats[2], featr[2], "x_1"), (feats[1], featr[1], "x_2"), (feats[0], featr[0], "x_3"), (x4, x4r, "x_4")]:
+        e = rel(got, want)
+        print(f"encoder {name}: rel {e:.3e}")
+        assert e < 3e-2, name
+    # one residual_S stage alone, fed the oracle's own (bf16-rounded) input: isolates the grouped split-attention path
+    t = {}
+    O.resnest_forward(xb, P, 3, 3, pre, taps=t)
+    s_in = O.avg_pool2(t["stem"]).to(torch.bfloat16)
+    want = O.residual_S(s_in.double(), P, pre + "conv_1.", 3, 3, as_executed=True)
+    got = enc.conv_1(s_in.to(DEV))
+    print(f"residual_S conv_1 alone: rel {rel(got, want):.3e}")
+    assert rel(got, want) < 1e-2
+
+
+def test_train_step_parity(small_model):
+    net, P = small_model
+    P = dict(P)
+    x, y = O.synthetic_batch(2, 64, 64, 1, seed=2)
+    xb = x.to(torch.bfloat16).double()
+    st = {}
+    O.STORAGE_DTYPE = torch.bfloat16
+    try:
+        _, _, grads_emu, _ = O.train_step(xb, y, dict(P), {}, global_batch_size=2, lr=1e-3, as_executed=False)
+    finally:
+        O.STORAGE_DTYPE = None
+    loss_r, probs_r, grads_r, gnorm_r = O.train_step(xb, y, P, st, global_batch_size=2, lr=1e-3, as_executed=True)
+    before = net.export_params()
+    loss, probs = net.train_step(x, y.float())
+    torch.cuda.synchronize()
+    e_p, e_l = rel(probs, probs_r), abs(loss.item() - loss_r.item()) / abs(loss_r.item())
+    print(f"probs rel {e_p:.3e}  loss {loss.item():.6f} vs {loss_r.item():.6f} (rel {e_l:.2e})")
+    assert e_p < 2e-2 and e_l < 5e-3
+    grads = net.export_grads()
+    # export_grads holds the UNCLIPPED gradients (the clip is applied inside the Adam kernel)
+    errs = {k: rel(grads[k], grads_r[k]) for k in grads_r}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    med = sorted(errs.values())[len(errs) // 2]
+    print("median grad rel", f"{med:.3e}", "worst:", [(k, f"{v:.2e}") for k, v in worst])
+    p90 = sorted(errs.values())[int(len(errs) * 0.9)]
+    assert med < 3e-2 and p90 < 8e-2, (med, p90)
+    errs_emu = {k: rel(grads[k], grads_emu[k]) for k in grads_r}
+    worst_emu = max(errs_emu.items(), key=lambda kv: kv[1])
+    print("worst vs bf16-emulated oracle:", worst_emu)
+    assert worst_emu[1] < 1e-1, worst_emu
+    gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()
+    assert abs(gn - gnorm_r.item()) / gnorm_r.item() < 2e-2
+    # parameters after clip + Adam: compare the UPDATE (delta), which is what the step computes
+    after = net.export_params()
+    num = den = 0.0
+    for k in grads_r:
+        d_got = (after[k].double().cpu() - before[k].double().cpu())
+        d_ref = (P[k].double() - before[k].double().cpu())
+        num += (d_got - d_ref).pow(2).sum().item()
+        den += d_ref.pow(2).sum().item()
+    print(f"Adam update rel {(num / den) ** 0.5:.3e}")
+    assert (num / den) ** 0.5 < 0.15     # first Adam step is sign-like (m/sqrt(v)): tiny-gradient entries flip easily
+    # BN moving statistics never change (inference mode as driven)
+    for k in after:
+        if k.endswith("moving_mean") or k.endswith("moving_variance"):
+            assert torch.equal(after[k], before[k])
+
+
+def test_eval_step_and_second_train_step(small_model):
+    net, P = small_model
+    x, y = O.synthetic_batch(2, 64, 64, 1, seed=5)
+    l0, p0 = net.step(x, y.float())
+    l1, _ = net.train_step(x, y.float())
+    l2, _ = net.step(x, y.float())
+    assert abs(l0.item() - l1.item()) < 1e-3 * abs(l0.item())   # same weights, same batch
+    assert l2.item() < l0.item()                                  # one Adam step on this batch lowers its loss
+    assert torch.isfinite(p0).all()
