@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: segmentation TRAINING images/sec at 256x256 on N MI355X (BASELINE.json metric).
+
+A "step" is one full training step (forward + backward + per-replica clip + gradient all-reduce + Adam + operand
+repack) of the Arch B network of BASELINE config 2 (ResNest.py r=3,k=3 encoder + patch embedding + Decoder.py
+DecoderCup, no ViT) on a synthetic batch of 16 256x256x1 tiles PER GPU that is already resident in HBM.
+Weak scaling: the per-GPU batch is fixed, the global batch (which divides the loss) is 16*N.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (see the keys below).  Extra objects:
+  roofline     - the dominant kernel family (the gather implicit-GEMM that runs every conv / tconv forward and
+                 backward-data pass): algorithmic FLOPs of its launches in one step / the summed duration of
+                 those launches, measured with HIP events recorded by the library on the launch stream.
+  cpu_baseline - the CPU oracle (a PyTorch-CPU fp32 restatement of the reference path; TensorFlow, hence the
+                 reference itself, cannot run here) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+B_PER_GPU = 16
+H = W = 256
+C_IN = 1
+
+
+def algorithmic_flops(net):
+    """Algorithmic FLOPs (2*MACs, logical channel counts, radix branches de-duplicated) of the conv / tconv layers
+    for the batch of the last forward pass: (forward, igemm family = fwd + dgrad actually run, wgrad)."""
+    from ultrasound_modeling_amd.layers import Conv2D
+    from ultrasound_modeling_amd.ResNest import residual_S
+    from ultrasound_modeling_amd import ops
+    fwd = igemm = 0.0
+    managed = set()
+    for m in net.modules():
+        if isinstance(m, residual_S):
+            g = m._group
+            x = g._saved[0]
+            Bx, Hx, Wx, _, _ = ops.geom(x)
+            M = Bx * Hx * Wx
+            f = 2.0 * M * g.P * (g.cin * g.cv11 + g.k * g.k * g.cv11 * g.cvkk)
+            fwd += f
+            igemm += 2 * f
+            for c in g.cards:
+                managed.update((id(c.conv1), id(c.conv2), id(c.split.dense1), id(c.split.dense2)))
+    first = net.transformer.embeddings.hybrid_model.conv1
+    for m in net.modules():
+        if isinstance(m, Conv2D) and id(m) not in managed:
+            Bx, Hx, Wx, _, _ = ops.geom(m._x)
+            f = 2.0 * Bx * Hx * Wx * m.k * m.k * m.cin * m.cout
+            fwd += f
+            igemm += f if m is first else 2 * f      # the first layer needs no input gradient
+    return fwd, igemm, fwd
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """Time the CPU oracle (fp32, all host cores) on a bounded sample: full train steps at B=2, 256x256x1."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import usseg_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bc = 2
+    P = O.init_vision_transformer_params(channel=C_IN, seed=0, dtype=torch.float32)
+    x, y = O.synthetic_batch(Bc, H, W, C_IN, seed=0, dtype=torch.float32)
+    st = {}
+    O.train_step(x, y, P, st, Bc)            # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.train_step(x, y, P, st, Bc)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 8:
+            break
+    return {"value": round(Bc * n / el, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} full train steps (fwd+bwd+clip+Adam) of the Arch B oracle, fp32 PyTorch-CPU, B={Bc}, 256x256x1, "
+                      f"{torch.get_num_threads()} threads; TensorFlow (the reference) is not installable here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra eager steps with per-launch HIP events (roofline leg)")
+    args = ap.parse_args()
+
+    from ultrasound_modeling_amd.MainParallel import MirroredTrainer, init_distributed
+    rank, world, local = init_distributed()
+    assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from ultrasound_modeling_amd import _lib
+    from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
+    net = VisionTransformer(batch_size=B_PER_GPU * world, img_size=(H, W), in_channels=C_IN, device=str(dev), seed=0)
+    trainer = MirroredTrainer(net)
+
+    g = torch.Generator().manual_seed(rank)
+    x = torch.randn(B_PER_GPU, H, W, C_IN, generator=g).clamp_(-1, 1).to(dev)
+    lab = torch.rand(B_PER_GPU, H // 16, W // 16, generator=g)
+    lab = (lab > 0.70).float() + (lab > 0.95).float()
+    lab = (lab + 0.9 * torch.rand(lab.shape, generator=g) * (lab >= 1)).repeat_interleave(16, 1).repeat_interleave(16, 2)
+    c2 = torch.where(lab >= 1.05, (lab - 1).clamp(0, 1), torch.zeros_like(lab))
+    y = torch.stack([(lab <= 0.95).float(), torch.where(lab > 0.95, 1 - c2, torch.zeros_like(lab)), c2], dim=-1).to(dev)
+
+    use_graph = not args.no_graph and world == 1     # the RCCL collective stays outside graphs in this round
+    for _ in range(max(args.warmup, 1) if not use_graph else 1):
+        trainer.train_step(x, y)
+    if use_graph:
+        net.capture_graph(x, y)
+        for _ in range(args.warmup):
+            trainer.train_step(x, y)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.train_step(x, y)
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    loss_val = float(loss.item())
+
+    # ---- roofline leg: eager steps with the library's per-launch HIP events around the igemm / wgrad kernels
+    roofline = None
+    if rank == 0:
+        lib = _lib.load()
+        net._graph_saved, net._graph = net._graph, None
+        P = args.profile_steps
+        _lib.check(lib.usseg_prof_enable(3, 4096 * P), "prof_enable")
+        for _ in range(P):
+            net._train_body(x, y)
+        torch.cuda.synchronize()
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        _lib.check(lib.usseg_prof_read(1, ctypes.byref(ms), ctypes.byref(n)), "prof_read")
+        ig_ms, ig_n = ms.value / P, n.value // P
+        _lib.check(lib.usseg_prof_read(2, ctypes.byref(ms), ctypes.byref(n)), "prof_read")
+        wg_ms, wg_n = ms.value / P, n.value // P
+        lib.usseg_prof_disable()
+        fwd_f, ig_f, wg_f = algorithmic_flops(net)
+        net._graph = net._graph_saved
+        achieved = ig_f / (ig_ms * 1e-3) / 1e12
+        roofline = {"kernel": "igemm_kernel<NT> (conv/tconv fwd + dgrad)", "bound": "mfma", "achieved": round(achieved, 2),
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
+                    "algorithmic_gflop_per_step": round(ig_f / 1e9, 2), "kernel_ms_per_step": round(ig_ms, 3),
+                    "wgrad": {"launches_per_step": wg_n, "kernel_ms_per_step": round(wg_ms, 3),
+                              "achieved": round(wg_f / (wg_ms * 1e-3) / 1e12, 2), "algorithmic_gflop_per_step": round(wg_f / 1e9, 2)},
+                    "fwd_gflop_per_image": round(fwd_f / B_PER_GPU / 1e9, 3)}
+
+    if rank == 0:
+        out = {"metric": "segmentation training images/sec at 256x256", "value": round(B_PER_GPU * world * args.steps / el, 2),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: Arch B (ResNest.py r=3,k=3 + Decoder.py, no ViT) train step, 256x256x1, "
+                                      "16 images per GPU, bf16 MFMA / fp32 accumulate, fp32 master weights + Adam",
+                          "per_gpu_batch": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
+                          "hip_graph": bool(use_graph), "final_loss": round(loss_val, 4)},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -226,6 +226,15 @@ int usseg_adam_advance(int32_t* step, float* lr_t_dev, float lr, float beta1, fl
 int usseg_fill_f32(float* p, int64_t n, float value, usseg_stream_t stream);
 int usseg_scale_f32(float* p, int64_t n, const float* sumsq, float clip_norm, usseg_stream_t stream);
 
+/* ---- opt-in per-launch timing (bench.py roofline leg) ------------------------------------------
+ * When enabled, every launch of the selected kernel family is bracketed by hipEventRecord on ITS stream.
+ * kinds: 1 = gather implicit-GEMM (conv/tconv fwd + dgrad), 2 = weight-gradient GEMM.  Events are created by
+ * usseg_prof_enable (never inside a launch function); usseg_prof_read synchronises the recorded events and
+ * returns the summed duration and the launch count.  Not graph-capture safe: disable before capturing. */
+int usseg_prof_enable(int32_t kind_mask, int32_t capacity);
+int usseg_prof_read(int32_t kind, double* total_ms, int64_t* launches);
+int usseg_prof_disable(void);
+
 #ifdef __cplusplus
 }
 #endif

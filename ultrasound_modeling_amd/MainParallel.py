@@ -1,0 +1,84 @@
+"""Single-node data parallelism with the semantics of the reference's ``MainParallel.py`` (MirroredStrategy).
+
+Reference behaviour being mirrored (MainParallel.py:16,117-146,209-210):
+  * variables are created once and mirrored on every GPU (:209-210)  -> rank 0's flat parameter buffer is broadcast;
+  * each global batch is split into N contiguous per-replica slices (:127-128) -> ``shard_batch``;
+  * every replica runs ``train_step`` on its slice with the loss divided by the GLOBAL batch size
+    (VisionTransformer.py:227), clips ITS OWN gradients by global norm (:244), and ``apply_gradients`` then
+    all-reduces them with SUM before the identical Adam update on every replica (:245 under :130);
+  * scalar metrics are SUM-reduced (:131-134) and evaluation outputs gathered (:160,:163).
+MI355X design: one process per GPU (torchrun), ONE RCCL all-reduce over the flat fp32 gradient buffer per step
+(25 MB for the conv-only Arch B): on the fully connected xGMI node a single large collective uses all 7 links.
+BatchNorm statistics are NOT synchronised (the reference uses plain BatchNormalization, ResNest.py:19).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment. -> (rank, world_size, local_rank)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(x, y, rank: int, world: int):
+    """The contiguous per-replica slice of a global batch (experimental_distribute_dataset, MainParallel.py:128)."""
+    B = x.shape[0]
+    assert B % world == 0, "global batch must divide evenly over the replicas"
+    n = B // world
+    return x[rank * n:(rank + 1) * n], y[rank * n:(rank + 1) * n]
+
+
+class MirroredTrainer:
+    """Wraps a model that has ``flat`` (FlatParams), ``grad_sync`` and ``train_step`` (VisionTransformer / Arch A)."""
+
+    def __init__(self, net, group=None):
+        self.net, self.group = net, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.world > 1:
+            dist.broadcast(net.flat.flat, src=0, group=group)          # mirrored variables (:209-210)
+            for m in net.modules():
+                for b in m._buffers.values():
+                    if b is not None:
+                        dist.broadcast(b, src=0, group=group)
+            if hasattr(net, "repack"):
+                net.repack()
+            net.grad_sync = self._allreduce_sum
+
+    def _allreduce_sum(self, flat_grad: torch.Tensor):
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)   # apply_gradients under MirroredStrategy
+
+    def train_step(self, x_local, y_local):
+        """One mirrored step on this replica's slice -> (global loss, local probs) (MainParallel.py:130-131)."""
+        loss, probs = self.net.train_step(x_local, y_local)
+        if self.world > 1:
+            loss = loss.clone()
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+        return loss, probs
+
+    def test_step(self, x_local, y_local):
+        """mirrored_test_step (MainParallel.py:148-176): SUM-reduced loss, gathered probabilities and labels."""
+        loss, probs = self.net.step(x_local, y_local)
+        if self.world > 1:
+            loss = loss.clone()
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+            plist = [torch.empty_like(probs) for _ in range(self.world)]
+            dist.all_gather(plist, probs.contiguous(), group=self.group)
+            probs = torch.cat(plist, dim=0)
+        return loss, probs

@@ -141,6 +141,9 @@ class VisionTransformer(nn.Module):
                 raise KeyError(f"unexpected parameter {k}")
         repack_all(self)
 
+    def repack(self):
+        repack_all(self)
+
     def export_params(self) -> dict:
         out = {k: v.data.detach().clone() for k, v in self.named_parameters()}
         for name, mod in self.named_modules():

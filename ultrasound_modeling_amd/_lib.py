@@ -91,6 +91,9 @@ _PROTOS = {
     "usseg_adam_advance": (C.c_int, [c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),
     "usseg_fill_f32": (C.c_int, [c_vp, c_i64, c_f32, c_vp]),
     "usseg_scale_f32": (C.c_int, [c_vp, c_i64, c_vp, c_f32, c_vp]),
+    "usseg_prof_enable": (C.c_int, [c_i32, c_i32]),
+    "usseg_prof_read": (C.c_int, [c_i32, P(C.c_double), P(c_i64)]),
+    "usseg_prof_disable": (C.c_int, []),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

@@ -57,6 +57,9 @@ void usseg_set_error(const char* fmt, ...);
     }                                              \
   } while (0)
 int usseg_check_launch(const char* what);
+// opt-in per-launch timing: returns an event slot (>=0) after recording its start event, or -1 when disabled
+int usseg_prof_start(int kind, hipStream_t s);
+void usseg_prof_stop(int kind, int slot, hipStream_t s);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

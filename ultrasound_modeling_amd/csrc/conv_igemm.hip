@@ -210,6 +210,7 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   dim3 block(256);
   int64_t gx = cdiv64(p.M, 128);
   USSEG_CHECK_ARG(gx < (1ll << 31), "igemm: too many pixel tiles");
+  const int slot = usseg_prof_start(1, s);
   if (p.Nout <= 16) {
     hipLaunchKernelGGL(igemm_kernel<1>, dim3((unsigned)gx, 1), block, 0, s, p);
   } else if (p.Nout <= 32) {
@@ -219,6 +220,7 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   } else {
     hipLaunchKernelGGL(igemm_kernel<8>, dim3((unsigned)gx, (unsigned)((p.Nout + 127) / 128)), block, 0, s, p);
   }
+  usseg_prof_stop(1, slot, s);
   return usseg_check_launch("igemm");
 }
 

@@ -132,7 +132,9 @@ static int launch_wgrad(WgradParams& p, int ntaps, hipStream_t s) {
   if (want < 1) want = 1;
   p.chunk = cdiv64(cdiv64(p.M, want), 32) * 32;
   int64_t splits = cdiv64(p.M, p.chunk);
+  const int slot = usseg_prof_start(2, s);
   hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)splits, (unsigned)(p.mtiles * p.ntiles), (unsigned)ntaps), dim3(256), 0, s, p);
+  usseg_prof_stop(2, slot, s);
   return usseg_check_launch("wgrad");
 }
 
