@@ -36,6 +36,22 @@ H = W = 256
 C_IN = 1
 
 
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """CPU share of this process: affinity mask, capped by the cgroup CPU quota (the GPU box gives 16 per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def algorithmic_flops(net):
     """Algorithmic FLOPs (2*MACs, logical channel counts, radix branches de-duplicated) of the conv / tconv layers
     for the batch of the last forward pass: (forward, igemm family = fwd + dgrad actually run, wgrad)."""
@@ -69,8 +85,9 @@ def cpu_baseline(seconds_budget: float = 25.0):
     """Time the CPU oracle (fp32, all host cores) on a bounded sample: full train steps at B=2, 256x256x1."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import usseg_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: timing the CPU oracle on {cores} threads")
     Bc = 2
     P = O.init_vision_transformer_params(channel=C_IN, seed=0, dtype=torch.float32)
     x, y = O.synthetic_batch(Bc, H, W, C_IN, seed=0, dtype=torch.float32)
@@ -119,6 +136,7 @@ def main():
     y = torch.stack([(lab <= 0.95).float(), torch.where(lab > 0.95, 1 - c2, torch.zeros_like(lab)), c2], dim=-1).to(dev)
 
     use_graph = not args.no_graph and world == 1     # the RCCL collective stays outside graphs in this round
+    log(f"rank {rank}/{world}: model built ({net.flat.n_trainable} params), warming up (graph={use_graph})")
     for _ in range(max(args.warmup, 1) if not use_graph else 1):
         trainer.train_step(x, y)
     if use_graph:
@@ -143,6 +161,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
     loss_val = float(loss.item())
+    log(f"timed region done: {el / args.steps * 1e3:.3f} ms/step")
 
     # ---- roofline leg: eager steps with the library's per-launch HIP events around the igemm / wgrad kernels
     roofline = None

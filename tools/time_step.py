@@ -1,0 +1,30 @@
+"""Eager-mode timing of the Arch B train step at the bench shape, with progress lines (diagnostic)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+HW = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
+print("building", flush=True)
+net = VisionTransformer(batch_size=B, img_size=(HW, HW), in_channels=1)
+x = torch.randn(B, HW, HW, 1, device="cuda").clamp_(-1, 1)
+y = torch.softmax(torch.randn(B, HW, HW, 3, device="cuda"), -1)
+print("built", flush=True)
+def t(fn, name):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+    print(f"{name}: {(time.perf_counter()-t0)*1e3:.2f} ms", flush=True); return r
+t(lambda: net.flat.zero_grad(), "zero_grad")
+probs, dl = t(lambda: net._forward_loss(x, y, True), "forward+loss")
+dh, df = t(lambda: net.decoder.backward(dl), "decoder.backward")
+t(lambda: net.transformer.backward(dh, df), "encoder.backward")
+t(lambda: net.optimizer.apply(), "adam")
+t(lambda: net.repack(), "repack")
+for i in range(3):
+    t(lambda: net.train_step(x, y), f"train_step {i}")
+if graph:
+    print("capturing", flush=True)
+    t(lambda: net.capture_graph(x, y), "capture")
+    for i in range(5):
+        t(lambda: net.train_step(x, y), f"graph step {i}")

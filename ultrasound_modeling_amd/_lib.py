@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (must be imported first: the HIP runtime torch loads is the one this library must share)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libusseg_hip.so")
 
