@@ -116,12 +116,18 @@ typedef struct UssegNormDesc {
 } UssegNormDesc;
 int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const float* gamma, const float* beta,
                        const float* mean, const float* var, void* y, usseg_stream_t stream);
-/* dx, and dgamma/dbeta accumulated with fp32 atomics.  x is the SAME pre-normalisation input as in fwd. */
+/* dx, and dgamma/dbeta accumulated.  x is the SAME pre-normalisation input as in fwd. */
 int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma, const float* beta,
-                       const float* mean, const float* var, void* dx, float* dgamma, float* dbeta,
-                       usseg_stream_t stream);
-/* BatchNormalization training mode statistics: per-channel sum and sum of squares (fp32 atomics). */
-int usseg_channel_stats(const void* x, int64_t M, int32_t C, int32_t ldx, float* sum, float* sumsq,
+                       const float* mean, const float* var, void* dx, float* dgamma, float* dbeta, float* dbias,
+                       float* ws, usseg_stream_t stream);
+/* Every per-channel reduction (norm backward, colsum, channel_stats, split-attention reductions) writes one partial
+ * row per workgroup into the caller's fp32 workspace `ws` (at least usseg_reduce_ws_floats() floats) and a finishing
+ * kernel ADDS the column sums to the destination: no atomics, bitwise reproducible.
+ * usseg_norm_act_bwd: dgamma/dbeta += ...; dbias (may be NULL) += sum over pixels of dx, i.e. the bias gradient of
+ * the convolution that produced x. */
+int64_t usseg_reduce_ws_floats(void);
+/* BatchNormalization training mode statistics: sum[c] += sum_m x, sumsq[c] += sum_m x^2. */
+int usseg_channel_stats(const void* x, int64_t M, int32_t C, int32_t ldx, float* sum, float* sumsq, float* ws,
                         usseg_stream_t stream);
 
 /* ---- plain activation (conv1 + LeakyReLU, ResNest.py:39-40; TBI_ResNest.py:83-87) ------------- */
@@ -172,7 +178,7 @@ typedef struct UssegSplitAttnParams {
 typedef struct UssegSplitAttnGrads {
   float *w1, *b1, *gamma, *beta, *w2, *b2;
 } UssegSplitAttnGrads;
-int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, float* g, usseg_stream_t stream);
+int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, float* g, float* ws, usseg_stream_t stream);
 /* ws: fp32 workspace of usseg_splitattn_ws_floats(d) floats holding the saved MLP intermediates */
 int64_t usseg_splitattn_ws_floats(const UssegSplitAttnDesc* d);
 int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, float* s,
@@ -182,7 +188,7 @@ int usseg_splitattn_apply_fwd(const UssegSplitAttnDesc* d, const void* y, const 
 /* backward: (1) ds[b][p][r][c] = sum_hw mult*y*dout (zeroed by caller) (2) MLP backward -> dg, param grads
  * (3) dy = mult*s*dout + dg*mult/HW */
 int usseg_splitattn_apply_bwd_reduce(const UssegSplitAttnDesc* d, const void* y, const void* dout, int32_t lddo,
-                                     float* ds, usseg_stream_t stream);
+                                     float* ds, float* ws, usseg_stream_t stream);
 int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, const float* s,
                             const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads,
                             usseg_stream_t stream);
@@ -211,7 +217,7 @@ int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, cons
 int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, int32_t C, float* scale, usseg_stream_t stream);
 
 /* ---- bias gradient: db[c] += sum_pixels dy[m][c] --------------------------------------------- */
-int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, usseg_stream_t stream);
+int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, float* ws, usseg_stream_t stream);
 
 /* ---- optimiser: tf.clip_by_global_norm(1.0) + Adam (VisionTransformer.py:204,244-245; TBI_ResNest.py:28,46)
  * sumsq: *out += sum g^2 over n floats (zeroed by caller).

@@ -79,20 +79,20 @@ class DecoderBlock(nn.Module):
         draw2 = ops.new_act(B, H2, W2, oc, dev)
         for j in range(4):
             sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"bn2_{j}").backward(dout[..., sl], dx=draw2[..., sl])
+            getattr(self, f"bn2_{j}").backward(dout[..., sl], dx=draw2[..., sl], dbias=getattr(self, f"conv2_{j}").bias.grad)
         dact1 = ops.new_act(B, H2, W2, oc, dev)
         for j in range(4):
             sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"conv2_{j}").backward(draw2[..., sl], dx=dact1, accumulate_dx=(j > 0))
+            getattr(self, f"conv2_{j}").backward(draw2[..., sl], dx=dact1, accumulate_dx=(j > 0), skip_bias=True)
         draw1 = ops.new_act(B, H2, W2, oc, dev)
         for j in range(4):
             sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"bn1_{j}").backward(dact1[..., sl], dx=draw1[..., sl])
+            getattr(self, f"bn1_{j}").backward(dact1[..., sl], dx=draw1[..., sl], dbias=getattr(self, f"conv1_{j}").bias.grad)
         c1 = oc + (self.skip_channels if self._has_skip else 0)
         dcat = ops.new_act(B, H2, W2, c1, dev)
         for j in range(4):
             sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"conv1_{j}").backward(draw1[..., sl], dx=dcat, accumulate_dx=(j > 0))
+            getattr(self, f"conv1_{j}").backward(draw1[..., sl], dx=dcat, accumulate_dx=(j > 0), skip_bias=True)
         dx = self.up.backward(dcat[..., :oc])
         dskip = dcat[..., oc:] if self._has_skip else None
         return dx, dskip
@@ -166,8 +166,8 @@ class DecoderCup(nn.Module):
             ops.copy_channels(d[..., blk.out_channels:], d_hidden.reshape(B, gh * s, gw * s, c0), accumulate=not first)
             first = False
             d, dfeats[i] = blk.backward(d[..., :blk.out_channels])
-        d = self.bn1.backward(d)
-        self.conv_more.backward(d, dx=d_hidden, accumulate_dx=True)
+        d = self.bn1.backward(d, dbias=self.conv_more.bias.grad)
+        self.conv_more.backward(d, dx=d_hidden, accumulate_dx=True, skip_bias=True)
         return d_hidden.reshape(self._hidden_shape), dfeats
 
     def __call__(self, hidden_states, features=None, *args, **kwargs):

@@ -191,7 +191,7 @@ class _CardinalGroup:
         params = self.mlp_p[:4] + (None, None) + self.mlp_p[4:]
         dy = ops.splitattn_bwd(d, y, dout, params, self.mlp_g, g, s, ws, torch.empty_like(y))
         dv = ops.norm_act_bwd(v_raw, dy, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, 0, self.P,
-                              KERAS_LN_EPS, ACT_LRELU, a)
+                              KERAS_LN_EPS, ACT_LRELU, a, dbias=self.db2)
         # grouped 3x3: dense wgrad into scratch, keep the diagonal blocks
         scratch = _Workspace.get(dev, T * self.Up * self.Vp)
         ops.fill_f32(scratch, 0.0)
@@ -200,16 +200,14 @@ class _CardinalGroup:
         for p, c in enumerate(self.cards):
             ops.unpack_wgrad(scratch, self.Up, self.Vp, T, self.cvkk, self.cv11, p * self.cvkk, p * self.cv11, c.conv2.kernel.grad,
                              sT, 1, self.cvkk)
-        ops.colsum(dv, self.db2, self.V)
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, self.dil, torch.empty_like(u))
         du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, 0, self.P,
-                                  KERAS_LN_EPS, ACT_LRELU, a)
+                                  KERAS_LN_EPS, ACT_LRELU, a, dbias=self.db1)
         scratch = _Workspace.get(dev, self.cin_p * self.Up)
         ops.fill_f32(scratch, 0.0)
         ops.conv2d_wgrad(x, du_raw, 1, 1, scratch)
         for p, c in enumerate(self.cards):
             ops.unpack_wgrad(scratch, self.cin_p, self.Up, 1, self.cv11, self.cin, p * self.cv11, 0, c.conv1.kernel.grad, 0, 1, self.cv11)
-        ops.colsum(du_raw, self.db1, self.U)
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
 
 
@@ -246,9 +244,9 @@ class residual_S(nn.Module):
 
     def backward(self, dout, need_dx=True):
         d_c1 = self.concats_2.backward(dout)
-        dsc_raw = self.convtmp_scbn.backward(dout)
+        dsc_raw = self.convtmp_scbn.backward(dout, dbias=self.convtmp_sc.bias.grad)
         dx_a = self._group.backward(d_c1)
-        return self.convtmp_sc.backward(dsc_raw, need_dx=need_dx, dx_residual=dx_a)
+        return self.convtmp_sc.backward(dsc_raw, need_dx=need_dx, dx_residual=dx_a, skip_bias=True)
 
     def __call__(self, x, *args, **kwargs):
         return self.forward(x)
@@ -306,10 +304,10 @@ class ResNest(nn.Module):
         d = self.conv2_pool.backward(d, add=d_x1)
         d = self.conv_1.backward(d)
         d = self.conv1_pool.backward(d)
-        d = self.convtmp_2bn.backward(d)
-        d = self.convtmp_2.backward(d)
-        d = self.convtmp_1bn.backward(d)
-        d = self.convtmp_1.backward(d)
+        d = self.convtmp_2bn.backward(d, dbias=self.convtmp_2.bias.grad)
+        d = self.convtmp_2.backward(d, skip_bias=True)
+        d = self.convtmp_1bn.backward(d, dbias=self.convtmp_1.bias.grad)
+        d = self.convtmp_1.backward(d, skip_bias=True)
         d = ops.act_bwd(self._y1, d, torch.empty_like(d), ACT_LRELU, KERAS_LRELU_ALPHA)   # LeakyReLU': sign(y) == sign(pre)
         self.conv1.backward(d, need_dx=False)
         return None

@@ -68,8 +68,9 @@ _PROTOS = {
     "usseg_unpack_wgrad": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_i64,
                                      c_f32, c_i32, c_vp]),
     "usseg_norm_act_fwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "usseg_norm_act_bwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "usseg_channel_stats": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "usseg_norm_act_bwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_reduce_ws_floats": (c_i64, []),
+    "usseg_channel_stats": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "usseg_act_fwd": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
     "usseg_act_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
     "usseg_avgpool2_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -77,17 +78,17 @@ _PROTOS = {
     "usseg_copy_channels": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "usseg_cast_input": (C.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_vp]),
     "usseg_cast_bf16_to_f32": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
-    "usseg_splitattn_gap": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp]),
+    "usseg_splitattn_gap": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp, c_vp]),
     "usseg_splitattn_ws_floats": (c_i64, [P(SplitAttnDesc)]),
     "usseg_splitattn_mlp_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, P(SplitAttnParams), c_vp, c_vp, c_vp]),
     "usseg_splitattn_apply_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp, c_vp]),
-    "usseg_splitattn_apply_bwd_reduce": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_splitattn_apply_bwd_reduce": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "usseg_splitattn_mlp_bwd": (C.c_int, [P(SplitAttnDesc), c_vp, P(SplitAttnParams), c_vp, c_vp, c_vp, c_vp,
                                           P(SplitAttnGrads), c_vp]),
     "usseg_splitattn_apply_bwd_dy": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "usseg_softmax_loss_fwd_bwd": (C.c_int, [P(LossDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_loss_cat_scale": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "usseg_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "usseg_sumsq": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "usseg_adam_clip_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_f32, c_f32, c_f32, c_vp]),
     "usseg_adam_advance": (C.c_int, [c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),

@@ -9,26 +9,10 @@ static inline int lanes_per_pixel(int chunks) {
   return l;
 }
 
-__device__ __forceinline__ void wave_chunk_atomic2(float* acc8, int LPP, int chunk, bool chunk_ok, float* dst, int C, float scale) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float v = acc8[j];
-    for (int msk = LPP; msk < 64; msk <<= 1) v += __shfl_xor(v, msk, 64);
-    acc8[j] = v;
-  }
-  const int lane = threadIdx.x & 63;
-  if (lane < LPP && chunk_ok) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int c = chunk * 8 + j;
-      if (c < C) atomicAdd(dst + c, acc8[j] * scale);
-    }
-  }
-}
-
 // g[b][c] += sum_hw y[b,hw,c]   (and, with dout != NULL, ds[b][cy] += mult * sum_hw y[b,hw,cy] * dout[b,hw,co(cy)])
 __global__ __launch_bounds__(256) void sa_reduce_kernel(const bf16_t* y, const bf16_t* dout, int HW, int Cy, int ldy, int lddo, int R, int Cg,
-                                                         int LPP, float scale, float* out) {
+                                                         int LPP, float* ws) {
+  __shared__ float s_red[4 * 512];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ppw = 64 / LPP, chunk = lane & (LPP - 1), slot = lane / LPP;
@@ -69,7 +53,21 @@ __global__ __launch_bounds__(256) void sa_reduce_kernel(const bf16_t* y, const b
       }
     }
   }
-  wave_chunk_atomic2(s, LPP, chunk, chunk_ok, out + (int64_t)b * Cy, Cy, scale);
+  // one partial row per workgroup (no atomics); usseg_launch_reduce_finish adds the rows of image b
+  const int Cp = (Cy + 7) & ~7;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = s[j];
+    for (int msk = LPP; msk < 64; msk <<= 1) v += __shfl_xor(v, msk, 64);
+    s[j] = v;
+  }
+  if (lane < LPP && chunk_ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_red[wv * 512 + chunk * 8 + j] = s[j];
+  }
+  __syncthreads();
+  float* row = ws + ((int64_t)b * gridDim.x + blockIdx.x) * Cp;
+  for (int c = threadIdx.x; c < Cp; c += 256) row[c] = s_red[c] + s_red[512 + c] + s_red[1024 + c] + s_red[1536 + c];
 }
 
 static int sa_check(const UssegSplitAttnDesc* d) {
@@ -82,32 +80,40 @@ static int sa_check(const UssegSplitAttnDesc* d) {
   return USSEG_OK;
 }
 
-extern "C" int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, float* g, usseg_stream_t stream) {
+extern "C" int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, float* g, float* ws, usseg_stream_t stream) {
   int rc = sa_check(d);
   if (rc) return rc;
-  USSEG_CHECK_ARG(y && g, "null pointer");
+  USSEG_CHECK_ARG(y && g && ws, "null pointer");
   int Cy = d->P * d->R * d->Cg;
   int LPP = lanes_per_pixel(roundup(Cy, 8) / 8);
   int ppb = 4 * (64 / LPP);
   int gx = (int)cdiv64(d->HW, (int64_t)ppb * 8);
-  if (gx > 128) gx = 128;
+  int gmax = USSEG_REDUCE_MAX_BLOCKS / d->B;
+  if (gmax > 64) gmax = 64;
+  if (gmax < 1) gmax = 1;
+  if (gx > gmax) gx = gmax;
   hipLaunchKernelGGL(sa_reduce_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)nullptr, d->HW, Cy,
-                     d->ldy, 0, d->R, d->Cg, LPP, 1.0f, g);
+                     d->ldy, 0, d->R, d->Cg, LPP, ws);
+  usseg_launch_reduce_finish(ws, d->B, gx, 1, roundup(Cy, 8), Cy, 1.0f, g, nullptr, nullptr, (hipStream_t)stream);
   return usseg_check_launch("splitattn_gap");
 }
 
 extern "C" int usseg_splitattn_apply_bwd_reduce(const UssegSplitAttnDesc* d, const void* y, const void* dout, int32_t lddo, float* ds,
-                                                usseg_stream_t stream) {
+                                                float* ws, usseg_stream_t stream) {
   int rc = sa_check(d);
   if (rc) return rc;
-  USSEG_CHECK_ARG(y && dout && ds && lddo % 8 == 0, "null pointer");
+  USSEG_CHECK_ARG(y && dout && ds && ws && lddo % 8 == 0, "null pointer");
   int Cy = d->P * d->R * d->Cg;
   int LPP = lanes_per_pixel(roundup(Cy, 8) / 8);
   int ppb = 4 * (64 / LPP);
   int gx = (int)cdiv64(d->HW, (int64_t)ppb * 8);
-  if (gx > 128) gx = 128;
+  int gmax = USSEG_REDUCE_MAX_BLOCKS / d->B;
+  if (gmax > 64) gmax = 64;
+  if (gmax < 1) gmax = 1;
+  if (gx > gmax) gx = gmax;
   hipLaunchKernelGGL(sa_reduce_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)dout, d->HW, Cy,
-                     d->ldy, lddo, d->R, d->Cg, LPP, d->mult, ds);
+                     d->ldy, lddo, d->R, d->Cg, LPP, ws);
+  usseg_launch_reduce_finish(ws, d->B, gx, 1, roundup(Cy, 8), Cy, d->mult, ds, nullptr, nullptr, (hipStream_t)stream);
   return usseg_check_launch("splitattn_apply_bwd_reduce");
 }
 

@@ -144,11 +144,13 @@ class Conv2D(nn.Module):
         self._x = x
         return ops.conv2d_fwd(x, self.wp_f, self.bias.data if use_bias else None, self.k, self.dil, out, act, alpha, residual, out_f32)
 
-    def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False):
-        """dy: gradient w.r.t. the conv output (before any fused activation).  Accumulates kernel/bias grads."""
+    def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False, skip_bias=False):
+        """dy: gradient w.r.t. the conv output (before any fused activation).  Accumulates kernel/bias grads.
+        ``skip_bias``: the bias gradient was already produced by the following norm layer's backward (its ``dbias``)."""
         x = self._x
         self._wgrad(x, dy)
-        ops.colsum(dy, self.bias.grad, self.cout)
+        if not skip_bias:
+            ops.colsum(dy, self.bias.grad, self.cout)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)
@@ -228,13 +230,14 @@ class LayerNormalization(nn.Module):
         mean, var = self._stats()
         return ops.norm_act_fwd(x, self.C, self.gamma.data, self.beta.data, out, self.mode, 1, self.eps, act, alpha, mean, var)
 
-    def backward(self, dy, dx=None):
+    def backward(self, dy, dx=None, dbias=None):
+        """``dbias``: optional fp32 vector that receives sum_pixels(dx) = the bias gradient of the conv that produced x."""
         x = self._x
         act, alpha = self._act
         dx = dx if dx is not None else torch.empty_like(x)
         mean, var = self._stats()
         return ops.norm_act_bwd(x, dy, self.C, self.gamma.data, self.beta.data, dx, self.gamma.grad, self.beta.grad, self.mode,
-                                1, self.eps, act, alpha, mean, var)
+                                1, self.eps, act, alpha, mean, var, dbias)
 
 
 class BatchNormalization(LayerNormalization):

@@ -32,6 +32,19 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_REDUCE_WS = {}
+
+
+def reduce_ws(device) -> torch.Tensor:
+    """fp32 workspace for the library's two-pass per-channel reductions (one per device; stream order serialises its users)."""
+    key = str(device)
+    ws = _REDUCE_WS.get(key)
+    if ws is None:
+        ws = torch.empty(int(L.load().usseg_reduce_ws_floats()), dtype=torch.float32, device=device)
+        _REDUCE_WS[key] = ws
+    return ws
+
+
 def geom(t: torch.Tensor) -> Tuple[int, int, int, int, int]:
     """(B,H,W,C,ld) of an NHWC tensor or channel-slice view; validates the layout."""
     assert t.dim() == 4, f"expected NHWC tensor, got shape {tuple(t.shape)}"
@@ -143,20 +156,21 @@ def norm_act_fwd(x, C_logical, gamma, beta, out, mode, G=1, eps=1e-3, act=ACT_NO
 
 
 def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None,
-                 var=None):
+                 var=None, dbias=None):
     B, H, W, Cphys, ldx = geom(x)
     lddy = geom(dy)[4]
     assert geom(dx)[4] == ldx, "dx must have the stride of x"
     d = NormDesc(B * H * W, C_logical, Cphys, ldx, lddy, G, mode, eps, act, alpha)
     L.check(L.load().usseg_norm_act_bwd(C.byref(d), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean),
-                                        _ptr(var), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _stream()), "norm_act_bwd")
+                                        _ptr(var), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias),
+                                        reduce_ws(x.device).data_ptr(), _stream()), "norm_act_bwd")
     return dx
 
 
 def channel_stats(x, C_logical, s, s2):
     B, H, W, _, ldx = geom(x)
-    L.check(L.load().usseg_channel_stats(x.data_ptr(), B * H * W, C_logical, ldx, s.data_ptr(), s2.data_ptr(), _stream()),
-            "channel_stats")
+    L.check(L.load().usseg_channel_stats(x.data_ptr(), B * H * W, C_logical, ldx, s.data_ptr(), s2.data_ptr(),
+                                         reduce_ws(x.device).data_ptr(), _stream()), "channel_stats")
 
 
 def act_fwd(x, out, act, alpha):
@@ -215,7 +229,8 @@ def to_f32(x: torch.Tensor, C_logical: Optional[int] = None) -> torch.Tensor:
 
 def colsum(dy, db: torch.Tensor, C_logical: Optional[int] = None):
     B, H, W, Cc, ld = geom(dy)
-    L.check(L.load().usseg_colsum(dy.data_ptr(), B * H * W, C_logical or Cc, ld, db.data_ptr(), _stream()), "colsum")
+    L.check(L.load().usseg_colsum(dy.data_ptr(), B * H * W, C_logical or Cc, ld, db.data_ptr(), reduce_ws(dy.device).data_ptr(),
+                                  _stream()), "colsum")
 
 
 # ------------------------------------------------------------------------------------------------ optimiser helpers
@@ -258,7 +273,7 @@ def splitattn_fwd(d: SplitAttnDesc, y, params, out):
     s = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
     ws = torch.empty(d.B * d.P * (d.Cg + 2 * d.Hd), dtype=torch.float32, device=dev)
     lib = L.load()
-    L.check(lib.usseg_splitattn_gap(C.byref(d), y.data_ptr(), g.data_ptr(), _stream()), "splitattn_gap")
+    L.check(lib.usseg_splitattn_gap(C.byref(d), y.data_ptr(), g.data_ptr(), reduce_ws(dev).data_ptr(), _stream()), "splitattn_gap")
     sp = _sa_params(*params)
     L.check(lib.usseg_splitattn_mlp_fwd(C.byref(d), g.data_ptr(), C.byref(sp), s.data_ptr(), ws.data_ptr(), _stream()), "splitattn_mlp_fwd")
     L.check(lib.usseg_splitattn_apply_fwd(C.byref(d), y.data_ptr(), s.data_ptr(), out.data_ptr(), _stream()), "splitattn_apply_fwd")
@@ -273,8 +288,8 @@ def splitattn_bwd(d: SplitAttnDesc, y, dout, params, grads, g, s, ws, dy):
     dg = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
     lib = L.load()
     lddo = geom(dout)[4]
-    L.check(lib.usseg_splitattn_apply_bwd_reduce(C.byref(d), y.data_ptr(), dout.data_ptr(), lddo, ds.data_ptr(), _stream()),
-            "splitattn_apply_bwd_reduce")
+    L.check(lib.usseg_splitattn_apply_bwd_reduce(C.byref(d), y.data_ptr(), dout.data_ptr(), lddo, ds.data_ptr(),
+                                                 reduce_ws(dev).data_ptr(), _stream()), "splitattn_apply_bwd_reduce")
     sp = _sa_params(*params)
     sg = SplitAttnGrads(*[_ptr(t) for t in grads])
     L.check(lib.usseg_splitattn_mlp_bwd(C.byref(d), g.data_ptr(), C.byref(sp), s.data_ptr(), ws.data_ptr(), ds.data_ptr(), dg.data_ptr(),
