@@ -95,6 +95,14 @@ int usseg_tconv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, f
 int usseg_pack_weight(const float* src, int64_t sT, int64_t sN, int64_t sK, int32_t T, int32_t Nn, int32_t Kk,
                       void* dst, int32_t Kw, int32_t tap_stride, int32_t n_off, int32_t k_off,
                       usseg_stream_t stream);
+/* All packs of a model in one launch: `jobs_dev` is a DEVICE array of njobs descriptors (same fields as above). */
+typedef struct UssegPackJob {
+  const float* src;
+  void* dst;
+  int64_t sT, sN, sK;
+  int32_t T, Nn, Kk, Kw, tap_stride, n_off, k_off, reserved;
+} UssegPackJob;
+int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t njobs, usseg_stream_t stream);
 int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t Ncols, int32_t T, int32_t Nn, int32_t Kk,
                        int32_t n_off, int32_t k_off, float* dst, int64_t sT, int64_t sN, int64_t sK,
                        float scale, int32_t accumulate, usseg_stream_t stream);

@@ -149,17 +149,23 @@ class _CardinalGroup:
             assert b.split.dense2.kernel.data_ptr() == a.split.dense2.kernel.data_ptr() + 4 * self.hid * self.cvkk
         self.repack()
 
-    def repack(self):
+    def pack_jobs(self):
         T = self.k * self.k
+        jobs = []
         for p, c in enumerate(self.cards):
             k1, k2 = c.conv1.kernel.data, c.conv2.kernel.data
             # conv1 [1,1,cin,cv11]: fwd rows n = p*cv11+j, K = ci ; dgrad rows = ci, K = p*cv11+j
-            ops.pack_weight(k1, 0, 1, self.cv11, 1, self.cv11, self.cin, self.w1_f, self.cin_p, self.cin_p, p * self.cv11, 0)
-            ops.pack_weight(k1, 0, self.cv11, 1, 1, self.cin, self.cv11, self.w1_d, self.Up, self.Up, 0, p * self.cv11)
+            jobs.append(ops.pack_job(k1, 0, 1, self.cv11, 1, self.cv11, self.cin, self.w1_f, self.cin_p, self.cin_p, p * self.cv11, 0))
+            jobs.append(ops.pack_job(k1, 0, self.cv11, 1, 1, self.cin, self.cv11, self.w1_d, self.Up, self.Up, 0, p * self.cv11))
             # conv2 [k,k,cv11,cvkk] on the diagonal block (p,p)
             sT = self.cv11 * self.cvkk
-            ops.pack_weight(k2, sT, 1, self.cvkk, T, self.cvkk, self.cv11, self.w2_f, T * self.Up, self.Up, p * self.cvkk, p * self.cv11)
-            ops.pack_weight(k2, sT, self.cvkk, 1, T, self.cv11, self.cvkk, self.w2_d, T * self.Vp, self.Vp, p * self.cv11, p * self.cvkk)
+            jobs.append(ops.pack_job(k2, sT, 1, self.cvkk, T, self.cvkk, self.cv11, self.w2_f, T * self.Up, self.Up, p * self.cvkk, p * self.cv11))
+            jobs.append(ops.pack_job(k2, sT, self.cvkk, 1, T, self.cv11, self.cvkk, self.w2_d, T * self.Vp, self.Vp, p * self.cv11, p * self.cvkk))
+        return jobs
+
+    def repack(self):
+        jobs = self.pack_jobs()
+        ops.pack_weights_batched(ops.make_pack_table(jobs, self.w1_f.device), len(jobs))
 
     def _sa_desc(self, B, HW):
         use_sigmoid = self.radix == 1   # ResNest.py:189-190
@@ -235,6 +241,9 @@ class residual_S(nn.Module):
 
     def repack(self):
         self._group.repack()
+
+    def pack_jobs(self):
+        return self._group.pack_jobs()
 
     def forward(self, x, out=None):
         concats_1 = self._group.forward(x)                                                          # :91-96

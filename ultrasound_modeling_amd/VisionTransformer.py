@@ -28,15 +28,23 @@ input_size = (256, 80)   # VisionTransformer.py:7
 
 
 def repack_all(root: nn.Module):
-    """Rebuild every bf16 packed operand from the fp32 master weights (after an optimiser step or a weight load)."""
-    for m in root.modules():
-        if isinstance(m, residual_S):
-            m.repack()
-        elif isinstance(m, cardinal):
-            if m._solo is not None:
-                m._solo.repack()
-        elif isinstance(m, Conv2D) and m.wp_f is not None:
-            m.repack()
+    """Rebuild every bf16 packed operand from the fp32 master weights (after an optimiser step or a weight load):
+    ONE batched launch driven by a device-resident job table that is built once (all pointers are static)."""
+    table = getattr(root, "_pack_table", None)
+    if table is None:
+        jobs = []
+        for m in root.modules():
+            if isinstance(m, residual_S):
+                jobs += m.pack_jobs()
+            elif isinstance(m, cardinal):
+                if m._solo is not None:
+                    jobs += m._solo.pack_jobs()
+            elif isinstance(m, Conv2D) and m.wp_f is not None:
+                jobs += m.pack_jobs()
+        dev = next(root.parameters()).device
+        table = (ops.make_pack_table(jobs, dev), len(jobs))
+        object.__setattr__(root, "_pack_table", table)
+    ops.pack_weights_batched(*table)
 
 
 class Embeddings(nn.Module):

@@ -65,6 +65,7 @@ _PROTOS = {
     "usseg_tconv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_tconv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp]),
     "usseg_pack_weight": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "usseg_pack_weights_batched": (C.c_int, [c_vp, c_i32, c_vp]),
     "usseg_unpack_wgrad": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_i64,
                                      c_f32, c_i32, c_vp]),
     "usseg_norm_act_fwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

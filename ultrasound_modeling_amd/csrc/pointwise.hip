@@ -46,24 +46,39 @@ __device__ __forceinline__ void block_chunk_partial(float* acc8, int LPP, int ch
 // dst_k[g*C + c] += scale * sum_{j<nb} ws[((g*nb + j)*K + k)*Cp + c]   for k < K (dst_k may be NULL)
 __global__ __launch_bounds__(256) void reduce_finish_kernel(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0,
                                                              float* d1, float* d2) {
+  // workgroup = 16 outputs x 16 row slices: the nb partial rows of an output are summed by 16 threads in parallel
+  // (a serial walk over 512 rows is a 512-deep chain of dependent loads: 45 us; this form is ~3 us)
+  __shared__ float s_part[16][17];
   const int total = groups * K * C;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    int c = i % C;
-    int k = (i / C) % K;
-    int g = i / (C * K);
-    float* dst = k == 0 ? d0 : (k == 1 ? d1 : d2);
-    if (!dst) continue;
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (int base = blockIdx.x * 16; base < total; base += gridDim.x * 16) {
+    const int i = base + o;
     float s = 0.f;
-    for (int j = 0; j < nb; ++j) s += ws[((int64_t)(g * nb + j) * K + k) * Cp + c];
-    dst[g * C + c] += scale * s;
+    int c = 0, k = 0, g = 0;
+    if (i < total) {
+      c = i % C;
+      k = (i / C) % K;
+      g = i / (C * K);
+      for (int j = sl; j < nb; j += 16) s += ws[((int64_t)(g * nb + j) * K + k) * Cp + c];
+    }
+    s_part[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += s_part[q][o];
+      float* dst = k == 0 ? d0 : (k == 1 ? d1 : d2);
+      if (dst) dst[g * C + c] += scale * t;
+    }
+    __syncthreads();
   }
 }
 
 void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0, float* d1, float* d2,
                                 hipStream_t s) {
   int total = groups * K * C;
-  int grid = (total + 255) / 256;
-  if (grid > 256) grid = 256;
+  int grid = (total + 15) / 16;
+  if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(reduce_finish_kernel, dim3(grid), dim3(256), 0, s, ws, groups, nb, K, Cp, C, scale, d0, d1, d2);
 }
 
@@ -552,4 +567,23 @@ extern "C" int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t N
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for((int64_t)T * Nn * Kk, 256, 1024)), dim3(256), 0, (hipStream_t)stream, scratch,
                      Mrows, Ncols, T, Nn, Kk, n_off, k_off, dst, sT, sN, sK, scale, accumulate);
   return usseg_check_launch("unpack_wgrad");
+}
+
+// ---- all operand packs of a model in ONE launch: blockIdx.y = job ---------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const UssegPackJob* jobs) {
+  const UssegPackJob j = jobs[blockIdx.y];
+  const int64_t total = (int64_t)j.T * j.Nn * j.Kk;
+  bf16_t* dst = reinterpret_cast<bf16_t*>(j.dst);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int k = (int)(i % j.Kk);
+    int64_t r = i / j.Kk;
+    int n = (int)(r % j.Nn);
+    int t = (int)(r / j.Nn);
+    dst[(int64_t)(j.n_off + n) * j.Kw + (int64_t)t * j.tap_stride + j.k_off + k] = f2bf(j.src[t * j.sT + n * j.sN + k * j.sK]);
+  }
+}
+extern "C" int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t njobs, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(jobs_dev && njobs > 0 && njobs < 65536, "pack_weights_batched: bad args");
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  return usseg_check_launch("pack_weights_batched");
 }

@@ -126,14 +126,19 @@ class Conv2D(nn.Module):
         self.wp_d = torch.zeros((roundup(self.cin_p, 16), T * self.cout_p), dtype=BF16, device=device)
         self.repack()
 
-    def repack(self):
-        """fp32 master kernel -> bf16 packed operands for the forward and the backward-data GEMMs."""
+    def pack_jobs(self):
+        """fp32 master kernel -> bf16 packed operands for the forward and the backward-data GEMMs (job descriptors)."""
         T = self.k * self.k
         sT, sI, sO = self._strides_tio()
-        # forward: rows n = out channel, K = tap*cin_p + ci
-        ops.pack_weight(self.kernel.data, sT, sO, sI, T, self.cout, self.cin, self.wp_f, T * self.cin_p, self.cin_p)
-        # dgrad: rows n = in channel, K = tap*cout_p + co
-        ops.pack_weight(self.kernel.data, sT, sI, sO, T, self.cin, self.cout, self.wp_d, T * self.cout_p, self.cout_p)
+        return [
+            # forward: rows n = out channel, K = tap*cin_p + ci
+            ops.pack_job(self.kernel.data, sT, sO, sI, T, self.cout, self.cin, self.wp_f, T * self.cin_p, self.cin_p),
+            # dgrad: rows n = in channel, K = tap*cout_p + co
+            ops.pack_job(self.kernel.data, sT, sI, sO, T, self.cin, self.cout, self.wp_d, T * self.cout_p, self.cout_p)]
+
+    def repack(self):
+        jobs = self.pack_jobs()
+        ops.pack_weights_batched(ops.make_pack_table(jobs, self.wp_f.device), len(jobs))
 
     def forward(self, x, out=None, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False, use_bias=True):
         B, H, W, C, _ = ops.geom(x)

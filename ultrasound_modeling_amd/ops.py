@@ -137,6 +137,26 @@ def pack_weight(src: torch.Tensor, sT, sN, sK, T, Nn, Kk, dst: torch.Tensor, Kw,
                                        _stream()), "pack_weight")
 
 
+PACK_JOB_DTYPE = [("src", "<u8"), ("dst", "<u8"), ("sT", "<i8"), ("sN", "<i8"), ("sK", "<i8"), ("T", "<i4"), ("Nn", "<i4"), ("Kk", "<i4"),
+                  ("Kw", "<i4"), ("tap_stride", "<i4"), ("n_off", "<i4"), ("k_off", "<i4"), ("reserved", "<i4")]
+
+
+def pack_job(src, sT, sN, sK, T, Nn, Kk, dst, Kw, tap_stride, n_off=0, k_off=0):
+    """Descriptor tuple of one pack (same arguments as pack_weight) for pack_weights_batched."""
+    assert src.dtype == torch.float32 and dst.dtype == BF16
+    return (src.data_ptr(), dst.data_ptr(), sT, sN, sK, T, Nn, Kk, Kw, tap_stride, n_off, k_off, 0)
+
+
+def make_pack_table(jobs, device) -> torch.Tensor:
+    import numpy as np
+    arr = np.array(jobs, dtype=PACK_JOB_DTYPE)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+
+
+def pack_weights_batched(table: torch.Tensor, njobs: int):
+    L.check(L.load().usseg_pack_weights_batched(table.data_ptr(), njobs, _stream()), "pack_weights_batched")
+
+
 def unpack_wgrad(scratch, Mrows, Ncols, T, Nn, Kk, n_off, k_off, dst, sT, sN, sK, scale=1.0, accumulate=True):
     L.check(L.load().usseg_unpack_wgrad(scratch.data_ptr(), Mrows, Ncols, T, Nn, Kk, n_off, k_off, dst.data_ptr(), sT, sN, sK,
                                         scale, 1 if accumulate else 0, _stream()), "unpack_wgrad")
