@@ -66,6 +66,14 @@ CONV_CASES = [
     (1, 24, 24, 128, 16, 3, 4),
     (1, 20, 20, 72, 136, 3, 8),   # dilation larger than half the image, Cout spans two N tiles
     (1, 1, 1, 10, 5, 1, 1),       # dense on a [B,1,1,C] tensor
+    # halo-tile kernel variants (conv_halo.hip): lattice patches 8x16, 8x8 (2 per workgroup), 4x4 (8 per workgroup), 4x8
+    (2, 32, 32, 64, 64, 3, 8),    # d=8 on 32x32: 4x4 virtual images
+    (1, 32, 32, 48, 24, 3, 4),    # d=4 on 32x32: 8x8 virtual images, Cin not a multiple of 32
+    (1, 64, 32, 88, 16, 3, 2),    # d=2: 32x16 lattice, Cin = 88 (cardinal conv2 input width at stage 4)
+    (3, 16, 16, 24, 136, 3, 1),   # N spans several channel tiles, 3 images -> ragged last workgroup
+    (1, 64, 64, 8, 16, 3, 1),     # stem conv1 class
+    (2, 16, 32, 32, 8, 3, 4),     # 4x8 lattice patches (4 per workgroup)
+    (5, 8, 8, 16, 32, 3, 1),      # 8x8 images, odd batch: last workgroup half empty
 ]
 
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/usseg.h"
 
 typedef unsigned short bf16_t;  // raw bf16 bits
@@ -65,6 +66,11 @@ void usseg_prof_stop(int kind, int slot, hipStream_t s);
 // adds the per-workgroup partial rows written by a reduction kernel to up to three destinations (pointwise.hip)
 void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0, float* d1, float* d2,
                                 hipStream_t s);
+
+// 3x3 conv with an LDS halo tile (conv_halo.hip): returns 1 if it took the launch, 0 if the geometry does not fit
+int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
+                               int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
+                               int accumulate, int flip, hipStream_t s);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

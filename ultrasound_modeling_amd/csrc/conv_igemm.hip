@@ -241,6 +241,11 @@ extern "C" int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const voi
   int rc = check_desc(d, false);
   if (rc) return rc;
   USSEG_CHECK_ARG(x && wp && y, "null pointer");
+  if (d->ksize == 3 &&
+      usseg_try_launch_conv_halo((const bf16_t*)x, (const bf16_t*)wp, y, bias, (const bf16_t*)residual, d->B, d->H, d->W, d->dilation, d->Cin,
+                                 d->ldx, d->Cout, d->ldy, ldr, roundup(d->Cout, 16), 9 * d->Cin, d->act, d->alpha,
+                                 (d->flags & USSEG_OUT_F32) ? 1 : 0, (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 0, (hipStream_t)stream))
+    return usseg_check_launch("conv_halo");
   IgemmParams p = {};
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.y = y; p.bias = bias; p.res = (const bf16_t*)residual; p.ldr = ldr;
   p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
@@ -269,6 +274,11 @@ extern "C" int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const 
   if (rc) return rc;
   USSEG_CHECK_ARG(dy && wp && dx, "null pointer");
   USSEG_CHECK_ARG(!(d->flags & USSEG_OUT_F32) && d->Cout % 8 == 0, "dgrad needs bf16 dy with Cout % 8 == 0");
+  if (d->ksize == 3 &&
+      usseg_try_launch_conv_halo((const bf16_t*)dy, (const bf16_t*)wp, dx, nullptr, (const bf16_t*)residual, d->B, d->H, d->W, d->dilation,
+                                 d->Cout, d->ldy, d->Cin, d->ldx, ldr, roundup(d->Cin, 16), 9 * d->Cout, USSEG_ACT_NONE, 0.f, 0,
+                                 (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 1, (hipStream_t)stream))
+    return usseg_check_launch("conv_halo_dgrad");
   IgemmParams p = {};
   p.x = (const bf16_t*)dy; p.w = (const bf16_t*)wp; p.y = dx; p.bias = nullptr; p.res = (const bf16_t*)residual; p.ldr = ldr;
   p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
