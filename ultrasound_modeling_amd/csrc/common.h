@@ -72,5 +72,9 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
                                int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
                                int accumulate, int flip, hipStream_t s);
 
+// 3x3 weight gradient with an LDS halo tile (wgrad_halo.hip): 1 if it took the launch, 0 otherwise
+int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, int B, int H, int W, int d, int Ma, int Nb, int ldx, int lddy,
+                                hipStream_t s);
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

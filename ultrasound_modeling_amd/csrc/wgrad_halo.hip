@@ -1,0 +1,215 @@
+// Weight gradient of a 3x3 convolution (stride 1, SAME, any dilation) with an LDS-resident input halo tile, gfx950.
+//
+//   dW[kh,kw][ci][co] += sum_p x[p + (kh-1,kw-1)*d][ci] * dy[p][co]
+//
+// The per-tap kernel (wgrad.hip) re-reads x and dy once per tap (9x).  Here a workgroup stages, per 128-pixel
+// chunk, the x patch + one-pixel halo and the dy patch ONCE and runs all 9 taps out of LDS: the shifted A^T
+// fragments are transposed reads (ds_read_b64_tr_b16) whose per-lane row addresses carry the tap offset.
+// Dilation uses the sub-lattice decomposition of conv_halo.hip (same patch geometry).
+// Workgroup tile: (32*WM input channels) x (32*WN output channels) x 9 taps, 4 waves as 2x2; split-K over pixel
+// chunks across blockIdx.x, fp32 atomics into the [9][Ma][Nb] scratch (only the valid m<Ma, n<Nb entries).
+#include "common.h"
+
+struct WgHaloParams {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* out;
+  int32_t B, H, W, d, Hl, Wl, PH, PW, NV;
+  int32_t tiles_x, tiles_per_v, npatches, ngroups, groups_per_block;
+  int32_t ldx, lddy, Ma, Nb, ntiles_n;
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p) {
+  constexpr int MAXHP = 288;
+  constexpr int BMc = 32 * WM, BNc = 32 * WN;      // channels per workgroup tile
+  constexpr int XS = BMc + 8, YS = BNc + 8;        // LDS row strides (elements): +16 B pad
+  constexpr int XCH = BMc / 8, YCH = BNc / 8;      // 16-byte chunks per pixel row
+  constexpr int X_IT = (MAXHP * XCH + 255) / 256, Y_IT = (128 * YCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16_t lds_x[MAXHP * XS];
+  __shared__ __attribute__((aligned(16))) bf16_t lds_y[128 * YS];
+  __shared__ int s_patch[8][8];  // per patch: b, la, lb, ly0, lx0, valid
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int mt = blockIdx.y / p.ntiles_n, nt = blockIdx.y - mt * p.ntiles_n;
+  const int m0 = mt * BMc, n0 = nt * BNc;
+  const int HW2 = p.PW + 2, HPP = (p.PH + 2) * HW2, NHP = p.NV * HPP;
+  const int rps = 16 / p.PW, spp = (p.PH * p.PW) >> 4;
+
+  // ---- fixed per-thread staging geometry
+  int x_geo[X_IT];  // (patch << 16) | (halo row << 8) | halo col, or -1
+#pragma unroll
+  for (int it = 0; it < X_IT; ++it) {
+    int idx = tid + 256 * it;
+    int hp = idx / XCH;
+    x_geo[it] = -1;
+    if (hp < NHP) {
+      int pi = hp / HPP, rem = hp - pi * HPP;
+      int hy = rem / HW2;
+      x_geo[it] = (pi << 16) | (hy << 8) | (rem - hy * HW2);
+    }
+  }
+  int y_geo[Y_IT];  // (patch << 16) | (row << 8) | col
+#pragma unroll
+  for (int it = 0; it < Y_IT; ++it) {
+    int idx = tid + 256 * it;
+    int pk = idx / YCH;  // 0..127
+    int s = pk >> 4, pl = pk & 15;
+    int pi = s / spp, sl = s - pi * spp;
+    int r = pl / p.PW, c = pl - r * p.PW;
+    y_geo[it] = (pi << 16) | ((sl * rps + r) << 8) | c;
+  }
+  const int xq = tid % XCH, yq = tid % YCH;  // 256 % XCH == 0 and 256 % YCH == 0, so the chunk column is fixed
+  const bool x_cok = (m0 + xq * 8) < p.Ma, y_cok = (n0 + yq * 8) < p.Nb;
+
+  // ---- fragment addressing (fixed): 16-lane group g covers K rows (pixels) 8g..8g+7 of each 32-pixel step
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int wm = wv >> 1, wn = wv & 1;
+  int xb[4][2], yb[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int pk = 32 * ks + 8 * g + 4 * h + tq;
+      int s = pk >> 4, pl = pk & 15;
+      int pi = s / spp, sl = s - pi * spp;
+      int r = pl / p.PW, c = pl - r * p.PW;
+      xb[ks][h] = (pi * HPP + (sl * rps + r) * HW2 + c) * XS + wm * 16 * WM + 4 * tp;
+      yb[ks][h] = pk * YS + wn * 16 * WN + 4 * tp;
+    }
+
+  f32x4_t acc[9][WM][WN];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[t][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  auto tr8 = [&](const bf16_t* base, int a0, int a1) -> bf16x8_t {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(base + a0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(base + a1));
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  const int g_begin = blockIdx.x * p.groups_per_block;
+  int g_end = g_begin + p.groups_per_block;
+  if (g_end > p.ngroups) g_end = p.ngroups;
+  for (int grp = g_begin; grp < g_end; ++grp) {
+    if (tid < p.NV) {
+      int gp = grp * p.NV + tid;
+      int valid = gp < p.npatches;
+      int gpc = valid ? gp : 0;
+      int v = gpc / p.tiles_per_v, tt = gpc - v * p.tiles_per_v;
+      int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+      int dd = p.d * p.d;
+      int b = v / dd, ab = v - b * dd;
+      s_patch[tid][0] = b; s_patch[tid][1] = ab / p.d; s_patch[tid][2] = ab - (ab / p.d) * p.d;
+      s_patch[tid][3] = ty * p.PH; s_patch[tid][4] = tx * p.PW; s_patch[tid][5] = valid;
+    }
+    __syncthreads();  // patch table ready; also: previous iteration's LDS reads are done
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      int idx = tid + 256 * it;
+      if (x_geo[it] < 0) continue;
+      const int* pt = s_patch[x_geo[it] >> 16];
+      uint4 v = make_uint4(0, 0, 0, 0);
+      int ly = pt[3] + ((x_geo[it] >> 8) & 255) - 1, lx = pt[4] + (x_geo[it] & 255) - 1;
+      if (x_cok && pt[5] && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl) {
+        int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * ly) * p.W + pt[2] + p.d * lx;
+        v = *reinterpret_cast<const uint4*>(p.x + pix * p.ldx + m0 + xq * 8);
+      }
+      *reinterpret_cast<uint4*>(&lds_x[(idx / XCH) * XS + xq * 8]) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      int idx = tid + 256 * it;
+      if (idx >= 128 * YCH) continue;
+      const int* pt = s_patch[y_geo[it] >> 16];
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (y_cok && pt[5]) {
+        int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * (pt[3] + ((y_geo[it] >> 8) & 255))) * p.W + pt[2] + p.d * (pt[4] + (y_geo[it] & 255));
+        v = *reinterpret_cast<const uint4*>(p.dy + pix * p.lddy + n0 + yq * 8);
+      }
+      *reinterpret_cast<uint4*>(&lds_y[(idx / YCH) * YS + yq * 8]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t bfr[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bfr[j] = tr8(lds_y, yb[ks][0] + 16 * j, yb[ks][1] + 16 * j);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * HW2 + (t % 3)) * XS;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          bf16x8_t af = tr8(lds_x, xb[ks][0] + toff + 16 * i, xb[ks][1] + toff + 16 * i);
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[t][i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // D[row = m_local = 4g + r][col = n_local = li]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        int n = n0 + wn * 16 * WN + j * 16 + li;
+        if (n >= p.Nb) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int m = m0 + wm * 16 * WM + i * 16 + g * 4 + r;
+          if (m < p.Ma) atomicAdd(p.out + ((int64_t)t * p.Ma + m) * p.Nb + n, acc[t][i][j][r]);
+        }
+      }
+}
+
+// Returns 1 and launches if the geometry fits, 0 if the caller must use the per-tap kernel.
+int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, int B, int H, int W, int d, int Ma, int Nb, int ldx, int lddy,
+                                hipStream_t s) {
+  static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
+  if (disabled) return 0;
+  if (d < 1 || H % d || W % d) return 0;
+  const int Hl = H / d, Wl = W / d;
+  int PW;
+  if (Wl % 16 == 0) PW = 16;
+  else if (Wl == 8 || Wl == 4) PW = Wl;
+  else return 0;
+  int PH = 128 / PW;
+  if (PH > Hl) PH = Hl;
+  if (Hl % PH || (PH * PW) % 16) return 0;
+  const int NV = 128 / (PH * PW);
+  if (NV * (PH + 2) * (PW + 2) > 288) return 0;
+  WgHaloParams p = {};
+  p.x = x; p.dy = dy; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.d = d; p.Hl = Hl; p.Wl = Wl; p.PH = PH; p.PW = PW; p.NV = NV;
+  p.tiles_x = Wl / PW;
+  p.tiles_per_v = (Hl / PH) * p.tiles_x;
+  p.npatches = B * d * d * p.tiles_per_v;
+  p.ngroups = (p.npatches + NV - 1) / NV;
+  p.ldx = ldx; p.lddy = lddy; p.Ma = Ma; p.Nb = Nb;
+  const bool small = Ma <= 32 && Nb <= 32;
+  const int bm = small ? 32 : 64, bn = small ? 32 : 64;
+  const int tm = (Ma + bm - 1) / bm;
+  p.ntiles_n = (Nb + bn - 1) / bn;
+  const int tiles = tm * p.ntiles_n;
+  // split-K: aim for ~512 workgroups, but keep >= 4 pixel chunks per workgroup so the atomic tail stays small
+  int splits = (512 + tiles - 1) / tiles;
+  int max_splits = (p.ngroups + 3) / 4;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.groups_per_block = (p.ngroups + splits - 1) / splits;
+  splits = (p.ngroups + p.groups_per_block - 1) / p.groups_per_block;
+  const int slot = usseg_prof_start(2, s);
+  if (small) hipLaunchKernelGGL((wgrad_halo_kernel<1, 1>), dim3(splits, tiles), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
+  usseg_prof_stop(2, slot, s);
+  return 1;
+}
