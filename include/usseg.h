@@ -74,9 +74,11 @@ int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const void* wp_fwd, 
  * packed with in/out swapped (K index = tap*Cout + co).  dx has d->Cin channels, stride d->ldx. */
 int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp_dgrad, const void* residual,
                        int32_t ldr, void* dx, usseg_stream_t stream);
-/* dW[tap][ci][co] += sum_pixels x * dy  (fp32 atomics into a zeroed [ntaps][Cin][Cout] scratch). */
-int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw_scratch,
-                       usseg_stream_t stream);
+/* dW[tap][ci][co] += sum_pixels x * dy, accumulated into a [ntaps][Cin][Cout] fp32 buffer (zeroed or holding a
+ * running sum).  ws (may be NULL) is a caller-owned fp32 workspace of ws_floats floats for the split-K partial slabs of
+ * the 3x3 kernel (any size helps; 9*Cin*Cout*512 is always enough); without it the partials are combined with atomics. */
+int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw_scratch, float* ws,
+                       int64_t ws_floats, usseg_stream_t stream);
 
 /* ---- transposed convolution: Conv2DTranspose 3x3 s2 (Decoder.py:57,120) and 4x4 s2 (TBI_ResNest.py:124,210),
  * padding 'same' (k=3: out[2i+k] += x[i] w[k], last row/col cropped; k=4: out[2i+k-1]).  Four parity-class

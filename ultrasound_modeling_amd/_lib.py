@@ -60,7 +60,7 @@ _PROTOS = {
     "usseg_version": (C.c_int, []),
     "usseg_conv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_conv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
-    "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp]),
+    "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "usseg_tconv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_tconv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_tconv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp]),

@@ -74,7 +74,7 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
 
 // 3x3 weight gradient with an LDS halo tile (wgrad_halo.hip): 1 if it took the launch, 0 otherwise
 int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, int B, int H, int W, int d, int Ma, int Nb, int ldx, int lddy,
-                                hipStream_t s);
+                                float* ws, int64_t ws_floats, hipStream_t s);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

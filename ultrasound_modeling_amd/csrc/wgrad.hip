@@ -138,12 +138,13 @@ static int launch_wgrad(WgradParams& p, int ntaps, hipStream_t s) {
   return usseg_check_launch("wgrad");
 }
 
-extern "C" int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw, usseg_stream_t stream) {
+extern "C" int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw, float* ws, int64_t ws_floats,
+                                  usseg_stream_t stream) {
   USSEG_CHECK_ARG(d && x && dy && dw, "null pointer");
   USSEG_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "channels must be multiples of 8");
   USSEG_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "conv ksize must be 1 or 3");
   if (d->ksize == 3 && usseg_try_launch_wgrad_halo((const bf16_t*)x, (const bf16_t*)dy, dw, d->B, d->H, d->W, d->dilation, d->Cin, d->Cout,
-                                                   d->ldx, d->ldy, (hipStream_t)stream))
+                                                   d->ldx, d->ldy, ws, ws_floats, (hipStream_t)stream))
     return usseg_check_launch("wgrad_halo");
   WgradParams p = {};
   p.a = (const bf16_t*)x; p.b = (const bf16_t*)dy; p.out = dw;

@@ -14,6 +14,7 @@ struct WgHaloParams {
   const bf16_t* x;
   const bf16_t* dy;
   float* out;
+  float* ws;  // partial slabs [splits][9][Ma][Nb], or NULL (atomics into out)
   int32_t B, H, W, d, Hl, Wl, PH, PW, NV;
   int32_t tiles_x, tiles_per_v, npatches, ngroups, groups_per_block;
   int32_t ldx, lddy, Ma, Nb, ntiles_n;
@@ -154,7 +155,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p
     }
   }
 
-  // D[row = m_local = 4g + r][col = n_local = li]
+  // D[row = m_local = 4g + r][col = n_local = li].  With a partials workspace every split stores its own
+  // [9][Ma][Nb] slab with plain stores (summed by wgrad_finish_kernel); without one it falls back to atomics.
+  float* dst = p.ws ? p.ws + (int64_t)blockIdx.x * 9 * p.Ma * p.Nb : p.out;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -166,14 +169,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int m = m0 + wm * 16 * WM + i * 16 + g * 4 + r;
-          if (m < p.Ma) atomicAdd(p.out + ((int64_t)t * p.Ma + m) * p.Nb + n, acc[t][i][j][r]);
+          if (m < p.Ma) {
+            float* q = dst + ((int64_t)t * p.Ma + m) * p.Nb + n;
+            if (p.ws) *q = acc[t][i][j][r];
+            else atomicAdd(q, acc[t][i][j][r]);
+          }
         }
       }
 }
 
+// out[i] += sum_s ws[s][i]  (n floats per slab, n % 4 == 0)
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* ws, int splits, int64_t n4, float* out) {
+  const float4* w4 = reinterpret_cast<const float4*>(ws);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int s = 0; s < splits; ++s) {
+      float4 v = w4[(int64_t)s * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float4 o = o4[i];
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    o4[i] = o;
+  }
+}
+
 // Returns 1 and launches if the geometry fits, 0 if the caller must use the per-tap kernel.
 int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, int B, int H, int W, int d, int Ma, int Nb, int ldx, int lddy,
-                                hipStream_t s) {
+                                float* ws, int64_t ws_floats, hipStream_t s) {
   static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
   if (disabled) return 0;
   if (d < 1 || H % d || W % d) return 0;
@@ -200,16 +224,28 @@ int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, i
   const int tm = (Ma + bm - 1) / bm;
   p.ntiles_n = (Nb + bn - 1) / bn;
   const int tiles = tm * p.ntiles_n;
-  // split-K: aim for ~512 workgroups, but keep >= 4 pixel chunks per workgroup so the atomic tail stays small
+  // split-K over pixel chunks: aim for ~512 workgroups with >= 2 chunks each.  With a workspace every split writes its
+  // own partial slab (plain stores) and wgrad_finish_kernel sums them; fp32 atomics into a 9*64*64 tile from hundreds of
+  // workgroups run at the ~1.3 TB/s atomic rate and cost more than the MFMAs, so they are only the no-workspace fallback.
+  const int64_t slab = (int64_t)9 * Ma * Nb;
   int splits = (512 + tiles - 1) / tiles;
-  int max_splits = (p.ngroups + 3) / 4;
+  int max_splits = (p.ngroups + 1) / 2;
+  if (!ws) max_splits = (p.ngroups + 15) / 16;
+  else if ((int64_t)max_splits * slab > ws_floats) max_splits = (int)(ws_floats / slab);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  p.ws = (ws && splits > 1 && (int64_t)splits * slab <= ws_floats) ? ws : nullptr;
   p.groups_per_block = (p.ngroups + splits - 1) / splits;
   splits = (p.ngroups + p.groups_per_block - 1) / p.groups_per_block;
   const int slot = usseg_prof_start(2, s);
   if (small) hipLaunchKernelGGL((wgrad_halo_kernel<1, 1>), dim3(splits, tiles), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
+  if (p.ws) {
+    int64_t n4 = slab / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid), dim3(256), 0, s, p.ws, splits, n4, out);
+  }
   usseg_prof_stop(2, slot, s);
   return 1;
 }

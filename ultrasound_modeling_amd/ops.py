@@ -33,6 +33,18 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 _REDUCE_WS = {}
+_WGRAD_WS = {}
+WGRAD_WS_FLOATS = 64 << 20   # 256 MB of the 288 GB: split-K partial slabs of the 3x3 weight-gradient kernel
+
+
+def wgrad_ws(device) -> torch.Tensor:
+    key = str(device)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = torch.empty(WGRAD_WS_FLOATS, dtype=torch.float32, device=device)
+        _WGRAD_WS[key] = ws
+    return ws
+
 
 
 def reduce_ws(device) -> torch.Tensor:
@@ -96,7 +108,9 @@ def conv2d_wgrad(x, dy, ksize, dilation, dw: torch.Tensor):
     _, _, _, Cout, ldy = geom(dy)
     assert dw.dtype == torch.float32 and dw.numel() == ksize * ksize * Cin * Cout
     d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation)
-    L.check(L.load().usseg_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _stream()), "conv2d_wgrad")
+    ws = wgrad_ws(x.device)
+    L.check(L.load().usseg_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+            "conv2d_wgrad")
     return dw
 
 
