@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import (KERAS_LRELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, LayerNormalization,
+from .layers import (KERAS_BN_EPS, KERAS_LRELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, LayerNormalization,
                      LeakyReLU)
 from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 
@@ -43,12 +43,49 @@ class DecoderBlock(nn.Module):
             setattr(self, f"bn2_{j}", BatchNormalization(oc // 4))
         self.up = Conv2DTranspose(self.in_channels, oc, 3)                            # :57
 
+    # ---- the four parallel branches of a stage share one BatchNormalization launch: their gamma / beta / conv-bias
+    # variables are laid out back to back in the flat buffer and their moving statistics share one device buffer
+    def adjacent_params(self):
+        groups = []
+        for st in ("1", "2"):
+            groups.append(([getattr(self, f"bn{st}_{j}").gamma for j in range(4)], 0))
+            groups.append(([getattr(self, f"bn{st}_{j}").beta for j in range(4)], 0))
+            groups.append(([getattr(self, f"conv{st}_{j}").bias for j in range(4)], 0))
+        return groups
+
+    def on_finalize(self, device):
+        oc, q = self.out_channels, self.out_channels // 4
+        assert q % 8 == 0
+        self._bn = {}
+        for st in ("1", "2"):
+            bns = [getattr(self, f"bn{st}_{j}") for j in range(4)]
+            mean = torch.cat([b.moving_mean_p.to(device) for b in bns])
+            var = torch.cat([b.moving_variance_p.to(device) for b in bns])
+            for j, b in enumerate(bns):
+                b._buffers["moving_mean_p"] = mean[j * q:(j + 1) * q]
+                b._buffers["moving_variance_p"] = var[j * q:(j + 1) * q]
+            span = lambda t: torch.as_strided(t, (oc,), (1,))
+            c0 = getattr(self, f"conv{st}_0")
+            self._bn[st] = dict(mean=mean, var=var, gamma=span(bns[0].gamma.data), beta=span(bns[0].beta.data),
+                                dgamma=span(bns[0].gamma.grad), dbeta=span(bns[0].beta.grad), dbias=span(c0.bias.grad))
+            for a_, b_ in zip(bns[:-1], bns[1:]):
+                assert b_.gamma.data_ptr() == a_.gamma.data_ptr() + 4 * q and b_.beta.data_ptr() == a_.beta.data_ptr() + 4 * q
+
+    def _bn_fwd(self, st, raw, out):
+        d = self._bn[st]
+        return ops.norm_act_fwd(raw, self.out_channels, d["gamma"], d["beta"], out, 1, 1, KERAS_BN_EPS, ACT_LRELU, KERAS_LRELU_ALPHA,
+                                d["mean"], d["var"])
+
+    def _bn_bwd(self, st, raw, dy, dx):
+        d = self._bn[st]
+        return ops.norm_act_bwd(raw, dy, self.out_channels, d["gamma"], d["beta"], dx, d["dgamma"], d["dbeta"], 1, 1, KERAS_BN_EPS,
+                                ACT_LRELU, KERAS_LRELU_ALPHA, d["mean"], d["var"], dbias=d["dbias"])
+
     def forward(self, x, skip=None, out=None):
         """x [B,h,w,in]; skip [B,2h,2w,skip] or None; ``out``: optional [B,2h,2w,oc] slice to write the result into."""
         B, H, W, _, _ = ops.geom(x)
         dev = x.device
         oc, q = self.out_channels, self.out_channels // 4
-        a = KERAS_LRELU_ALPHA
         has_skip = skip is not None
         c1 = oc + (self.skip_channels if has_skip else 0)
         assert has_skip or self.skip_channels == 0, "block was built for a skip connection"
@@ -57,18 +94,15 @@ class DecoderBlock(nn.Module):
         if has_skip:
             ops.copy_channels(skip, cat[..., oc:])                                    # :66
         raw1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
-        act1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
-        for j in range(4):                                                            # :67-76
-            sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"conv1_{j}").forward(cat, out=raw1[..., sl])
-            getattr(self, f"bn1_{j}").forward(raw1[..., sl], ACT_LRELU, a, out=act1[..., sl])
+        for j in range(4):                                                            # :67-74 convs write their channel slice
+            getattr(self, f"conv1_{j}").forward(cat, out=raw1[..., j * q:(j + 1) * q])
+        act1 = self._bn_fwd("1", raw1, ops.new_act(B, 2 * H, 2 * W, oc, dev))        # :68-76 four BNs + LeakyReLU, one launch
         raw2 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
+        for j in range(4):                                                            # :79-86
+            getattr(self, f"conv2_{j}").forward(act1, out=raw2[..., j * q:(j + 1) * q])
         out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, oc, dev)
-        for j in range(4):                                                            # :79-88
-            sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"conv2_{j}").forward(act1, out=raw2[..., sl])
-            getattr(self, f"bn2_{j}").forward(raw2[..., sl], ACT_LRELU, a, out=out[..., sl])
-        self._has_skip = has_skip
+        self._bn_fwd("2", raw2, out)                                                  # :80-88
+        self._has_skip, self._raw = has_skip, (raw1, raw2)
         return out
 
     def backward(self, dout):
@@ -76,23 +110,16 @@ class DecoderBlock(nn.Module):
         oc, q = self.out_channels, self.out_channels // 4
         B, H2, W2, _, _ = ops.geom(dout)
         dev = dout.device
-        draw2 = ops.new_act(B, H2, W2, oc, dev)
-        for j in range(4):
-            sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"bn2_{j}").backward(dout[..., sl], dx=draw2[..., sl], dbias=getattr(self, f"conv2_{j}").bias.grad)
+        raw1, raw2 = self._raw
+        draw2 = self._bn_bwd("2", raw2, dout, ops.new_act(B, H2, W2, oc, dev))
         dact1 = ops.new_act(B, H2, W2, oc, dev)
         for j in range(4):
-            sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"conv2_{j}").backward(draw2[..., sl], dx=dact1, accumulate_dx=(j > 0), skip_bias=True)
-        draw1 = ops.new_act(B, H2, W2, oc, dev)
-        for j in range(4):
-            sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"bn1_{j}").backward(dact1[..., sl], dx=draw1[..., sl], dbias=getattr(self, f"conv1_{j}").bias.grad)
+            getattr(self, f"conv2_{j}").backward(draw2[..., j * q:(j + 1) * q], dx=dact1, accumulate_dx=(j > 0), skip_bias=True)
+        draw1 = self._bn_bwd("1", raw1, dact1, ops.new_act(B, H2, W2, oc, dev))
         c1 = oc + (self.skip_channels if self._has_skip else 0)
         dcat = ops.new_act(B, H2, W2, c1, dev)
         for j in range(4):
-            sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"conv1_{j}").backward(draw1[..., sl], dx=dcat, accumulate_dx=(j > 0), skip_bias=True)
+            getattr(self, f"conv1_{j}").backward(draw1[..., j * q:(j + 1) * q], dx=dcat, accumulate_dx=(j > 0), skip_bias=True)
         dx = self.up.backward(dcat[..., :oc])
         dskip = dcat[..., oc:] if self._has_skip else None
         return dx, dskip

@@ -285,7 +285,8 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->ldx;
   if (p.M <= 0) return USSEG_OK;
   int ppb = 4 * (64 / p.LPP);
-  unsigned grid = grid_for(p.M, ppb * 8, USSEG_REDUCE_MAX_BLOCKS);
+  // small tensors are latency bound (each loop trip is a dependent load -> store): spread them over many workgroups
+  unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
   hipLaunchKernelGGL(norm_act_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
   return usseg_check_launch("norm_act_bwd");
