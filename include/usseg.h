@@ -124,12 +124,16 @@ typedef struct UssegNormDesc {
   int32_t act;
   float alpha;
 } UssegNormDesc;
+/* mask (may be NULL): bf16 tensor [M][ldm] multiplied into the ACTIVATED output (dropout: 0 or 1/keep; since the mask is
+ * non-negative relu(bn(x)*mask) == relu(bn(x))*mask, TBI_ResNest.py:213-218); the backward applies it to dy. */
 int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const float* gamma, const float* beta,
-                       const float* mean, const float* var, void* y, usseg_stream_t stream);
+                       const float* mean, const float* var, const void* mask, int32_t ldm, void* y, usseg_stream_t stream);
+/* tf.nn.dropout mask (TBI_ResNest.py:216): mask = keep ? 1/(1-rate) : 0 from a counter-based hash of (seed, index). */
+int usseg_dropout_mask(void* mask, int64_t M, int32_t C, int32_t ld, uint64_t seed, float rate, usseg_stream_t stream);
 /* dx, and dgamma/dbeta accumulated.  x is the SAME pre-normalisation input as in fwd. */
 int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma, const float* beta,
-                       const float* mean, const float* var, void* dx, float* dgamma, float* dbeta, float* dbias,
-                       float* ws, usseg_stream_t stream);
+                       const float* mean, const float* var, const void* mask, int32_t ldm, void* dx, float* dgamma,
+                       float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
 /* Every per-channel reduction (norm backward, colsum, channel_stats, split-attention reductions) writes one partial
  * row per workgroup into the caller's fp32 workspace `ws` (at least usseg_reduce_ws_floats() floats) and a finishing
  * kernel ADDS the column sums to the destination: no atomics, bitwise reproducible.

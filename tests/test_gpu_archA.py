@@ -1,0 +1,108 @@
+"""GPU parity of Arch A (TBI_ResNest.py model + my_loss_cat + step) against the fp64 oracle, same weights and inputs.
+
+Tolerances are the bf16-depth bars of test_gpu_model.py (probabilities 2e-2, loss 5e-3, gradients median 3e-2 and
+every tensor within 1.5e-1 of the oracle run with bf16 storage emulation).  The always-on tf.nn.dropout(0.5) of the
+first three decoder levels (TBI_ResNest.py:215-216) is made deterministic by injecting the keep masks on both sides.
+"""
+import pytest
+import torch
+
+import usseg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def arch_a():
+    from ultrasound_modeling_amd.TBI_ResNest import ResNest
+    P = {k: v.float().double() for k, v in O.init_archA_params(channel=1, radix=3, kpaths=4, seed=4, perturb=True).items()}
+    net = ResNest(64, 64, 1, 3, ksize=3, radix=3, kpaths=4, learning_rate=5e-3)
+    net.load_params(P)
+    gen = torch.Generator().manual_seed(8)
+    keep = [(torch.rand(2, 2 ** (i + 1), 2 ** (i + 1), 512, generator=gen) > 0.5).double() for i in range(3)]
+    net.resModel.injected_masks = [(k * 2.0).to(torch.bfloat16).to(DEV) for k in keep]      # kernel mask = keep / (1 - rate)
+    return net, P, keep
+
+
+def test_surface(arch_a):
+    net, P, _ = arch_a
+    assert set(dict(net.resModel.named_parameters())) == set(O.trainable_names(P))
+    assert net.flat.n_trainable == sum(P[k].numel() for k in O.trainable_names(P))      # 25.7 M
+    assert abs(net.flat.n_trainable - 25.7e6) < 0.1e6
+
+
+def test_forward_loss_and_gradients(arch_a):
+    net, P, keep = arch_a
+    x, y = O.synthetic_batch(2, 64, 64, 1, seed=12)
+    xb = x.to(torch.bfloat16).double()
+    names = O.trainable_names(P)
+
+    def oracle_grads(storage):
+        O.STORAGE_DTYPE = storage
+        try:
+            leaves = [P[n].clone().requires_grad_(True) for n in names]
+            Pl = dict(P)
+            Pl.update(zip(names, leaves))
+            probs = O.archA_forward(xb, Pl, 3, 4, dropout_masks=keep)
+            lm = O.my_loss_cat(y, probs, 64, 64)
+            grads = torch.autograd.grad(lm.sum(), leaves)          # tape.gradient of a non-scalar = gradient of its sum
+        finally:
+            O.STORAGE_DTYPE = None
+        return probs.detach(), lm.detach(), dict(zip(names, grads))
+    probs_r, lm_r, g_r = oracle_grads(None)
+    _, _, g_e = oracle_grads(torch.bfloat16)
+
+    before = net.export_params()
+    loss_map, acc, probs = net.step(x, y.float(), train=True)
+    torch.cuda.synchronize()
+    assert tuple(loss_map.shape) == (64, 64) and tuple(probs.shape) == (2, 64, 64, 3)
+    e_p, e_l = rel(probs, probs_r), rel(loss_map, lm_r)
+    print(f"probs rel {e_p:.3e}  loss-map rel {e_l:.3e}  acc {acc.item():.3f}")
+    assert e_p < 2e-2 and e_l < 2e-2
+    acc_r = (probs_r.argmax(-1) == y.argmax(-1)).double().mean().item()
+    assert abs(acc.item() - acc_r) < 2e-2
+    g = net.export_grads()
+    errs = sorted(rel(g[k], g_r[k]) for k in names)
+    worst_emu = max(((rel(g[k], g_e[k]), k) for k in names))
+    print(f"grad rel median {errs[len(errs) // 2]:.3e} p90 {errs[int(len(errs) * .9)]:.3e}; worst vs bf16-emulated oracle {worst_emu}")
+    assert errs[len(errs) // 2] < 3e-2 and errs[int(len(errs) * 0.9)] < 1e-1
+    assert worst_emu[0] < 1.5e-1
+    # plain Adam (no clipping), lr 5e-3: compare the update
+    new = [P[n].clone() for n in names]
+    O.adam_step(new, [g_r[n] for n in names], [torch.zeros_like(t) for t in new], [torch.zeros_like(t) for t in new], 1, 5e-3)
+    after = net.export_params()
+    num = sum(((after[n].double().cpu() - before[n].double().cpu()) - (t - P[n])).pow(2).sum().item() for n, t in zip(names, new))
+    den = sum((t - P[n]).pow(2).sum().item() for n, t in zip(names, new))
+    assert (num / den) ** 0.5 < 0.2
+
+
+def test_eval_step_and_random_dropout(arch_a):
+    net, P, keep = arch_a
+    x, y = O.synthetic_batch(2, 64, 64, 1, seed=13)
+    l0, _, p0 = net.step(x, y.float(), train=False)
+    l1, _, p1 = net.step(x, y.float(), train=False)
+    assert torch.equal(p0, p1)                                  # injected masks: deterministic
+    saved, net.resModel.injected_masks = net.resModel.injected_masks, None
+    try:
+        _, _, q0 = net.step(x, y.float(), train=False)
+        _, _, q1 = net.step(x, y.float(), train=False)
+        assert not torch.equal(q0, q1)                          # the raw dropout is active at test time too (:215-216)
+        assert torch.isfinite(q0).all()
+    finally:
+        net.resModel.injected_masks = saved
+
+
+def test_dropout_mask_statistics():
+    from ultrasound_modeling_amd import ops
+    m = ops.dropout_mask(torch.empty(4, 16, 16, 512, dtype=torch.bfloat16, device=DEV), seed=123, rate=0.5)
+    vals = m.float().unique().tolist()
+    assert vals == [0.0, 2.0]
+    assert abs((m > 0).float().mean().item() - 0.5) < 5e-3
+    m2 = ops.dropout_mask(torch.empty_like(m), seed=124, rate=0.5)
+    assert ((m > 0) != (m2 > 0)).float().mean().item() > 0.45  # different seed -> independent mask

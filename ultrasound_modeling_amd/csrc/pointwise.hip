@@ -88,6 +88,8 @@ extern "C" int64_t usseg_reduce_ws_floats(void) { return (int64_t)USSEG_REDUCE_M
 struct NormParams {
   const bf16_t* x; const bf16_t* dy; bf16_t* y; bf16_t* dx;
   const float *gamma, *beta, *mean, *var;
+  const bf16_t* mask;  // optional multiplicative mask on the activated output (dropout: 0 or 1/keep), stride ldm
+  int32_t ldm;
   float *dgamma, *dbeta, *dbias, *ws;
   int64_t M;
   int32_t C, Cphys, ldx, ldy, lddy, lddx, G, Cg, mode, act, LPP;
@@ -182,12 +184,24 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (grp[j] >= 0) ? apply_act(ga[j] * xh[j] + be[j], p.act, p.alpha) : 0.f;
+      if (p.mask && valid) {
+        float mk[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.mask + m * p.ldm + c0), mk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= mk[j];
+      }
       if (valid) *reinterpret_cast<uint4*>(p.y + m * p.ldy + c0) = pack8(o);
     } else {
       float dyv[8];
       if (valid) {
         uint4 raw = *reinterpret_cast<const uint4*>(p.dy + m * p.lddy + c0);
         unpack8(raw, dyv);
+        if (p.mask) {
+          float mk[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.mask + m * p.ldm + c0), mk);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dyv[j] *= mk[j];
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) dyv[j] = 0.f;
@@ -260,12 +274,14 @@ static int norm_common(const UssegNormDesc* d, NormParams& p) {
 }
 
 extern "C" int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const float* gamma, const float* beta,
-                                  const float* mean, const float* var, void* y, usseg_stream_t stream) {
+                                  const float* mean, const float* var, const void* mask, int32_t ldm, void* y,
+                                  usseg_stream_t stream) {
   NormParams p = {};
   int rc = norm_common(d, p);
   if (rc) return rc;
   USSEG_CHECK_ARG(x && y && gamma && beta && (d->mode == 0 || (mean && var)), "norm fwd: null pointer");
   p.x = (const bf16_t*)x; p.y = (bf16_t*)y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
+  p.mask = (const bf16_t*)mask; p.ldm = ldm;
   p.ldx = d->ldx; p.ldy = d->ldy;
   if (p.M <= 0) return USSEG_OK;
   int ppb = 4 * (64 / p.LPP);
@@ -274,13 +290,14 @@ extern "C" int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const f
 }
 
 extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma,
-                                  const float* beta, const float* mean, const float* var, void* dx, float* dgamma,
-                                  float* dbeta, float* dbias, float* ws, usseg_stream_t stream) {
+                                  const float* beta, const float* mean, const float* var, const void* mask, int32_t ldm,
+                                  void* dx, float* dgamma, float* dbeta, float* dbias, float* ws, usseg_stream_t stream) {
   NormParams p = {};
   int rc = norm_common(d, p);
   if (rc) return rc;
   USSEG_CHECK_ARG(x && dy && dx && gamma && beta && dgamma && dbeta && ws && (d->mode == 0 || (mean && var)), "norm bwd: null pointer");
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
+  p.mask = (const bf16_t*)mask; p.ldm = ldm;
   p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias; p.ws = ws;
   p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->ldx;
   if (p.M <= 0) return USSEG_OK;
@@ -587,4 +604,30 @@ extern "C" int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t 
   USSEG_CHECK_ARG(jobs_dev && njobs > 0 && njobs < 65536, "pack_weights_batched: bad args");
   hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return usseg_check_launch("pack_weights_batched");
+}
+
+// ---- dropout mask (tf.nn.dropout(x, rate), TBI_ResNest.py:216): mask[m][c] = keep ? 1/(1-rate) : 0, counter-based hash RNG
+__device__ __forceinline__ uint32_t hash32(uint64_t v) {
+  v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
+  return (uint32_t)v;
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(bf16_t* mask, int64_t M, int CH, int ld, uint64_t seed, float rate) {
+  const int64_t total = M * CH;
+  const float keep_scale = 1.f / (1.f - rate);
+  const uint32_t thr = (uint32_t)(rate * 4294967296.0);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t m = i / CH;
+    int c0 = (int)(i - m * CH) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = hash32(seed * 0x9e3779b97f4a7c15ULL + (uint64_t)(i * 8 + j)) >= thr ? keep_scale : 0.f;
+    *reinterpret_cast<uint4*>(mask + m * ld + c0) = pack8(v);
+  }
+}
+extern "C" int usseg_dropout_mask(void* mask, int64_t M, int32_t C, int32_t ld, uint64_t seed, float rate, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(mask && C % 8 == 0 && ld % 8 == 0 && rate >= 0.f && rate < 1.f, "dropout_mask: bad args");
+  if (M <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(M * (C / 8), 256 * 2, 4096)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)mask, M,
+                     C / 8, ld, seed, rate);
+  return usseg_check_launch("dropout_mask");
 }

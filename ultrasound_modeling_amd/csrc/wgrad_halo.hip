@@ -179,19 +179,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p
 }
 
 // out[i] += sum_s ws[s][i]  (n floats per slab, n % 4 == 0)
+// Workgroup = 64 float4 outputs x 4 slab slices; blockIdx.y splits the slabs further when the output is small, and
+// those partial sums meet in `out` through a handful of atomics per element.
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* ws, int splits, int64_t n4, float* out) {
+  __shared__ float4 s_part[4][64];
   const float4* w4 = reinterpret_cast<const float4*>(ws);
-  float4* o4 = reinterpret_cast<float4*>(out);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int per_y = (splits + gridDim.y - 1) / gridDim.y;
+  const int s0 = blockIdx.y * per_y;
+  int s1 = s0 + per_y;
+  if (s1 > splits) s1 = splits;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < n4; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + o;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int s = 0; s < splits; ++s) {
-      float4 v = w4[(int64_t)s * n4 + i];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    if (i < n4) {
+#pragma unroll 4
+      for (int s = s0 + sl; s < s1; s += 4) {
+        float4 v = w4[(int64_t)s * n4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
     }
-    float4 o = o4[i];
-    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-    o4[i] = o;
+    s_part[sl][o] = a;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+      float4 t = s_part[0][o];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) { t.x += s_part[q][o].x; t.y += s_part[q][o].y; t.z += s_part[q][o].z; t.w += s_part[q][o].w; }
+      float* d = out + i * 4;
+      if (gridDim.y == 1) { d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
+      else { atomicAdd(d, t.x); atomicAdd(d + 1, t.y); atomicAdd(d + 2, t.z); atomicAdd(d + 3, t.w); }
+    }
+    __syncthreads();
   }
 }
 
@@ -242,9 +260,11 @@ int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, i
   else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
   if (p.ws) {
     int64_t n4 = slab / 4;
-    int grid = (int)((n4 + 255) / 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid), dim3(256), 0, s, p.ws, splits, n4, out);
+    int gx = (int)((n4 + 63) / 64);
+    if (gx > 2048) gx = 2048;
+    int gy = 1;  // small outputs: also split the slab axis so a few hundred workgroups share the walk
+    while (gx * gy < 256 && splits / (gy * 2) >= 8) gy *= 2;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(gx, gy), dim3(256), 0, s, p.ws, splits, n4, out);
   }
   usseg_prof_stop(2, slot, s);
   return 1;

@@ -182,23 +182,31 @@ def _norm_desc(x, C_logical, out_ld, G, mode, eps, act, alpha) -> NormDesc:
     return NormDesc(B * H * W, C_logical, Cphys, ldx, out_ld, G, mode, eps, act, alpha)
 
 
-def norm_act_fwd(x, C_logical, gamma, beta, out, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None, var=None):
+def norm_act_fwd(x, C_logical, gamma, beta, out, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None, var=None, mask=None):
     d = _norm_desc(x, C_logical, geom(out)[4], G, mode, eps, act, alpha)
+    ldm = geom(mask)[4] if mask is not None else 0
     L.check(L.load().usseg_norm_act_fwd(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean), _ptr(var),
-                                        out.data_ptr(), _stream()), "norm_act_fwd")
+                                        _ptr(mask), ldm, out.data_ptr(), _stream()), "norm_act_fwd")
     return out
 
 
 def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None,
-                 var=None, dbias=None):
+                 var=None, dbias=None, mask=None):
     B, H, W, Cphys, ldx = geom(x)
     lddy = geom(dy)[4]
     assert geom(dx)[4] == ldx, "dx must have the stride of x"
     d = NormDesc(B * H * W, C_logical, Cphys, ldx, lddy, G, mode, eps, act, alpha)
+    ldm = geom(mask)[4] if mask is not None else 0
     L.check(L.load().usseg_norm_act_bwd(C.byref(d), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean),
-                                        _ptr(var), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias),
+                                        _ptr(var), _ptr(mask), ldm, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias),
                                         reduce_ws(x.device).data_ptr(), _stream()), "norm_act_bwd")
     return dx
+
+
+def dropout_mask(mask, seed: int, rate: float):
+    B, H, W, Cc, ld = geom(mask)
+    L.check(L.load().usseg_dropout_mask(mask.data_ptr(), B * H * W, Cc, ld, seed, rate, _stream()), "dropout_mask")
+    return mask
 
 
 def channel_stats(x, C_logical, s, s2):
