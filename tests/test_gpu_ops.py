@@ -74,6 +74,10 @@ CONV_CASES = [
     (1, 64, 64, 8, 16, 3, 1),     # stem conv1 class
     (2, 16, 32, 32, 8, 3, 4),     # 4x8 lattice patches (4 per workgroup)
     (5, 8, 8, 16, 32, 3, 1),      # 8x8 images, odd batch: last workgroup half empty
+    # persistent-weights variant (>= 1024 pixel groups, whole weight operand resident in LDS)
+    (2, 256, 256, 16, 32, 3, 1),  # stem convtmp_1 class, 1024 groups
+    (2, 256, 256, 64, 16, 3, 4),  # decoder b2 class: 2 channel chunks resident, dilation 4
+    (5, 256, 128, 24, 8, 3, 2),   # 1280 groups, 2 per workgroup, Cin not a multiple of 32
 ]
 
 

@@ -210,6 +210,178 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   }
 }
 
+// ---- persistent variant for the HBM-bound layers (few input channels, many pixels) ------------------------------
+// When the whole weight operand of a workgroup's channel tile (nchunks x 9 x BN x 32) fits in LDS it is staged ONCE and
+// the workgroup then walks over many pixel groups: per group it only stages the activation halo tile.  (In the plain
+// kernel a 128-pixel workgroup of the 32->32 stem conv moves 18 KB of weights for 11 KB of activations.)
+// `gpb` consecutive pixel groups per workgroup; their patch geometry is decoded once into LDS.
+template <int NT>
+__global__ __launch_bounds__(256) void conv_halo_persist_kernel(const HaloParams p, const int gpb) {
+  constexpr int BN = 16 * NT, LDSS = 40, MAXHP = 288, MAXG = 16;
+  constexpr int A_IT = (MAXHP * 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];   // [nchunks][9*BN][LDSS] weights, then the halo tile
+  __shared__ int s_patch[MAXG * 8][6];                                // b, la, lb, ly0, lx0, valid
+  bf16_t* lds_w = lds_dyn;
+  bf16_t* lds_a = lds_dyn + (size_t)p.nchunks * 9 * BN * LDSS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = blockIdx.y * BN;
+  const int HW2 = p.PW + 2, HPP = (p.PH + 2) * HW2, NHP = p.NV * HPP;
+  const int ngroups = (p.npatches + p.NV - 1) / p.NV;
+  const int g_begin = blockIdx.x * gpb;
+  int ng = ngroups - g_begin;
+  if (ng > gpb) ng = gpb;
+  const int q = tid & 3;
+
+  // weights: all chunks, once
+  for (int idx = tid; idx < p.nchunks * 9 * BN * 4; idx += 256) {
+    int row = idx >> 2;                  // (ck*9 + t)*BN + n
+    int ck = row / (9 * BN), rem = row - ck * 9 * BN;
+    int t = rem / BN, n = rem - t * BN;
+    int c = ck * 32 + (idx & 3) * 8;
+    int tw = p.flip ? 8 - t : t;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c < p.Cin && (n0 + n) < p.Nw) v = *reinterpret_cast<const uint4*>(p.w + (int64_t)(n0 + n) * p.Kw + tw * p.Cin + c);
+    *reinterpret_cast<uint4*>(&lds_w[row * LDSS + (idx & 3) * 8]) = v;
+  }
+  // patch table of every group this workgroup owns
+  for (int i = tid; i < ng * p.NV; i += 256) {
+    int gp = (g_begin + i / p.NV) * p.NV + (i % p.NV);
+    int valid = gp < p.npatches;
+    int gpc = valid ? gp : 0;
+    int v = gpc / p.tiles_per_v, tt = gpc - v * p.tiles_per_v;
+    int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+    int dd = p.d * p.d;
+    int b = v / dd, ab = v - b * dd;
+    int* e = s_patch[(i / p.NV) * 8 + (i % p.NV)];
+    e[0] = b; e[1] = ab / p.d; e[2] = ab - (ab / p.d) * p.d; e[3] = ty * p.PH; e[4] = tx * p.PW; e[5] = valid;
+  }
+  // fixed staging geometry: (patch, halo row, halo col) of each A item of this thread
+  int a_geo[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    int hp = (tid + 256 * it) >> 2;
+    a_geo[it] = -1;
+    if (hp < NHP) {
+      int pi = hp / HPP, rem = hp - pi * HPP;
+      int hy = rem / HW2;
+      a_geo[it] = (pi << 16) | (hy << 8) | (rem - hy * HW2);
+    }
+  }
+  // this lane's two output pixels: patch, row, col (fixed), LDS base of the top-left tap
+  const int pl = lane & 15, fk = (lane >> 4) * 8;
+  const int rows_per_strip = 16 / p.PW, spp = (p.PH * p.PW) >> 4;
+  int a_base[2], o_pi[2], o_row[2], o_col[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    int s = wv * 2 + s2;
+    int pi = s / spp, sl = s - pi * spp;
+    int r = pl / p.PW, c = pl - r * p.PW;
+    o_pi[s2] = pi; o_row[s2] = sl * rows_per_strip + r; o_col[s2] = c;
+    a_base[s2] = (pi * HPP + o_row[s2] * HW2 + c) * LDSS + fk;
+  }
+  const int w_base = (lane & 15) * LDSS + fk;
+  __syncthreads();
+
+  uint4 ra[A_IT];
+  auto load_a = [&](int gl, int ck) {
+    const int c = ck * 32 + q * 8;
+    const bool cok = c < p.Cin;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a_geo[it] >= 0 && cok) {
+        const int* pt = s_patch[gl * 8 + (a_geo[it] >> 16)];
+        int ly = pt[3] + ((a_geo[it] >> 8) & 255) - 1, lx = pt[4] + (a_geo[it] & 255) - 1;
+        if (pt[5] && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl)
+          v = *reinterpret_cast<const uint4*>(p.x + ((int64_t)(pt[0] * p.H + pt[1] + p.d * ly) * p.W + pt[2] + p.d * lx) * p.ldx + c);
+      }
+      ra[it] = v;
+    }
+  };
+
+  f32x4_t acc[2][NT];
+  const int total = ng * p.nchunks;
+  if (total > 0) load_a(0, 0);
+  for (int it = 0; it < total; ++it) {
+    const int gl = it / p.nchunks, ck = it - gl * p.nchunks;
+    if (ck == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < A_IT; ++k) {
+      int idx = tid + 256 * k;
+      if ((idx >> 2) < NHP) *reinterpret_cast<uint4*>(&lds_a[(idx >> 2) * LDSS + q * 8]) = ra[k];
+    }
+    __syncthreads();
+    if (it + 1 < total) load_a((it + 1) / p.nchunks, (it + 1) % p.nchunks);
+    const bf16_t* wck = lds_w + (size_t)ck * 9 * BN * LDSS;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int toff = ((t / 3) * HW2 + (t % 3)) * LDSS;
+      bf16x8_t xf[2], wf[NT];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) xf[a] = *reinterpret_cast<const bf16x8_t*>(&lds_a[a_base[a] + toff]);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8_t*>(&wck[(t * BN + b * 16) * LDSS + w_base]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+    if (ck != p.nchunks - 1) continue;
+    // ---- epilogue of pixel group gl
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int* pt = s_patch[gl * 8 + o_pi[a]];
+      if (!pt[5]) continue;
+      const int64_t opix = ((int64_t)pt[0] * p.H + pt[1] + p.d * (pt[3] + o_row[a])) * p.W + pt[2] + p.d * (pt[4] + o_col[a]);
+#pragma unroll
+      for (int bt = 0; bt < NT; ++bt) {
+        int n = n0 + bt * 16 + (lane >> 4) * 4;
+        if (n >= p.Nout) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
+        if (p.bias) {
+          float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        if (p.act != USSEG_ACT_NONE) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act, p.alpha);
+        }
+        if (p.res) {
+          uint2 rr = *reinterpret_cast<const uint2*>(p.res + opix * p.ldr + n);
+          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        }
+        if (p.out_f32) {
+          float* dst = reinterpret_cast<float*>(p.y) + opix * p.ldy + n;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + j < p.Nout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+        } else {
+          bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + opix * p.ldy + n;
+          if (p.accumulate) {
+            uint2 o = *reinterpret_cast<const uint2*>(dst);
+            v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
+            v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(dst) = o;
+        }
+      }
+    }
+  }
+}
+
 // Returns 1 and launches if the geometry fits the halo kernel, 0 if the caller must use the gather kernel.
 int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
                                int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
@@ -242,6 +414,27 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
   while (nt > 1 && (int64_t)gx * ((Nout + 16 * nt - 1) / (16 * nt)) < 256 && Nout > 16 * (nt / 2)) nt >>= 1;
   const int gy = (Nout + 16 * nt - 1) / (16 * nt);
   const int slot = usseg_prof_start(1, s);
+  // persistent variant: the tile's whole weight operand fits in 46 KB of LDS and there are pixel groups to amortise it over
+  static const int no_persist = getenv("USSEG_NO_PERSIST") != nullptr;
+  const size_t wbytes = (size_t)p.nchunks * 9 * 16 * nt * 40 * sizeof(bf16_t);
+  if (!no_persist && wbytes <= 46080 && gx >= 1024) {
+    int gpb = (gx + 1023) / 1024;          // ~1024 workgroups (2 per CU resident, two waves of them)
+    if (gpb > 16) gpb = 16;
+    const int pgx = (gx + gpb - 1) / gpb;
+    const size_t dyn = wbytes + (size_t)288 * 40 * sizeof(bf16_t);
+    static bool attr_done = false;   // > 64 KB of LDS per workgroup needs the opt-in (one-time host call, never a stream op)
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)conv_halo_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_halo_persist_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_halo_persist_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_done = true;
+    }
+    if (nt == 1) hipLaunchKernelGGL(conv_halo_persist_kernel<1>, dim3(pgx, gy), dim3(256), dyn, s, p, gpb);
+    else if (nt == 2) hipLaunchKernelGGL(conv_halo_persist_kernel<2>, dim3(pgx, gy), dim3(256), dyn, s, p, gpb);
+    else hipLaunchKernelGGL(conv_halo_persist_kernel<4>, dim3(pgx, gy), dim3(256), dyn, s, p, gpb);
+    usseg_prof_stop(1, slot, s);
+    return 1;
+  }
   if (nt == 1) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(gx, gy), dim3(256), 0, s, p);
   else if (nt == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(gx, gy), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(gx, gy), dim3(256), 0, s, p);

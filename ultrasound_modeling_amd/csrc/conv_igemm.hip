@@ -35,6 +35,10 @@ struct IgemmParams {
   int32_t out_f32;
   int32_t accumulate;
   int16_t tap_dy[16], tap_dx[16], tap_w[16];
+  // Conv2DTranspose forward: the four output-parity classes run as blockIdx.z of ONE launch; class c owns the tap-table
+  // entries [4c, 4c+4) (cls_ntaps[c] of them) and writes output pixels (2*gy + (c>>1), 2*gx + (c&1)).
+  int32_t cls_mode;
+  int16_t cls_ntaps[4];
 };
 
 template <int NT>
@@ -54,6 +58,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int HWg = p.Hg * p.Wg;
+  const int cls = p.cls_mode ? (int)blockIdx.z : 0;
+  const int tbase = cls * 4;
+  const int ntaps = p.cls_mode ? (int)p.cls_ntaps[cls] : p.ntaps;
+  const int oay = p.cls_mode ? (cls >> 1) : p.oay, oax = p.cls_mode ? (cls & 1) : p.oax;
 
   // --- per-thread staging coordinates: chunk column q (0..3) of rows r0 and r0+64
   const int q = tid & 3;
@@ -76,16 +84,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // (tap, chunk-in-tap) of this thread's chunk column, advanced by 4 chunks per K step
   int ti = q / p.cpt;
   int c8 = q - ti * p.cpt;
-  const int nks = (p.nchunks + 3) >> 2;
+  const int nks = (ntaps * p.cpt + 3) >> 2;
   const int Cin = p.cpt * 8;
 
   uint4 ra[2], rw[WCH];
   __syncthreads();  // tap table visible
 
   auto load_step = [&]() {
-    const bool tv = ti < p.ntaps;
+    const bool tv = ti < ntaps;
     int dy = 0, dx = 0, tw = 0;
-    if (tv) { dy = s_tap[ti]; dx = s_tap[16 + ti]; tw = s_tap[32 + ti]; }
+    if (tv) { dy = s_tap[tbase + ti]; dx = s_tap[16 + tbase + ti]; tw = s_tap[32 + tbase + ti]; }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     int rem = mm - b * HWg;
     int gy = rem / p.Wg;
     int gx = rem - gy * p.Wg;
-    int64_t opix = ((int64_t)(b * p.Ho + gy * p.osy + p.oay)) * p.Wo + gx * p.osx + p.oax;
+    int64_t opix = ((int64_t)(b * p.Ho + gy * p.osy + oay)) * p.Wo + gx * p.osx + oax;
 #pragma unroll
     for (int bt = 0; bt < NT; ++bt) {
       int n = n0 + bt * 16 + (lane >> 4) * 4;
@@ -210,15 +218,16 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   dim3 block(256);
   int64_t gx = cdiv64(p.M, 128);
   USSEG_CHECK_ARG(gx < (1ll << 31), "igemm: too many pixel tiles");
+  const unsigned gz = p.cls_mode ? 4 : 1;
   const int slot = usseg_prof_start(1, s);
   if (p.Nout <= 16) {
-    hipLaunchKernelGGL(igemm_kernel<1>, dim3((unsigned)gx, 1), block, 0, s, p);
+    hipLaunchKernelGGL(igemm_kernel<1>, dim3((unsigned)gx, 1, gz), block, 0, s, p);
   } else if (p.Nout <= 32) {
-    hipLaunchKernelGGL(igemm_kernel<2>, dim3((unsigned)gx, 1), block, 0, s, p);
+    hipLaunchKernelGGL(igemm_kernel<2>, dim3((unsigned)gx, 1, gz), block, 0, s, p);
   } else if (p.Nout <= 64) {
-    hipLaunchKernelGGL(igemm_kernel<4>, dim3((unsigned)gx, 1), block, 0, s, p);
+    hipLaunchKernelGGL(igemm_kernel<4>, dim3((unsigned)gx, 1, gz), block, 0, s, p);
   } else {
-    hipLaunchKernelGGL(igemm_kernel<8>, dim3((unsigned)gx, (unsigned)((p.Nout + 127) / 128)), block, 0, s, p);
+    hipLaunchKernelGGL(igemm_kernel<8>, dim3((unsigned)gx, (unsigned)((p.Nout + 127) / 128), gz), block, 0, s, p);
   }
   usseg_prof_stop(1, slot, s);
   return usseg_check_launch("igemm");
@@ -307,14 +316,16 @@ extern "C" int usseg_tconv2d_fwd(const UssegConvDesc* d, const void* x, const vo
   if (rc) return rc;
   USSEG_CHECK_ARG(x && wp && y, "null pointer");
   const int k = d->ksize, pad = (k == 4) ? 1 : 0;
+  IgemmParams p = {};
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.y = y; p.bias = bias; p.res = nullptr; p.ldr = 0;
+  p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
+  p.Hi = d->H; p.Wi = d->W; p.ldx = d->ldx; p.isy = p.isx = 1;
+  p.Ho = 2 * d->H; p.Wo = 2 * d->W; p.ldy = d->ldy; p.osy = p.osx = 2;
+  p.cpt = d->Cin / 8;
+  p.cls_mode = 1;
   for (int a = 0; a < 2; ++a)
     for (int b = 0; b < 2; ++b) {
-      IgemmParams p = {};
-      p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.y = y; p.bias = bias; p.res = nullptr; p.ldr = 0;
-      p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
-      p.Hi = d->H; p.Wi = d->W; p.ldx = d->ldx; p.isy = p.isx = 1;
-      p.Ho = 2 * d->H; p.Wo = 2 * d->W; p.ldy = d->ldy; p.osy = p.osx = 2; p.oay = a; p.oax = b;
-      p.cpt = d->Cin / 8;
+      const int c = a * 2 + b;
       int nt = 0;
       for (int kh = 0; kh < k; ++kh) {
         if (((kh - pad) & 1) != a) continue;      // 2*i + kh - pad == 2*gy + a
@@ -322,18 +333,16 @@ extern "C" int usseg_tconv2d_fwd(const UssegConvDesc* d, const void* x, const vo
         for (int kw = 0; kw < k; ++kw) {
           if (((kw - pad) & 1) != b) continue;
           int dxo = (b - (kw - pad)) / 2;
-          p.tap_dy[nt] = (int16_t)dyo; p.tap_dx[nt] = (int16_t)dxo; p.tap_w[nt] = (int16_t)(kh * k + kw);
+          p.tap_dy[4 * c + nt] = (int16_t)dyo; p.tap_dx[4 * c + nt] = (int16_t)dxo; p.tap_w[4 * c + nt] = (int16_t)(kh * k + kw);
           ++nt;
         }
       }
-      p.ntaps = nt;
-      p.nchunks = nt * p.cpt;
-      p.Nw = roundup(d->Cout, 16); p.Kw = k * k * d->Cin; p.Nout = d->Cout;
-      p.act = d->act; p.alpha = d->alpha; p.out_f32 = (d->flags & USSEG_OUT_F32) ? 1 : 0; p.accumulate = 0;
-      rc = launch_igemm(p, (hipStream_t)stream);
-      if (rc) return rc;
+      p.cls_ntaps[c] = (int16_t)nt;
     }
-  return USSEG_OK;
+  p.ntaps = 4; p.nchunks = 4 * p.cpt;
+  p.Nw = roundup(d->Cout, 16); p.Kw = k * k * d->Cin; p.Nout = d->Cout;
+  p.act = d->act; p.alpha = d->alpha; p.out_f32 = (d->flags & USSEG_OUT_F32) ? 1 : 0; p.accumulate = 0;
+  return launch_igemm(p, (hipStream_t)stream);
 }
 
 // dx[i] = sum_k dy[2i + kh - pad] * w[kh]: a stride-2 gather over dy (2H x 2W).
