@@ -421,7 +421,7 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
     int gpb = (gx + 1023) / 1024;          // ~1024 workgroups (2 per CU resident, two waves of them)
     if (gpb > 16) gpb = 16;
     const int pgx = (gx + gpb - 1) / gpb;
-    const size_t dyn = wbytes + (size_t)288 * 40 * sizeof(bf16_t);
+    const size_t dyn = wbytes + (size_t)NV * (PH + 2) * (PW + 2) * 40 * sizeof(bf16_t);   // weights + this geometry's halo tile
     static bool attr_done = false;   // > 64 KB of LDS per workgroup needs the opt-in (one-time host call, never a stream op)
     if (!attr_done) {
       (void)hipFuncSetAttribute((const void*)conv_halo_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -20,10 +20,13 @@ struct WgHaloParams {
   int32_t ldx, lddy, Ma, Nb, ntiles_n;
 };
 
-template <int WM, int WN>
+// WVM = waves along the input-channel axis (2 or 4; the other 4/WVM waves split the output channels),
+// WM x WN = 16x16 MFMA tiles per wave: workgroup tile = (16*WM*WVM) x (16*WN*(4/WVM)).
+template <int WVM, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p) {
   constexpr int MAXHP = 288;
-  constexpr int BMc = 32 * WM, BNc = 32 * WN;      // channels per workgroup tile
+  constexpr int WVN = 4 / WVM;
+  constexpr int BMc = 16 * WM * WVM, BNc = 16 * WN * WVN;      // channels per workgroup tile
   constexpr int XS = BMc + 8, YS = BNc + 8;        // LDS row strides (elements): +16 B pad
   constexpr int XCH = BMc / 8, YCH = BNc / 8;      // 16-byte chunks per pixel row
   constexpr int X_IT = (MAXHP * XCH + 255) / 256, Y_IT = (128 * YCH + 255) / 256;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p
 
   // ---- fragment addressing (fixed): 16-lane group g covers K rows (pixels) 8g..8g+7 of each 32-pixel step
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  const int wm = wv >> 1, wn = wv & 1;
+  const int wm = wv / WVN, wn = wv % WVN;
   int xb[4][2], yb[4][2];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
@@ -237,8 +240,12 @@ int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, i
   p.npatches = B * d * d * p.tiles_per_v;
   p.ngroups = (p.npatches + NV - 1) / NV;
   p.ldx = ldx; p.lddy = lddy; p.Ma = Ma; p.Nb = Nb;
-  const bool small = Ma <= 32 && Nb <= 32;
-  const int bm = small ? 32 : 64, bn = small ? 32 : 64;
+  // tile shape by channel counts: 64x64, 32x32 (both small), 64x16 / 64x32 (few output channels, e.g. the decoder branches)
+  int shape = 0;
+  if (Ma <= 32 && Nb <= 32) shape = 1;
+  else if (Nb <= 16) shape = 2;
+  else if (Nb <= 32) shape = 3;
+  const int bm = shape == 1 ? 32 : 64, bn = shape == 0 ? 64 : (shape == 2 ? 16 : 32);
   const int tm = (Ma + bm - 1) / bm;
   p.ntiles_n = (Nb + bn - 1) / bn;
   const int tiles = tm * p.ntiles_n;
@@ -256,8 +263,10 @@ int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, i
   p.groups_per_block = (p.ngroups + splits - 1) / splits;
   splits = (p.ngroups + p.groups_per_block - 1) / p.groups_per_block;
   const int slot = usseg_prof_start(2, s);
-  if (small) hipLaunchKernelGGL((wgrad_halo_kernel<1, 1>), dim3(splits, tiles), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
+  if (shape == 1) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1>), dim3(splits, tiles), dim3(256), 0, s, p);
+  else if (shape == 2) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1>), dim3(splits, tiles), dim3(256), 0, s, p);
+  else if (shape == 3) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
   if (p.ws) {
     int64_t n4 = slab / 4;
     int gx = (int)((n4 + 63) / 64);
