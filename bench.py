@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path (RCCL all-reduce, 2 graphs) even at N=1")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra eager steps with per-launch HIP events (roofline leg)")
     args = ap.parse_args()
 
@@ -125,7 +126,11 @@ def main():
     from ultrasound_modeling_amd import _lib
     from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
     net = VisionTransformer(batch_size=B_PER_GPU * world, img_size=(H, W), in_channels=C_IN, device=str(dev), seed=0)
-    trainer = MirroredTrainer(net)
+    if args.force_dist and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    trainer = MirroredTrainer(net, force=args.force_dist)
 
     g = torch.Generator().manual_seed(rank)
     x = torch.randn(B_PER_GPU, H, W, C_IN, generator=g).clamp_(-1, 1).to(dev)
@@ -135,7 +140,7 @@ def main():
     c2 = torch.where(lab >= 1.05, (lab - 1).clamp(0, 1), torch.zeros_like(lab))
     y = torch.stack([(lab <= 0.95).float(), torch.where(lab > 0.95, 1 - c2, torch.zeros_like(lab)), c2], dim=-1).to(dev)
 
-    use_graph = not args.no_graph and world == 1     # the RCCL collective stays outside graphs in this round
+    use_graph = not args.no_graph                    # N > 1: two graphs with the RCCL all-reduce between them
     log(f"rank {rank}/{world}: model built ({net.flat.n_trainable} params), warming up (graph={use_graph})")
     for _ in range(max(args.warmup, 1) if not use_graph else 1):
         trainer.train_step(x, y)
@@ -168,6 +173,7 @@ def main():
     if rank == 0:
         lib = _lib.load()
         net._graph_saved, net._graph = net._graph, None
+        sync_saved, net.grad_sync = net.grad_sync, None     # kernel timing only: no collective inside the profiled steps
         P = args.profile_steps
         _lib.check(lib.usseg_prof_enable(3, 4096 * P), "prof_enable")
         for _ in range(P):
@@ -180,7 +186,7 @@ def main():
         wg_ms, wg_n = ms.value / P, n.value // P
         lib.usseg_prof_disable()
         fwd_f, ig_f, wg_f = algorithmic_flops(net)
-        net._graph = net._graph_saved
+        net._graph, net.grad_sync = net._graph_saved, sync_saved
         achieved = ig_f / (ig_ms * 1e-3) / 1e12
         roofline = {"kernel": "igemm_kernel<NT> (conv/tconv fwd + dgrad)", "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
@@ -203,7 +209,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -47,11 +47,11 @@ def shard_batch(x, y, rank: int, world: int):
 class MirroredTrainer:
     """Wraps a model that has ``flat`` (FlatParams), ``grad_sync`` and ``train_step`` (VisionTransformer / Arch A)."""
 
-    def __init__(self, net, group=None):
+    def __init__(self, net, group=None, force: bool = False):
         self.net, self.group = net, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if self.world > 1:
+        if self.world > 1 or (force and dist.is_initialized()):
             dist.broadcast(net.flat.flat, src=0, group=group)          # mirrored variables (:209-210)
             for m in net.modules():
                 for b in m._buffers.values():

@@ -198,18 +198,25 @@ class VisionTransformer(nn.Module):
         probs, _ = self._forward_loss(self._prep_x(x), self._prep_y(y), with_grad=False)
         return self._loss.clone().reshape(()), probs
 
-    def _train_body(self, x, y):
+    def _grad_body(self, x, y):
+        """zero grads, forward, loss, backward (+ the per-replica clip when gradients are exchanged afterwards)."""
         self.flat.zero_grad()
         probs, dlogits = self._forward_loss(x, y, with_grad=True)                      # :240-241
         d_hidden, d_feats = self.decoder.backward(dlogits)                             # :243
         self.transformer.backward(d_hidden, d_feats)
-        if self.grad_sync is None:
-            self.optimizer.apply()                                                     # :244-245 clip + Adam
-        else:
-            self.optimizer.clip_local()                                                # per-replica clip (:244) ...
-            self.grad_sync(self.flat.grad)                                             # ... then SUM all-reduce inside apply_gradients
-            self.optimizer.apply(already_clipped=True)
+        if self.grad_sync is not None:
+            self.optimizer.clip_local()                                                # per-replica clip (:244) BEFORE the exchange
+        return probs
+
+    def _update_body(self):
+        self.optimizer.apply(already_clipped=self.grad_sync is not None)               # (:244-)245 clip + Adam
         repack_all(self)
+
+    def _train_body(self, x, y):
+        probs = self._grad_body(x, y)
+        if self.grad_sync is not None:
+            self.grad_sync(self.flat.grad)                                             # SUM all-reduce inside apply_gradients
+        self._update_body()
         return probs
 
     def train_step(self, x, y):
@@ -222,7 +229,8 @@ class VisionTransformer(nn.Module):
 
     # ------------------------------------------------------------------ HIP-graph replay of the whole step
     def capture_graph(self, x, y, warmup: int = 2):
-        """Capture ``train_step`` for inputs of this shape into a HIP graph (launch-bound at small batch)."""
+        """Capture ``train_step`` for inputs of this shape into HIP graphs (the step is ~400 launches of 5-70 us).
+        Single GPU: one graph.  Data parallel: two graphs (gradients, update) with the RCCL all-reduce between them."""
         x, y = self._prep_x(x), self._prep_y(y)
         self._gx, self._gy = x.clone(), y.clone()
         s = torch.cuda.Stream()
@@ -231,15 +239,29 @@ class VisionTransformer(nn.Module):
             for _ in range(warmup):
                 self._train_body(self._gx, self._gy)
         torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._gprobs = self._train_body(self._gx, self._gy)
-        self._graph = g
+        torch.cuda.synchronize()
+        if self.grad_sync is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._gprobs = self._train_body(self._gx, self._gy)
+            self._graph = (g, None)
+        else:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._gprobs = self._grad_body(self._gx, self._gy)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._update_body()
+            self._graph = (g1, g2)
 
     def _graph_step(self, x, y):
         self._gx.copy_(x)
         self._gy.copy_(y)
-        self._graph.replay()
+        g1, g2 = self._graph
+        g1.replay()
+        if g2 is not None:
+            self.grad_sync(self.flat.grad)
+            g2.replay()
         return self._loss.clone().reshape(()), self._gprobs
 
     def __call__(self, x, *args, **kwargs):
