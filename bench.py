@@ -95,6 +95,39 @@ def pmc_traffic(launches_per_step):
         return None
 
 
+def layer_probe(dev):
+    """The two 3x3 exemplars of BASELINE.md section 2, forward only, B=32: the HBM-bound stem conv 32->32 at 256x256
+    (north_star's "3x3 conv fwd at 256x256 bs=32") and the MFMA-bound concats_2 256->512 at 16x16.  HIP-event timed."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.flat import FlatParams
+    from ultrasound_modeling_amd.layers import Conv2D
+    out = []
+    for name, B, HW, ci, co in (("stem convtmp_2 3x3 32->32 @256x256 B=32", 32, 256, 32, 32),
+                                ("concats_2 3x3 256->512 @16x16 B=32", 32, 16, 256, 512)):
+        layer = Conv2D(ci, co, 3)
+        FlatParams(layer, dev)
+        x = torch.randn(B, HW, HW, ci, device=dev).to(torch.bfloat16)
+        y = ops.new_act(B, HW, HW, co, dev)
+        for _ in range(3):
+            layer.forward(x, out=y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            layer.forward(x, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        flops = 2.0 * B * HW * HW * 9 * ci * co
+        byts = 2.0 * B * HW * HW * (ci + co) + 2.0 * 9 * ci * co
+        tf = flops / us / 1e6
+        roof = min(PEAK_BF16_TFLOPS, flops / byts * 8.0)          # min(MFMA peak, AI x 8 TB/s) in TFLOP/s
+        out.append({"layer": name, "us": round(us, 2), "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4),
+                    "ai_flop_per_byte": round(flops / byts, 1), "roofline_tflops": round(roof, 1), "frac_of_roofline": round(tf / roof, 4),
+                    "gb_per_s": round(byts / us / 1e3, 1)})
+    return out
+
+
 def cpu_baseline(seconds_budget: float = 25.0):
     """Time the CPU oracle (fp32, all host cores) on a bounded sample: full train steps at B=2, 256x256x1."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -202,7 +235,7 @@ def main():
         fwd_f, ig_f, wg_f = algorithmic_flops(net)
         net._graph, net.grad_sync = net._graph_saved, sync_saved
         achieved = ig_f / (ig_ms * 1e-3) / 1e12
-        roofline = {"kernel": "igemm_kernel<NT> (conv/tconv fwd + dgrad)", "bound": "mfma", "achieved": round(achieved, 2),
+        roofline = {"kernel": "conv family: conv_halo_kernel / conv_halo_persist_kernel / igemm_kernel (every conv + tconv forward and backward-data launch)", "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
                     "algorithmic_gflop_per_step": round(ig_f / 1e9, 2), "kernel_ms_per_step": round(ig_ms, 3),
@@ -210,6 +243,7 @@ def main():
                               "achieved": round(wg_f / (wg_ms * 1e-3) / 1e12, 2), "algorithmic_gflop_per_step": round(wg_f / 1e9, 2)},
                     "fwd_gflop_per_image": round(fwd_f / B_PER_GPU / 1e9, 3)}
         roofline["traffic"] = pmc_traffic(ig_n)
+        roofline["layers"] = layer_probe(dev)
 
     if rank == 0:
         out = {"metric": "segmentation training images/sec at 256x256", "value": round(B_PER_GPU * world * args.steps / el, 2),
