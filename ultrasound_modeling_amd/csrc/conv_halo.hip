@@ -283,10 +283,8 @@ __global__ __launch_bounds__(256) void conv_halo_persist_kernel(const HaloParams
   const int w_base = (lane & 15) * LDSS + fk;
   __syncthreads();
 
-  // two register sets: the activation tile of step it+2 is in flight while step it computes (one HBM latency is several
-  // times longer than the 9 x 2 x NT MFMAs of a step, so a single prefetch slot left the loads exposed)
-  uint4 ra0[A_IT], ra1[A_IT];
-  auto load_a = [&](uint4 (&ra)[A_IT], int gl, int ck) {
+  uint4 ra[A_IT];
+  auto load_a = [&](int gl, int ck) {
     const int c = ck * 32 + q * 8;
     const bool cok = c < p.Cin;
 #pragma unroll
@@ -304,7 +302,8 @@ __global__ __launch_bounds__(256) void conv_halo_persist_kernel(const HaloParams
 
   f32x4_t acc[2][NT];
   const int total = ng * p.nchunks;
-  auto step = [&](uint4 (&ra)[A_IT], int it) {
+  if (total > 0) load_a(0, 0);
+  for (int it = 0; it < total; ++it) {
     const int gl = it / p.nchunks, ck = it - gl * p.nchunks;
     if (ck == 0) {
 #pragma unroll
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_halo_persist_kernel(const HaloParams
       if ((idx >> 2) < NHP) *reinterpret_cast<uint4*>(&lds_a[(idx >> 2) * LDSS + q * 8]) = ra[k];
     }
     __syncthreads();
-    if (it + 2 < total) load_a(ra, (it + 2) / p.nchunks, (it + 2) % p.nchunks);
+    if (it + 1 < total) load_a((it + 1) / p.nchunks, (it + 1) % p.nchunks);
     const bf16_t* wck = lds_w + (size_t)ck * 9 * BN * LDSS;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_halo_persist_kernel(const HaloParams
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
     }
     __syncthreads();
-    if (ck != p.nchunks - 1) return;
+    if (ck != p.nchunks - 1) continue;
     // ---- epilogue of pixel group gl
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -380,12 +379,6 @@ __global__ __launch_bounds__(256) void conv_halo_persist_kernel(const HaloParams
         }
       }
     }
-  };
-  if (total > 0) load_a(ra0, 0, 0);
-  if (total > 1) load_a(ra1, 1 / p.nchunks, 1 % p.nchunks);
-  for (int it = 0; it < total; it += 2) {
-    step(ra0, it);
-    if (it + 1 < total) step(ra1, it + 1);
   }
 }
 
