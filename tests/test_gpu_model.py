@@ -134,3 +134,24 @@ def test_eval_step_and_second_train_step(small_model):
     assert abs(l0.item() - l1.item()) < 1e-3 * abs(l0.item())   # same weights, same batch
     assert l2.item() < l0.item()                                  # one Adam step on this batch lowers its loss
     assert torch.isfinite(p0).all()
+
+
+def test_native_256x80x10_configuration():
+    """The reference's own input (MainParallel.py:29: [256, 80, 10]; grid 16x5, VisionTransformer.py:90): forward, loss and
+    gradients against the oracle.  W=80 makes most levels take the gather kernel (40, 20, 10, 5 columns)."""
+    from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
+    P = _f32(O.init_vision_transformer_params(channel=10, seed=6, perturb=True))
+    net = VisionTransformer(batch_size=2, img_size=(256, 80), in_channels=10)
+    net.load_params(P)
+    assert net.decoder.grid == (16, 5)
+    x, y = O.synthetic_batch(2, 256, 80, 10, seed=7)
+    xb = x.to(torch.bfloat16).double()
+    loss_r, probs_r, grads_r, _ = O.train_step(xb, y, dict(P), {}, global_batch_size=2, as_executed=False)
+    loss, probs = net.train_step(x, y.float())           # float64 NHWC in, as Dataset_2.py:91 hands it over
+    torch.cuda.synchronize()
+    assert tuple(probs.shape) == (2, 256, 80, 3)
+    e_p, e_l = rel(probs, probs_r), abs(loss.item() - loss_r.item()) / abs(loss_r.item())
+    grads = net.export_grads()
+    errs = sorted(rel(grads[k], grads_r[k]) for k in grads_r)
+    print(f"native 256x80x10: probs rel {e_p:.3e} loss rel {e_l:.2e} grad median {errs[len(errs) // 2]:.3e} p90 {errs[int(len(errs) * .9)]:.3e}")
+    assert e_p < 2e-2 and e_l < 5e-3 and errs[len(errs) // 2] < 3e-2 and errs[int(len(errs) * 0.9)] < 1e-1
