@@ -42,7 +42,7 @@ typedef enum UssegStatus {
   USSEG_ERR_LAUNCH = -3
 } UssegStatus;
 
-typedef enum UssegAct { USSEG_ACT_NONE = 0, USSEG_ACT_LRELU = 1, USSEG_ACT_RELU = 2, USSEG_ACT_ELU = 3 } UssegAct;
+typedef enum UssegAct { USSEG_ACT_NONE = 0, USSEG_ACT_LRELU = 1, USSEG_ACT_RELU = 2, USSEG_ACT_ELU = 3, USSEG_ACT_GELU = 4 } UssegAct;
 
 enum {
   USSEG_OUT_F32 = 1,   /* y is float* (ldy counted in floats); default bf16 */
@@ -245,6 +245,31 @@ int usseg_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n
 int usseg_adam_advance(int32_t* step, float* lr_t_dev, float lr, float beta1, float beta2, usseg_stream_t stream);
 int usseg_fill_f32(float* p, int64_t n, float value, usseg_stream_t stream);
 int usseg_scale_f32(float* p, int64_t n, const float* sumsq, float clip_norm, usseg_stream_t stream);
+
+/* ---- ViT bottleneck helpers (VisionTransformer.py:9-79,127-174) ------------------------
+ * Batched GEMMs on the conv kernels (bf16 operands, fp32 accumulate), 2-level batch (image, head) with element strides:
+ *   nt: Y[b1,b2][m][n]  = sum_k X[b1,b2][m][k] * W[b1,b2][n][k]   (M rows, K contiguous in both operands)
+ *   tn: O[b1,b2][m][n] += sum_r A[b1,b2][r][m] * B[b1,b2][r][n]   (K = number of rows r; fp32 atomics, zero O first)
+ * For tn, ldx and ldw are the row strides of A and B, and xs1, xs2, ws1, ws2 their batch strides. */
+typedef struct UssegGemmDesc {
+  int32_t M, N, K;
+  int32_t ldx, ldw, ldy;
+  int32_t nb1, nb2;
+  int64_t xs1, xs2, ws1, ws2, ys1, ys2;
+  int32_t flags;   /* USSEG_OUT_F32 (nt only) */
+} UssegGemmDesc;
+int usseg_gemm_nt_batched(const UssegGemmDesc* d, const void* x, const void* w, void* y, usseg_stream_t stream);
+int usseg_gemm_tn_batched(const UssegGemmDesc* d, const void* a, const void* b, float* out, usseg_stream_t stream);
+/* Row softmax of scale*S (fp32 [rows][ld]) -> P fp32 (the attention weights the reference returns, :44) and P bf16;
+ * backward: dS = scale * P * (dP - sum_k dP*P)  (bf16 out). */
+int usseg_softmax_rows_fwd(const float* s, int64_t rows, int32_t n, float scale, float* p32, void* pbf, usseg_stream_t stream);
+int usseg_softmax_rows_bwd(const float* p32, const float* dp, int64_t rows, int32_t n, float scale, void* ds_bf, usseg_stream_t stream);
+/* dst[b][c][r] = src[b][r][c]: bf16, src row stride lds, batch strides ss1/ss2 (2-level), dst dense [nb1*nb2][C][R]. */
+int usseg_transpose_batched(const void* src, int32_t R, int32_t C, int32_t lds, int32_t nb1, int32_t nb2, int64_t ss1, int64_t ss2,
+                            void* dst, usseg_stream_t stream);
+/* dst_bf16[b1,b2][r][c] = src_f32[(b1*nb2+b2)][r][c] with dst row stride ldd and batch strides ds1/ds2 */
+int usseg_cast_f32_to_bf16_batched(const float* src, int32_t R, int32_t C, int32_t nb1, int32_t nb2, void* dst, int32_t ldd, int64_t ds1,
+                                   int64_t ds2, usseg_stream_t stream);
 
 /* ---- opt-in per-launch timing (bench.py roofline leg) ------------------------------------------
  * When enabled, every launch of the selected kernel family is bracketed by hipEventRecord on ITS stream.

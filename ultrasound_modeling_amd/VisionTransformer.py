@@ -7,8 +7,9 @@
 
 Differences that are parameters here and literals in the reference: the input channel count (10 at
 VisionTransformer.py:100,198) and the 16x5 token grid (:90) which becomes (H/16, W/16).
-``use_vit=False`` is BASELINE config 2 ("ResNeSt encoder + Decoder.py, no ViT"): the patch embedding feeds the
-decoder directly.  The 8-layer ViT bottleneck (:9-189) is SURVEY.md §8f rank 1 ("next") and is not built yet.
+``use_vit=False`` (default) is BASELINE config 2 ("ResNeSt encoder + Decoder.py, no ViT"): the patch embedding feeds the
+decoder directly.  ``use_vit=True`` inserts the 8-layer ViT bottleneck (:9-189), i.e. the model the reference's drivers
+actually build; its variables carry the reference's attribute paths (``transformer.encoder.Transformer_layers.3.attn.query``).
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ import torch.nn as nn
 from . import ops
 from .Decoder import DecoderCup
 from .flat import AdamClip, FlatParams
-from .layers import BatchNormalization, Conv2D
+from .layers import BatchNormalization, Conv2D, LayerNormalization, _Workspace
 from .ResNest import ResNest, cardinal, residual_S
 from .ops import BF16, roundup
 
@@ -39,6 +40,8 @@ def repack_all(root: nn.Module):
             elif isinstance(m, cardinal):
                 if m._solo is not None:
                     jobs += m._solo.pack_jobs()
+            elif isinstance(m, Attention):
+                jobs += m.pack_jobs()
             elif isinstance(m, Conv2D) and m.wp_f is not None:
                 jobs += m.pack_jobs()
         dev = next(root.parameters()).device
@@ -71,21 +74,174 @@ class Embeddings(nn.Module):
         self.hybrid_model.backward(d_x4, d_feats)
 
 
+class Attention(nn.Module):
+    """VisionTransformer.py:9-57: 4 heads of 128, scores divided by sqrt(num_heads) = 2 (NOT sqrt(head_dim), :42), softmax
+    over keys, returns the attention weights.  Q/K/V projections run as ONE GEMM (N = 1536); the per-(image, head)
+    products are batched GEMMs on the conv kernels with the head split expressed as a channel slice."""
+
+    def __init__(self, num_heads=4, attention_head_size=512, attention_dropout_rate=0.0, wDecay=None):
+        super().__init__()
+        self.num_heads, self.hidden_size, self.wDecay = num_heads, attention_head_size, wDecay
+        self.qkv_size = attention_head_size // num_heads
+        hs = self.hidden_size
+        self.query, self.key, self.value = (Conv2D(hs, hs, 1, init="glorot") for _ in range(3))     # Dense = 1x1 conv on [B,N,1,C]
+        for c in (self.query, self.key, self.value):
+            c.on_finalize = lambda device: None                                                       # packed together below
+        self.out = Conv2D(hs, hs, 1, init="glorot")
+
+    def adjacent_params(self):
+        return [([self.query.bias, self.key.bias, self.value.bias], 0)]
+
+    def on_finalize(self, device):
+        hs = self.hidden_size
+        self.w_f = torch.zeros((3 * hs, hs), dtype=BF16, device=device)
+        self.w_d = torch.zeros((hs, 3 * hs), dtype=BF16, device=device)
+        self.b_qkv = torch.as_strided(self.query.bias.data, (3 * hs,), (1,))
+        self.db_qkv = torch.as_strided(self.query.bias.grad, (3 * hs,), (1,))
+        assert self.key.bias.data_ptr() == self.query.bias.data_ptr() + 4 * hs
+        jobs = self.pack_jobs()
+        ops.pack_weights_batched(ops.make_pack_table(jobs, device), len(jobs))
+
+    def pack_jobs(self):
+        hs, jobs = self.hidden_size, []
+        for i, c in enumerate((self.query, self.key, self.value)):       # Dense kernel [in, out]
+            jobs.append(ops.pack_job(c.kernel.data, 0, 1, hs, 1, hs, hs, self.w_f, hs, hs, i * hs, 0))
+            jobs.append(ops.pack_job(c.kernel.data, 0, hs, 1, 1, hs, hs, self.w_d, 3 * hs, 3 * hs, 0, i * hs))
+        return jobs
+
+    def forward(self, xn, residual):
+        """xn, residual: [B,N,1,hidden] bf16 -> (attention output + residual, weights fp32 [B,heads,N,N])."""
+        B, N, _, hs = xn.shape
+        nh, dh, dev = self.num_heads, self.qkv_size, xn.device
+        qkv = ops.conv2d_fwd(xn, self.w_f, self.b_qkv, 1, 1, ops.new_act(B, N, 1, 3 * hs, dev))          # :34-36
+        q, k, v = qkv[..., :hs], qkv[..., hs:2 * hs], qkv[..., 2 * hs:]
+        S = torch.empty((B, nh, N, N), dtype=torch.float32, device=dev)
+        ops.gemm_nt_batched(q, k, S, N, N, dh, 3 * hs, 3 * hs, N, B, nh, (N * 3 * hs, dh), (N * 3 * hs, dh), (nh * N * N, N * N), out_f32=True)  # :41
+        P32, Pb = torch.empty_like(S), torch.empty((B, nh, N, N), dtype=BF16, device=dev)
+        ops.softmax_rows_fwd(S, N, 1.0 / (float(nh) ** 0.5), P32, Pb)                                     # :42-43
+        vt = torch.empty((B * nh, dh, N), dtype=BF16, device=dev)
+        kt = torch.empty((B * nh, dh, N), dtype=BF16, device=dev)
+        ops.transpose_batched(v, N, dh, 3 * hs, B, nh, (N * 3 * hs, dh), vt)
+        ops.transpose_batched(k, N, dh, 3 * hs, B, nh, (N * 3 * hs, dh), kt)
+        ctx = ops.new_act(B, N, 1, hs, dev)
+        ops.gemm_nt_batched(Pb, vt, ctx, N, dh, N, N, N, hs, B, nh, (nh * N * N, N * N), (nh * dh * N, dh * N), (N * hs, dh))                 # :47-49
+        out = self.out.forward(ctx, residual=residual)                                                    # :50 (+ h, :140)
+        self._saved = (xn, qkv, P32, Pb, kt)
+        return out, P32
+
+    def backward(self, d_out):
+        xn, qkv, P32, Pb, kt = self._saved
+        B, N, _, hs = xn.shape
+        nh, dh, dev = self.num_heads, self.qkv_size, xn.device
+        q, k, v = qkv[..., :hs], qkv[..., hs:2 * hs], qkv[..., 2 * hs:]
+        dctx = self.out.backward(d_out)
+        dqkv = ops.new_act(B, N, 1, 3 * hs, dev)
+        s_pp, s_qkv, s_ctx, s_hd = (nh * N * N, N * N), (N * 3 * hs, dh), (N * hs, dh), (nh * N * dh, N * dh)
+        dV = torch.zeros((B, nh, N, dh), dtype=torch.float32, device=dev)
+        ops.gemm_tn_batched(Pb, dctx, dV, N, dh, N, N, hs, B, nh, s_pp, s_ctx, s_hd)                       # dV = P^T dO
+        dP = torch.empty((B, nh, N, N), dtype=torch.float32, device=dev)
+        ops.gemm_nt_batched(dctx, v, dP, N, N, dh, hs, 3 * hs, N, B, nh, s_ctx, s_qkv, s_pp, out_f32=True)  # dP = dO V^T
+        dS = torch.empty((B, nh, N, N), dtype=BF16, device=dev)
+        ops.softmax_rows_bwd(P32, dP, N, 1.0 / (float(nh) ** 0.5), dS)
+        ops.gemm_nt_batched(dS, kt, dqkv, N, dh, N, N, N, 3 * hs, B, nh, s_pp, (nh * dh * N, dh * N), s_qkv)  # dQ = dS K
+        dK = torch.zeros((B, nh, N, dh), dtype=torch.float32, device=dev)
+        ops.gemm_tn_batched(dS, q, dK, N, dh, N, N, 3 * hs, B, nh, s_pp, s_qkv, s_hd)                       # dK = dS^T Q
+        ops.cast_f32_to_bf16_batched(dK, N, dh, B, nh, dqkv[..., hs:2 * hs], 3 * hs, s_qkv)
+        ops.cast_f32_to_bf16_batched(dV, N, dh, B, nh, dqkv[..., 2 * hs:], 3 * hs, s_qkv)
+        # fused projection backward
+        scratch = _Workspace.get(dev, hs * 3 * hs)
+        ops.fill_f32(scratch, 0.0)
+        ops.conv2d_wgrad(xn, dqkv, 1, 1, scratch)
+        for i, c in enumerate((self.query, self.key, self.value)):
+            ops.unpack_wgrad(scratch, hs, 3 * hs, 1, hs, hs, i * hs, 0, c.kernel.grad, 0, 1, hs)
+        ops.colsum(dqkv, self.db_qkv, 3 * hs)
+        return ops.conv2d_dgrad(dqkv, self.w_d, 1, 1, ops.new_act(B, N, 1, hs, dev))
+
+
+class Mlp(nn.Module):
+    """VisionTransformer.py:60-78: fc1 -> (dropout 0) -> exact GELU -> fc2."""
+
+    def __init__(self, hidden_size=512, mlp_dim=2048, dropout_rate=0.0):
+        super().__init__()
+        self.fc1 = Conv2D(hidden_size, mlp_dim, 1, init="glorot")
+        self.fc2 = Conv2D(mlp_dim, hidden_size, 1, init="glorot")
+
+    def forward(self, x, residual):
+        self._raw = self.fc1.forward(x)                                                                   # :69
+        g = ops.act_fwd(self._raw, torch.empty_like(self._raw), ops.ACT_GELU, 0.0)                       # :71
+        return self.fc2.forward(g, residual=residual)                                                     # :72 (+ h, :145)
+
+    def backward(self, d):
+        dg = self.fc2.backward(d)
+        return self.fc1.backward(ops.act_bwd(self._raw, dg, torch.empty_like(dg), ops.ACT_GELU, 0.0))
+
+
+class Block(nn.Module):
+    """VisionTransformer.py:127-150: pre-LN (eps 1e-6) attention and MLP with residuals."""
+
+    def __init__(self, hidden_size=512, wDecay=None):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.attention_norm = LayerNormalization(hidden_size, epsilon=1e-6)
+        self.ffn_norm = LayerNormalization(hidden_size, epsilon=1e-6)
+        self.ffn = Mlp(hidden_size)
+        self.attn = Attention(attention_head_size=hidden_size, wDecay=wDecay)
+
+    def forward(self, x):
+        a, weights = self.attn.forward(self.attention_norm.forward(x), residual=x)                        # :137-140
+        return self.ffn.forward(self.ffn_norm.forward(a), residual=a), weights                            # :142-146
+
+    def backward(self, d):
+        da = self.ffn_norm.backward(self.ffn.backward(d))
+        ops.copy_channels(d, da, accumulate=True)               # residual branch of x = x + h (:145)
+        dx = self.attention_norm.backward(self.attn.backward(da))
+        ops.copy_channels(da, dx, accumulate=True)              # residual branch (:140)
+        return dx
+
+
+class Encoder(nn.Module):
+    """VisionTransformer.py:153-174."""
+
+    def __init__(self, xdim, ydim, num_layers=8, wDecay=None):
+        super().__init__()
+        self.xDim, self.yDim = xdim, ydim
+        self.encoder_norm = LayerNormalization(512, epsilon=1e-6)
+        self.Transformer_layers = nn.ModuleList([Block(wDecay=wDecay) for _ in range(num_layers)])
+
+    def forward(self, hidden_states):
+        attn_weights = []
+        for blk in self.Transformer_layers:                                                               # :166-168
+            hidden_states, w = blk.forward(hidden_states)
+            attn_weights.append(w)
+        return self.encoder_norm.forward(hidden_states), attn_weights                                     # :169
+
+    def backward(self, d):
+        d = self.encoder_norm.backward(d)
+        for blk in reversed(self.Transformer_layers):
+            d = blk.backward(d)
+        return d
+
+
 class Transformer(nn.Module):
     """VisionTransformer.py:177-189."""
 
     def __init__(self, img_size, wDecay=None, in_channels=10, use_vit=False):
         super().__init__()
         self.embeddings = Embeddings(img_size=img_size, in_channels=in_channels)
-        self.encoder = None
-        if use_vit:
-            raise NotImplementedError("ViT bottleneck (VisionTransformer.py:9-189) is SURVEY.md §8f 'next'; use use_vit=False")
+        self.encoder = Encoder(img_size[0], img_size[1], wDecay=wDecay) if use_vit else None
 
     def forward(self, input_ids):
         embedding_output, features = self.embeddings.forward(input_ids)
-        return embedding_output, [], features
+        if self.encoder is None:
+            return embedding_output, [], features
+        B, N, hs = embedding_output.shape
+        encoded, attn_weights = self.encoder.forward(embedding_output.reshape(B, N, 1, hs))              # :185
+        return encoded.reshape(B, N, hs), attn_weights, features
 
     def backward(self, d_hidden, d_feats):
+        if self.encoder is not None:
+            B, N, hs = d_hidden.shape
+            d_hidden = self.encoder.backward(d_hidden.reshape(B, N, 1, hs).contiguous()).reshape(B, N, hs)
         self.embeddings.backward(d_hidden, d_feats)
 
 
@@ -141,8 +297,9 @@ class VisionTransformer(nn.Module):
         for k, v in params.items():
             t = own.get(k)
             if t is not None:
-                assert tuple(t.shape) == tuple(v.shape), f"{k}: {tuple(t.shape)} vs {tuple(v.shape)}"
-                t.data.copy_(v.to(torch.float32))
+                assert t.numel() == v.numel() and tuple(t.shape)[-2:] == tuple(v.shape)[-2:] or tuple(t.shape) == tuple(v.shape), \
+                    f"{k}: {tuple(t.shape)} vs {tuple(v.shape)}"
+                t.data.copy_(v.to(torch.float32).reshape(t.shape))        # Dense [in,out] == 1x1 conv [1,1,in,out]
             elif k in bufs:
                 bufs[k].copy_(v.to(torch.float32))
             else:

@@ -45,12 +45,17 @@ class SplitAttnGrads(C.Structure):
     _fields_ = [(n, c_vp) for n in ("w1", "b1", "gamma", "beta", "w2", "b2")]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [("M", c_i32), ("N", c_i32), ("K", c_i32), ("ldx", c_i32), ("ldw", c_i32), ("ldy", c_i32), ("nb1", c_i32), ("nb2", c_i32),
+                ("xs1", c_i64), ("xs2", c_i64), ("ws1", c_i64), ("ws2", c_i64), ("ys1", c_i64), ("ys2", c_i64), ("flags", c_i32)]
+
+
 class LossDesc(C.Structure):
     _fields_ = [("M", c_i64), ("HW", c_i32), ("C", c_i32), ("ldl", c_i32), ("lddl", c_i32), ("loss_kind", c_i32),
                 ("label_smoothing", c_f32), ("clip_eps", c_f32), ("inv_global_batch", c_f32)]
 
 
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU, ACT_GELU = 0, 1, 2, 3, 4
 OUT_F32, ACCUMULATE = 1, 2
 
 P = C.POINTER
@@ -96,6 +101,12 @@ _PROTOS = {
     "usseg_adam_advance": (C.c_int, [c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),
     "usseg_fill_f32": (C.c_int, [c_vp, c_i64, c_f32, c_vp]),
     "usseg_scale_f32": (C.c_int, [c_vp, c_i64, c_vp, c_f32, c_vp]),
+    "usseg_gemm_nt_batched": (C.c_int, [P(GemmDesc), c_vp, c_vp, c_vp, c_vp]),
+    "usseg_gemm_tn_batched": (C.c_int, [P(GemmDesc), c_vp, c_vp, c_vp, c_vp]),
+    "usseg_softmax_rows_fwd": (C.c_int, [c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "usseg_softmax_rows_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp]),
+    "usseg_transpose_batched": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp]),
+    "usseg_cast_f32_to_bf16_batched": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
     "usseg_prof_enable": (C.c_int, [c_i32, c_i32]),
     "usseg_prof_read": (C.c_int, [c_i32, P(C.c_double), P(c_i64)]),
     "usseg_prof_disable": (C.c_int, []),

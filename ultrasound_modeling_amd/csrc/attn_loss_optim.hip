@@ -564,3 +564,89 @@ extern "C" int usseg_scale_f32(float* p, int64_t n, const float* sumsq, float cl
   hipLaunchKernelGGL(scale_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, n, sumsq, clip_norm);
   return usseg_check_launch("scale");
 }
+
+// ------------------------------------------------------------------------------------------ ViT attention helpers
+// One wave per row (n <= 2048): softmax(scale * s) with fp32 statistics; writes the fp32 weights and a bf16 copy.
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* s, int64_t rows, int n, float scale, float* p32, bf16_t* pbf) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = s + row * n;
+  float mx = -INFINITY;
+  for (int c = lane; c < n; c += 64) mx = fmaxf(mx, sr[c] * scale);
+  for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
+  float sum = 0.f;
+  for (int c = lane; c < n; c += 64) sum += __expf(sr[c] * scale - mx);
+  for (int msk = 32; msk >= 1; msk >>= 1) sum += __shfl_xor(sum, msk, 64);
+  const float inv = 1.f / sum;
+  for (int c = lane; c < n; c += 64) {
+    float v = __expf(sr[c] * scale - mx) * inv;
+    p32[row * n + c] = v;
+    pbf[row * n + c] = f2bf(v);
+  }
+}
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* p32, const float* dp, int64_t rows, int n, float scale, bf16_t* ds) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* pr = p32 + row * n;
+  const float* dr = dp + row * n;
+  float dot = 0.f;
+  for (int c = lane; c < n; c += 64) dot += pr[c] * dr[c];
+  for (int msk = 32; msk >= 1; msk >>= 1) dot += __shfl_xor(dot, msk, 64);
+  for (int c = lane; c < n; c += 64) ds[row * n + c] = f2bf(scale * pr[c] * (dr[c] - dot));
+}
+extern "C" int usseg_softmax_rows_fwd(const float* s, int64_t rows, int32_t n, float scale, float* p32, void* pbf, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(s && p32 && pbf && rows > 0 && n > 0, "softmax_rows_fwd: bad args");
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, s, rows, n, scale, p32, (bf16_t*)pbf);
+  return usseg_check_launch("softmax_rows_fwd");
+}
+extern "C" int usseg_softmax_rows_bwd(const float* p32, const float* dp, int64_t rows, int32_t n, float scale, void* ds_bf, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(p32 && dp && ds_bf && rows > 0 && n > 0, "softmax_rows_bwd: bad args");
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, p32, dp, rows, n, scale, (bf16_t*)ds_bf);
+  return usseg_check_launch("softmax_rows_bwd");
+}
+
+// 32x32 tiles through LDS: dst[b][c][r] = src[b][r][c]
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t* src, int R, int C, int lds_, int nb2, int64_t ss1, int64_t ss2, bf16_t* dst) {
+  __shared__ bf16_t tile[32][33];
+  const int bz = blockIdx.z, b1 = bz / nb2, b2 = bz - b1 * nb2;
+  const bf16_t* s = src + b1 * ss1 + b2 * ss2;
+  bf16_t* d = dst + (int64_t)bz * R * C;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < C) tile[i][tx] = s[(int64_t)(r0 + i) * lds_ + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && r0 + tx < R) d[(int64_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+extern "C" int usseg_transpose_batched(const void* src, int32_t R, int32_t C, int32_t lds_, int32_t nb1, int32_t nb2, int64_t ss1, int64_t ss2,
+                                       void* dst, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(src && dst && R > 0 && C > 0 && nb1 > 0 && nb2 > 0 && (int64_t)nb1 * nb2 < 65536, "transpose_batched: bad args");
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((C + 31) / 32, (R + 31) / 32, nb1 * nb2), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, R, C, lds_, nb2, ss1, ss2, (bf16_t*)dst);
+  return usseg_check_launch("transpose_batched");
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_batched_kernel(const float* src, int R, int C, int nb2, bf16_t* dst, int ldd, int64_t ds1,
+                                                                     int64_t ds2, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c = (int)(i % C);
+    int64_t t = i / C;
+    int r = (int)(t % R);
+    int bz = (int)(t / R);
+    int b1 = bz / nb2, b2 = bz - b1 * nb2;
+    dst[b1 * ds1 + b2 * ds2 + (int64_t)r * ldd + c] = f2bf(src[i]);
+  }
+}
+extern "C" int usseg_cast_f32_to_bf16_batched(const float* src, int32_t R, int32_t C, int32_t nb1, int32_t nb2, void* dst, int32_t ldd, int64_t ds1,
+                                              int64_t ds2, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(src && dst && R > 0 && C > 0 && nb1 > 0 && nb2 > 0, "cast_f32_to_bf16_batched: bad args");
+  int64_t total = (int64_t)nb1 * nb2 * R * C;
+  int64_t g = cdiv64(total, 256 * 4);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(cast_f32_bf16_batched_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, R, C, nb2, (bf16_t*)dst, ldd, ds1,
+                     ds2, total);
+  return usseg_check_launch("cast_f32_to_bf16_batched");
+}

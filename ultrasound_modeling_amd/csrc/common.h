@@ -36,6 +36,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
     case USSEG_ACT_LRELU: return v >= 0.f ? v : alpha * v;
     case USSEG_ACT_RELU: return v > 0.f ? v : 0.f;
     case USSEG_ACT_ELU: return v > 0.f ? v : alpha * (__expf(v) - 1.f);
+    case USSEG_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));   // exact (erf) GELU, VisionTransformer.py:71
     default: return v;
   }
 }
@@ -45,6 +46,7 @@ __device__ __forceinline__ float act_grad(float v, int act, float alpha) {
     case USSEG_ACT_LRELU: return v >= 0.f ? 1.f : alpha;
     case USSEG_ACT_RELU: return v > 0.f ? 1.f : 0.f;
     case USSEG_ACT_ELU: return v > 0.f ? 1.f : alpha * __expf(v);
+    case USSEG_ACT_GELU: return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
     default: return 1.f;
   }
 }

@@ -39,6 +39,9 @@ struct IgemmParams {
   // entries [4c, 4c+4) (cls_ntaps[c] of them) and writes output pixels (2*gy + (c>>1), 2*gx + (c&1)).
   int32_t cls_mode;
   int16_t cls_ntaps[4];
+  // batched GEMM (attention): blockIdx.z = b1*nb2 + b2 selects operand bases x + b1*xs1 + b2*xs2 etc. (elements)
+  int32_t nb2, nbatch;
+  int64_t xs1, xs2, ws1, ws2, ys1, ys2;
 };
 
 template <int NT>
@@ -62,6 +65,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int tbase = cls * 4;
   const int ntaps = p.cls_mode ? (int)p.cls_ntaps[cls] : p.ntaps;
   const int oay = p.cls_mode ? (cls >> 1) : p.oay, oax = p.cls_mode ? (cls & 1) : p.oax;
+  const int bz = (!p.cls_mode && p.nb2 > 0) ? (int)blockIdx.z : 0;
+  const int bz1 = p.nb2 > 0 ? bz / p.nb2 : 0, bz2 = p.nb2 > 0 ? bz - bz1 * p.nb2 : 0;
+  const bf16_t* const xbase = p.x + bz1 * p.xs1 + bz2 * p.xs2;
+  const bf16_t* const wbase = p.w + bz1 * p.ws1 + bz2 * p.ws2;
+  const int64_t ybatch = bz1 * p.ys1 + bz2 * p.ys2;
 
   // --- per-thread staging coordinates: chunk column q (0..3) of rows r0 and r0+64
   const int q = tid & 3;
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       int iy = py[h] + dy, ix = px[h] + dx;
       if (tv && pv[h] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-        const bf16_t* src = p.x + ((int64_t)(pb[h] + iy) * p.Wi + ix) * p.ldx + c8 * 8;
+        const bf16_t* src = xbase + ((int64_t)(pb[h] + iy) * p.Wi + ix) * p.ldx + c8 * 8;
         v = *reinterpret_cast<const uint4*>(src);
       }
       ra[h] = v;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       int n = idx >> 2;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (idx < BN * 4 && tv && (n0 + n) < p.Nw) {
-        const bf16_t* src = p.w + (int64_t)(n0 + n) * p.Kw + tw * Cin + c8 * 8;
+        const bf16_t* src = wbase + (int64_t)(n0 + n) * p.Kw + tw * Cin + c8 * 8;
         v = *reinterpret_cast<const uint4*>(src);
       }
       rw[j] = v;
@@ -193,12 +201,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
       }
       if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.y) + opix * p.ldy + n;
+        float* dst = reinterpret_cast<float*>(p.y) + ybatch + opix * p.ldy + n;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (n + j < p.Nout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
       } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + opix * p.ldy + n;
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + ybatch + opix * p.ldy + n;
         if (p.accumulate) {
           uint2 o = *reinterpret_cast<const uint2*>(dst);
           v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
@@ -218,7 +226,7 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   dim3 block(256);
   int64_t gx = cdiv64(p.M, 128);
   USSEG_CHECK_ARG(gx < (1ll << 31), "igemm: too many pixel tiles");
-  const unsigned gz = p.cls_mode ? 4 : 1;
+  const unsigned gz = p.cls_mode ? 4 : (p.nb2 > 0 ? (unsigned)p.nbatch : 1);
   const int slot = usseg_prof_start(1, s);
   if (p.Nout <= 16) {
     hipLaunchKernelGGL(igemm_kernel<1>, dim3((unsigned)gx, 1, gz), block, 0, s, p);
@@ -368,5 +376,26 @@ extern "C" int usseg_tconv2d_dgrad(const UssegConvDesc* d, const void* dy, const
   p.nchunks = p.ntaps * p.cpt;
   p.Nw = roundup(d->Cin, 16); p.Kw = p.ntaps * d->Cout; p.Nout = d->Cin;
   p.act = USSEG_ACT_NONE; p.out_f32 = 0; p.accumulate = (d->flags & USSEG_ACCUMULATE) ? 1 : 0;
+  return launch_igemm(p, (hipStream_t)stream);
+}
+
+// ---- batched GEMM on the same kernel: Y[b1,b2][m][n] = sum_k X[b1,b2][m][k] * W[b1,b2][n][k]  (both operands K-contiguous).
+// Used for the ViT attention products (VisionTransformer.py:41,47): rows m = tokens, the head split is a channel slice.
+extern "C" int usseg_gemm_nt_batched(const UssegGemmDesc* d, const void* x, const void* w, void* y, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && x && w && y, "null pointer");
+  USSEG_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->K % 8 == 0 && d->ldx % 8 == 0 && d->ldw % 8 == 0, "gemm: K, ldx, ldw must be multiples of 8");
+  USSEG_CHECK_ARG(d->nb1 > 0 && d->nb2 > 0 && (int64_t)d->nb1 * d->nb2 < 65536, "gemm: bad batch");
+  const bool f32 = (d->flags & USSEG_OUT_F32) != 0;
+  USSEG_CHECK_ARG(f32 ? d->ldy % 4 == 0 : (d->ldy % 8 == 0 && d->N % 8 == 0), "gemm: ldy / N alignment");
+  IgemmParams p = {};
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = y;
+  p.B = 1; p.Hg = 1; p.Wg = d->M; p.M = d->M;
+  p.Hi = 1; p.Wi = d->M; p.ldx = d->ldx; p.isy = p.isx = 1;
+  p.Ho = 1; p.Wo = d->M; p.ldy = d->ldy; p.osy = p.osx = 1;
+  p.cpt = d->K / 8; p.ntaps = 1; p.nchunks = p.cpt;
+  p.Nw = d->N; p.Kw = d->ldw; p.Nout = d->N;
+  p.out_f32 = f32 ? 1 : 0;
+  p.nb2 = d->nb2; p.nbatch = d->nb1 * d->nb2;
+  p.xs1 = d->xs1; p.xs2 = d->xs2; p.ws1 = d->ws1; p.ws2 = d->ws2; p.ys1 = d->ys1; p.ys2 = d->ys2;
   return launch_igemm(p, (hipStream_t)stream);
 }

@@ -20,6 +20,9 @@ struct WgradParams {
   int32_t mtiles, ntiles;
   int64_t chunk;  // pixels per split (multiple of 32)
   int16_t ady[16], adx[16], bdy[16], bdx[16];
+  // batched form (attention): blockIdx.z = b1*nb2 + b2 instead of the tap; operand bases + b1*s1 + b2*s2 (elements)
+  int32_t nb2;
+  int64_t as1, as2, bs1, bs2, os1, os2;
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
@@ -27,7 +30,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][BK * TS];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int t = blockIdx.z;
+  const int t = p.nb2 > 0 ? 0 : (int)blockIdx.z;
+  const int bz1 = p.nb2 > 0 ? (int)blockIdx.z / p.nb2 : 0, bz2 = p.nb2 > 0 ? (int)blockIdx.z - bz1 * p.nb2 : 0;
+  const bf16_t* const abase = p.a + bz1 * p.as1 + bz2 * p.as2;
+  const bf16_t* const bbase = p.b + bz1 * p.bs1 + bz2 * p.bs2;
   const int mt = blockIdx.y / p.ntiles, nt = blockIdx.y - mt * p.ntiles;
   const int m0 = mt * 64, n0 = nt * 64;
   const int64_t k_begin = (int64_t)blockIdx.x * p.chunk;
@@ -54,8 +60,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       bool in_a = (unsigned)ay < (unsigned)p.Ha && (unsigned)ax < (unsigned)p.Wa;
       bool in_b = (unsigned)by < (unsigned)p.Hb && (unsigned)bx < (unsigned)p.Wb;
       if (in_a && in_b) {  // a product with a zero operand contributes nothing: skip both loads
-        if (a_ok) ra = *reinterpret_cast<const uint4*>(p.a + ((int64_t)(b * p.Ha + ay) * p.Wa + ax) * p.lda + m0 + cc * 8);
-        if (b_ok) rb = *reinterpret_cast<const uint4*>(p.b + ((int64_t)(b * p.Hb + by) * p.Wb + bx) * p.ldb + n0 + cc * 8);
+        if (a_ok) ra = *reinterpret_cast<const uint4*>(abase + ((int64_t)(b * p.Ha + ay) * p.Wa + ax) * p.lda + m0 + cc * 8);
+        if (b_ok) rb = *reinterpret_cast<const uint4*>(bbase + ((int64_t)(b * p.Hb + by) * p.Wb + bx) * p.ldb + n0 + cc * 8);
       }
     }
   };
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
 
   // D[row = m_local = 4*(lane>>4)+j][col = n_local = lane&15]
-  float* out = p.out + (int64_t)t * p.Ma * p.Nb;
+  float* out = p.out + (int64_t)t * p.Ma * p.Nb + bz1 * p.os1 + bz2 * p.os2;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -180,4 +186,27 @@ extern "C" int usseg_tconv2d_wgrad(const UssegConvDesc* d, const void* x, const 
       p.bdy[t] = (int16_t)(kh - pad); p.bdx[t] = (int16_t)(kw - pad);
     }
   return launch_wgrad(p, k * k, (hipStream_t)stream);
+}
+
+// ---- batched "TN" GEMM: OUT[b1,b2][m][n] += sum_r A[b1,b2][r][m] * B[b1,b2][r][n]  (contraction over ROWS of both operands,
+// fp32 atomics into a zeroed buffer).  Attention backward: dV = P^T dO, dK = dS^T Q (VisionTransformer.py:41-47 transposed).
+extern "C" int usseg_gemm_tn_batched(const UssegGemmDesc* d, const void* a, const void* b, float* out, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && a && b && out, "null pointer");
+  USSEG_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->M % 8 == 0 && d->N % 8 == 0 && d->ldx % 8 == 0 && d->ldw % 8 == 0,
+                  "gemm_tn: M, N, lda, ldb must be multiples of 8");
+  USSEG_CHECK_ARG(d->nb1 > 0 && d->nb2 > 0 && (int64_t)d->nb1 * d->nb2 < 65536, "gemm_tn: bad batch");
+  WgradParams p = {};
+  p.a = (const bf16_t*)a; p.b = (const bf16_t*)b; p.out = out;
+  p.B = 1; p.Hg = 1; p.Wg = d->K; p.M = d->K;            // contraction length = rows
+  p.Ha = 1; p.Wa = d->K; p.lda = d->ldx; p.asy = p.asx = 1;
+  p.Hb = 1; p.Wb = d->K; p.ldb = d->ldw; p.bsy = p.bsx = 1;
+  p.Ma = d->M; p.Nb = d->N;
+  p.nb2 = d->nb2; p.as1 = d->xs1; p.as2 = d->xs2; p.bs1 = d->ws1; p.bs2 = d->ws2; p.os1 = d->ys1; p.os2 = d->ys2;
+  p.mtiles = (p.Ma + 63) / 64;
+  p.ntiles = (p.Nb + 63) / 64;
+  p.chunk = ((d->K + 31) / 32) * 32;                     // one split: the batch already fills the chip
+  const int slot = usseg_prof_start(2, (hipStream_t)stream);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(1, (unsigned)(p.mtiles * p.ntiles), (unsigned)(d->nb1 * d->nb2)), dim3(256), 0, (hipStream_t)stream, p);
+  usseg_prof_stop(2, slot, (hipStream_t)stream);
+  return usseg_check_launch("gemm_tn_batched");
 }

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib as L
-from ._lib import (ACCUMULATE, ACT_ELU, ACT_LRELU, ACT_NONE, ACT_RELU, OUT_F32, ConvDesc, LossDesc, NormDesc,
+from ._lib import (ACCUMULATE, ACT_ELU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, OUT_F32, ConvDesc, GemmDesc, LossDesc, NormDesc,
                    SplitAttnDesc, SplitAttnGrads, SplitAttnParams)
 
 BF16 = torch.bfloat16
@@ -355,3 +355,33 @@ def softmax_loss(logits, y_true, probs, loss, dlogits, *, HW, C_classes, loss_ki
 def loss_cat_scale(y_true, scale):
     B, H, W, Cc = y_true.shape
     L.check(L.load().usseg_loss_cat_scale(y_true.data_ptr(), B, H * W, Cc, scale.data_ptr(), _stream()), "loss_cat_scale")
+
+
+# ------------------------------------------------------------------------------------------------ ViT attention helpers
+def gemm_nt_batched(x, w, y, M, N, K, ldx, ldw, ldy, nb1, nb2, xs, ws, ys, out_f32=False):
+    """Y[b1,b2][m][n] = sum_k X[b1,b2][m][k] W[b1,b2][n][k]; x/w/y are tensors whose data_ptr is the (0,0) batch base."""
+    d = GemmDesc(M, N, K, ldx, ldw, ldy, nb1, nb2, xs[0], xs[1], ws[0], ws[1], ys[0], ys[1], OUT_F32 if out_f32 else 0)
+    L.check(L.load().usseg_gemm_nt_batched(C.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), _stream()), "gemm_nt_batched")
+
+
+def gemm_tn_batched(a, b, out, M, N, K, lda, ldb, nb1, nb2, as_, bs, os):
+    """OUT[b1,b2][m][n] += sum_r A[b1,b2][r][m] B[b1,b2][r][n] (fp32 out, zero it first)."""
+    d = GemmDesc(M, N, K, lda, ldb, N, nb1, nb2, as_[0], as_[1], bs[0], bs[1], os[0], os[1], 0)
+    L.check(L.load().usseg_gemm_tn_batched(C.byref(d), a.data_ptr(), b.data_ptr(), out.data_ptr(), _stream()), "gemm_tn_batched")
+
+
+def softmax_rows_fwd(s, n, scale, p32, pbf):
+    L.check(L.load().usseg_softmax_rows_fwd(s.data_ptr(), s.numel() // n, n, scale, p32.data_ptr(), pbf.data_ptr(), _stream()), "softmax_rows_fwd")
+
+
+def softmax_rows_bwd(p32, dp, n, scale, ds):
+    L.check(L.load().usseg_softmax_rows_bwd(p32.data_ptr(), dp.data_ptr(), p32.numel() // n, n, scale, ds.data_ptr(), _stream()), "softmax_rows_bwd")
+
+
+def transpose_batched(src, R, Cc, lds, nb1, nb2, ss, dst):
+    L.check(L.load().usseg_transpose_batched(src.data_ptr(), R, Cc, lds, nb1, nb2, ss[0], ss[1], dst.data_ptr(), _stream()), "transpose_batched")
+
+
+def cast_f32_to_bf16_batched(src, R, Cc, nb1, nb2, dst, ldd, ds):
+    L.check(L.load().usseg_cast_f32_to_bf16_batched(src.data_ptr(), R, Cc, nb1, nb2, dst.data_ptr(), ldd, ds[0], ds[1], _stream()),
+            "cast_f32_to_bf16_batched")
