@@ -30,7 +30,9 @@ def test_vit_bottleneck_train_step_parity():
     e = O.conv2d_same(x4, P["transformer.embeddings.patch_embeddings.kernel"], P["transformer.embeddings.patch_embeddings.bias"])
     _, w_ref = O.vit_block(e.reshape(2, 32, 512), P, "transformer.encoder.Transformer_layers.0.")
     print(f"attention weights (block 0) rel {rel(attn[0], w_ref):.3e}")
-    assert rel(attn[0], w_ref) < 2e-2
+    # the scores are divided by sqrt(num_heads) = 2 only (:42), so the softmax is sharp and amplifies the bf16 noise of
+    # the encoder output it is fed; test_vit_block_alone pins the block itself on identical inputs
+    assert rel(attn[0], w_ref) < 8e-2
 
     def oracle(storage):
         O.STORAGE_DTYPE = storage
@@ -44,12 +46,50 @@ def test_vit_bottleneck_train_step_parity():
     torch.cuda.synchronize()
     e_p, e_l = rel(probs, probs_r), abs(loss.item() - loss_r.item()) / abs(loss_r.item())
     g = net.export_grads()
-    errs = sorted(rel(g[k], g_r[k]) for k in g_r)
-    emu = sorted(rel(g_e[k], g_r[k]) for k in g_r)
-    worst = max((rel(g[k], g_e[k]), k) for k in g_r)
-    vit = sorted(rel(g[k], g_r[k]) for k in g_r if ".encoder." in k)
+    # the key bias has an exactly zero gradient (adding a constant to every key shifts each score row by a constant,
+    # which the softmax ignores): no relative error there, only "small"
+    zero = [k for k in g_r if k.endswith("attn.key.bias")]
+    for k in zero:
+        assert g_r[k].abs().max().item() < 1e-9
+        assert g[k].abs().max().item() < 2e-2 * max(g["transformer.encoder.Transformer_layers.0.attn.query.bias"].abs().max().item(), 1e-6), k
+    keys = [k for k in g_r if k not in zero]
+    errs = sorted(rel(g[k], g_r[k]) for k in keys)
+    emu = sorted(rel(g_e[k], g_r[k]) for k in keys)
+    worst = max((rel(g[k], g_e[k]), k) for k in keys)
+    vit = sorted(rel(g[k], g_r[k]) for k in keys if ".encoder." in k)
     print(f"probs rel {e_p:.3e} loss rel {e_l:.2e} grad median {errs[len(errs)//2]:.3e} p90 {errs[int(len(errs)*.9)]:.3e} "
           f"(ViT tensors median {vit[len(vit)//2]:.3e}); emulated oracle median {emu[len(emu)//2]:.3e} p90 {emu[int(len(emu)*.9)]:.3e}; worst vs emu {worst}")
     assert e_p < 2e-2 and e_l < 5e-3
     assert errs[len(errs) // 2] < max(3e-2, 1.5 * emu[len(emu) // 2]) and errs[int(len(errs) * 0.9)] < max(1e-1, 1.5 * emu[int(len(emu) * 0.9)])
     assert worst[0] < 2e-1
+
+
+def test_vit_block_alone():
+    """One transformer block on IDENTICAL bf16-representable inputs: output and attention weights vs the oracle."""
+    from ultrasound_modeling_amd.flat import FlatParams
+    from ultrasound_modeling_amd.VisionTransformer import Block
+    gen = torch.Generator().manual_seed(5)
+    bld = O._Builder(5, torch.float64)
+    O.init_vit_params(bld, "", layers=1, perturb=True)
+    P = {k: v.float().double() for k, v in bld.P.items()}
+    blk = Block()
+    FlatParams(blk, DEV)
+    own = dict(blk.named_parameters())
+    for k, t in own.items():
+        t.data.copy_(P["Transformer_layers.0." + k].float().reshape(t.shape))
+    blk.attn.on_finalize(DEV)           # repack the fused QKV operand and the per-layer operands after loading
+    for m in blk.modules():
+        if hasattr(m, "wp_f") and m.wp_f is not None:
+            m.repack()
+    B, N = 2, 48
+    x = (torch.randn(B, N, 512, generator=gen, dtype=torch.float64) * 0.7).to(torch.bfloat16).double()
+    xr = x.clone().requires_grad_(True)
+    out_r, w_r = O.vit_block(xr, P, "Transformer_layers.0.")
+    dy = torch.randn(B, N, 512, generator=gen, dtype=torch.float64).to(torch.bfloat16).double()
+    (out_r * dy).sum().backward()
+    out, w = blk.forward(x.to(torch.bfloat16).to(DEV).reshape(B, N, 1, 512))
+    dx = blk.backward(dy.to(torch.bfloat16).to(DEV).reshape(B, N, 1, 512))
+    torch.cuda.synchronize()
+    e_o, e_w, e_dx = rel(out.reshape(B, N, 512), out_r.detach()), rel(w, w_r.detach()), rel(dx.reshape(B, N, 512), xr.grad)
+    print(f"block alone: out rel {e_o:.3e} weights rel {e_w:.3e} dx rel {e_dx:.3e}")
+    assert e_o < 1e-2 and e_w < 2e-2 and e_dx < 3e-2

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* a, int64_t M,
 }
 
 extern "C" int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, float* ws, usseg_stream_t stream) {
-  USSEG_CHECK_ARG(dy && db && ws && C > 0 && ld % 8 == 0 && C <= 1024, "colsum: bad args");
+  USSEG_CHECK_ARG(dy && db && ws && C > 0 && ld % 8 == 0 && C <= 16384, "colsum: bad args");
   if (M <= 0) return USSEG_OK;
   // wide rows: process in slabs of 512 channels
   for (int c0 = 0; c0 < C; c0 += 512) {
