@@ -144,6 +144,15 @@ int64_t usseg_reduce_ws_floats(void);
 int usseg_channel_stats(const void* x, int64_t M, int32_t C, int32_t ldx, float* sum, float* sumsq, float* ws,
                         usseg_stream_t stream);
 
+/* BatchNormalization TRAINING mode (Keras semantics: batch mean, biased variance, moving statistics *= momentum).
+ * forward : usseg_channel_stats -> usseg_bn_finalize_stats -> usseg_norm_act_fwd(mode 1, mean/var = batch statistics);
+ * backward: usseg_norm_act_bwd(mode 1) with ZEROED scratch tg/tb as dgamma/dbeta, then usseg_bn_train_bwd_fix
+ *           (dx -= gamma*rstd*(tb + xhat*tg)/M), then add tg/tb to the real gradients. */
+int usseg_bn_finalize_stats(const float* sum, const float* sumsq, int64_t M, int32_t C, float momentum, float* mean, float* var,
+                            float* moving_mean, float* moving_var, usseg_stream_t stream);
+int usseg_bn_train_bwd_fix(const void* x, void* dx, int64_t M, int32_t C, int32_t Cphys, int32_t ldx, int32_t lddx, const float* gamma,
+                           const float* mean, const float* var, float eps, const float* tg, const float* tb, usseg_stream_t stream);
+
 /* ---- plain activation (conv1 + LeakyReLU, ResNest.py:39-40; TBI_ResNest.py:83-87) ------------- */
 int usseg_act_fwd(const void* x, int64_t M, int32_t C, int32_t ldx, int32_t ldy, int32_t act, float alpha, void* y,
                   usseg_stream_t stream);

@@ -362,3 +362,31 @@ def test_clip_adam_matches_oracle(gen):
         O.adam_step(po, clipped, mo, vo, it, 1e-3)
         assert rel(pd[:n], po[0]) < 1e-6
     assert step.item() == 3
+
+
+def test_batchnorm_training_mode(gen):
+    """Keras training=True semantics: batch mean / biased variance, moving statistics with momentum 0.99,
+    and the full batch-statistics backward."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import BatchNormalization
+    B, H, W, C = 3, 10, 6, 24
+    x = rnd(gen, B, H, W, C) * 1.5 + 0.3
+    x = bf(x)
+    bn = BatchNormalization(C)
+    ga, be = (1 + 0.3 * torch.randn(C, generator=gen)).double(), (0.2 * torch.randn(C, generator=gen)).double()
+    bn.gamma.data.copy_(ga)
+    bn.beta.data.copy_(be)
+    finalize(bn)
+    bn.training_mode = True
+    xd = to_dev_padded(x)
+    xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    y_ref, (mm, mv) = O.batch_norm(xr, gr, br, torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64), training=True)
+    y_ref = O.leaky_relu(y_ref)
+    y = bn.forward(xd, ops.ACT_LRELU, 0.3)
+    assert rel(y, bf(y_ref)) < 2e-3
+    assert rel(bn.moving_mean, mm) < 1e-4 and rel(bn.moving_variance, mv) < 1e-4
+    dy = rnd(gen, B, H, W, C)
+    (y_ref * dy).sum().backward()
+    dx = bn.backward(to_dev_padded(dy))
+    assert rel(dx, bf(xr.grad)) < 5e-3
+    assert rel(bn.gamma.grad, gr.grad) < 2e-3 and rel(bn.beta.grad, br.grad) < 2e-3

@@ -631,3 +631,58 @@ extern "C" int usseg_dropout_mask(void* mask, int64_t M, int32_t C, int32_t ld, 
                      C / 8, ld, seed, rate);
   return usseg_check_launch("dropout_mask");
 }
+
+// ---- BatchNormalization TRAINING mode (Keras: batch mean / biased variance, moving statistics updated with momentum) -------
+// forward : usseg_channel_stats -> usseg_bn_finalize_stats -> usseg_norm_act_fwd(mode 1, batch statistics)
+// backward: usseg_norm_act_bwd(mode 1) gives dx0 = dyh*gamma*rstd and this launch's sums tg = sum dyh*xhat, tb = sum dyh;
+//           usseg_bn_train_bwd_fix subtracts the batch-statistics terms: dx = dx0 - gamma*rstd*(tb + xhat*tg)/M.
+__global__ void bn_finalize_stats_kernel(const float* sum, const float* sumsq, float inv_m, int C, float momentum, float* mean, float* var,
+                                         float* moving_mean, float* moving_var) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mu = sum[c] * inv_m;
+  float v = fmaxf(sumsq[c] * inv_m - mu * mu, 0.f);
+  mean[c] = mu;
+  var[c] = v;
+  if (moving_mean) {
+    moving_mean[c] = moving_mean[c] * momentum + mu * (1.f - momentum);
+    moving_var[c] = moving_var[c] * momentum + v * (1.f - momentum);
+  }
+}
+extern "C" int usseg_bn_finalize_stats(const float* sum, const float* sumsq, int64_t M, int32_t C, float momentum, float* mean, float* var,
+                                       float* moving_mean, float* moving_var, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(sum && sumsq && mean && var && M > 0 && C > 0 && (!moving_mean == !moving_var), "bn_finalize_stats: bad args");
+  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq, 1.f / (float)M, C, momentum,
+                     mean, var, moving_mean, moving_var);
+  return usseg_check_launch("bn_finalize_stats");
+}
+
+__global__ __launch_bounds__(256) void bn_train_bwd_fix_kernel(const bf16_t* x, bf16_t* dx, int64_t M, int C, int CH, int ldx, int lddx, const float* gamma,
+                                                                const float* mean, const float* var, float eps, const float* tg, const float* tb,
+                                                                float inv_m) {
+  const int64_t total = M * CH;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t m = i / CH;
+    int c0 = (int)(i - m * CH) * 8;
+    float xv[8], dv[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c0), xv);
+    unpack8(*reinterpret_cast<const uint4*>(dx + m * lddx + c0), dv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = c0 + j;
+      if (c < C) {
+        float rs = rsqrtf(var[c] + eps);
+        float xh = (xv[j] - mean[c]) * rs;
+        dv[j] -= gamma[c] * rs * (tb[c] + xh * tg[c]) * inv_m;
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + m * lddx + c0) = pack8(dv);
+  }
+}
+extern "C" int usseg_bn_train_bwd_fix(const void* x, void* dx, int64_t M, int32_t C, int32_t Cphys, int32_t ldx, int32_t lddx, const float* gamma,
+                                      const float* mean, const float* var, float eps, const float* tg, const float* tb, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(x && dx && gamma && mean && var && tg && tb && Cphys % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && M > 0, "bn_train_bwd_fix: bad args");
+  hipLaunchKernelGGL(bn_train_bwd_fix_kernel, dim3(grid_for(M * (Cphys / 8), 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)dx, M, C, Cphys / 8, ldx, lddx, gamma, mean, var, eps, tg, tb, 1.f / (float)M);
+  return usseg_check_launch("bn_train_bwd_fix");
+}

@@ -277,5 +277,25 @@ class BatchNormalization(LayerNormalization):
 
     def forward(self, x, act=ACT_NONE, alpha=0.0, out=None):
         if self.training_mode:
-            raise NotImplementedError("BatchNormalization training mode is handled by bn_train_forward (see DESIGN.md)")
+            # Keras training=True: normalise with the batch mean / biased variance and move the running statistics
+            B, H, W, _, _ = ops.geom(x)
+            cp, dev = self.moving_mean_p.numel(), x.device
+            s, s2 = torch.zeros(cp, device=dev), torch.zeros(cp, device=dev)
+            ops.channel_stats(x, self.C, s, s2)
+            self._bmean, self._bvar = torch.zeros(cp, device=dev), torch.ones(cp, device=dev)
+            ops.bn_finalize_stats(s, s2, B * H * W, self.C, self.momentum, self._bmean, self._bvar, self.moving_mean_p, self.moving_variance_p)
         return super().forward(x, act, alpha, out)
+
+    def backward(self, dy, dx=None, dbias=None):
+        if not self.training_mode:
+            return super().backward(dy, dx, dbias)
+        x = self._x
+        act, alpha = self._act
+        dx = dx if dx is not None else torch.empty_like(x)
+        cp = self.moving_mean_p.numel()
+        tg, tb = torch.zeros(cp, device=x.device), torch.zeros(cp, device=x.device)
+        ops.norm_act_bwd(x, dy, self.C, self.gamma.data, self.beta.data, dx, tg, tb, 1, 1, self.eps, act, alpha, self._bmean, self._bvar)
+        ops.bn_train_bwd_fix(x, dx, self.C, self.gamma.data, self._bmean, self._bvar, self.eps, tg, tb)
+        self.gamma.grad.add_(tg[:self.C])      # tiny [C] vectors: host-side glue, not a compute kernel of the path
+        self.beta.grad.add_(tb[:self.C])
+        return dx                              # (a conv bias feeding a batch-statistics BN has exactly zero gradient: dbias untouched)

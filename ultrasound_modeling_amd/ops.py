@@ -215,6 +215,17 @@ def channel_stats(x, C_logical, s, s2):
                                          reduce_ws(x.device).data_ptr(), _stream()), "channel_stats")
 
 
+def bn_finalize_stats(s, s2, M, C_logical, momentum, mean, var, moving_mean=None, moving_var=None):
+    L.check(L.load().usseg_bn_finalize_stats(s.data_ptr(), s2.data_ptr(), M, C_logical, momentum, mean.data_ptr(), var.data_ptr(),
+                                             _ptr(moving_mean), _ptr(moving_var), _stream()), "bn_finalize_stats")
+
+
+def bn_train_bwd_fix(x, dx, C_logical, gamma, mean, var, eps, tg, tb):
+    B, H, W, Cphys, ldx = geom(x)
+    L.check(L.load().usseg_bn_train_bwd_fix(x.data_ptr(), dx.data_ptr(), B * H * W, C_logical, Cphys, ldx, geom(dx)[4], gamma.data_ptr(),
+                                            mean.data_ptr(), var.data_ptr(), eps, tg.data_ptr(), tb.data_ptr(), _stream()), "bn_train_bwd_fix")
+
+
 def act_fwd(x, out, act, alpha):
     B, H, W, Cc, ldx = geom(x)
     L.check(L.load().usseg_act_fwd(x.data_ptr(), B * H * W, Cc, ldx, geom(out)[4], act, alpha, out.data_ptr(), _stream()), "act_fwd")
