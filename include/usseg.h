@@ -70,18 +70,6 @@ int usseg_version(void);
  * y = act(conv(x, Wp) + bias) (+ residual).  bias may be NULL; residual (bf16, stride ldr) may be NULL. */
 int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const void* wp_fwd, const float* bias,
                      const void* residual, int32_t ldr, void* y, usseg_stream_t stream);
-/* Conv2D + BatchNormalization (inference affine, App. A.4) + activation in ONE launch (ResNest.py:41-46; Decoder.py:67-88):
- * y_raw receives the bf16 conv output (the backward needs it), e->y_act the normalised + activated tensor. */
-typedef struct UssegBnEpilogue {
-  void* y_act;
-  int32_t ldy_act;
-  const float *gamma, *beta, *mean, *var;   /* padded to the physical channel count */
-  float eps;
-  int32_t act;
-  float alpha;
-} UssegBnEpilogue;
-int usseg_conv2d_fwd_bn(const UssegConvDesc* d, const void* x, const void* wp_fwd, const float* bias, void* y_raw,
-                        const UssegBnEpilogue* e, usseg_stream_t stream);
 /* dx = conv_transpose(dy, W) (+ residual): the backward-data of the op above.  wp_dgrad is the operand
  * packed with in/out swapped (K index = tap*Cout + co).  dx has d->Cin channels, stride d->ldx. */
 int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp_dgrad, const void* residual,

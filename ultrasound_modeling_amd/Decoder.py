@@ -93,16 +93,15 @@ class DecoderBlock(nn.Module):
         self.up.forward(x, out=cat[..., :oc])                                         # :63
         if has_skip:
             ops.copy_channels(skip, cat[..., oc:])                                    # :66
-        a = KERAS_LRELU_ALPHA
-        raw1, act1 = ops.new_act(B, 2 * H, 2 * W, oc, dev), ops.new_act(B, 2 * H, 2 * W, oc, dev)
-        for j in range(4):            # :67-76 conv + BN + LeakyReLU in one launch per branch, each writing its channel slice
-            sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"conv1_{j}").forward_bn(cat, getattr(self, f"bn1_{j}"), ACT_LRELU, a, raw1[..., sl], act1[..., sl])
+        raw1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
+        for j in range(4):                                                            # :67-74 convs write their channel slice
+            getattr(self, f"conv1_{j}").forward(cat, out=raw1[..., j * q:(j + 1) * q])
+        act1 = self._bn_fwd("1", raw1, ops.new_act(B, 2 * H, 2 * W, oc, dev))        # :68-76 four BNs + LeakyReLU, one launch
         raw2 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
+        for j in range(4):                                                            # :79-86
+            getattr(self, f"conv2_{j}").forward(act1, out=raw2[..., j * q:(j + 1) * q])
         out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, oc, dev)
-        for j in range(4):                                                            # :79-88
-            sl = slice(j * q, (j + 1) * q)
-            getattr(self, f"conv2_{j}").forward_bn(act1, getattr(self, f"bn2_{j}"), ACT_LRELU, a, raw2[..., sl], out[..., sl])
+        self._bn_fwd("2", raw2, out)                                                  # :80-88
         self._has_skip, self._raw = has_skip, (raw1, raw2)
         return out
 

@@ -291,8 +291,10 @@ class ResNest(nn.Module):
             x = ops.cast_input(x.contiguous(), roundup(self.channel, 8))
         a = KERAS_LRELU_ALPHA
         self._y1 = self.conv1.forward(x, act=ACT_LRELU, alpha=a)                                  # :39-40
-        _, t = self.convtmp_1.forward_bn(self._y1, self.convtmp_1bn, ACT_LRELU, a)              # :41-43 (one launch)
-        _, t = self.convtmp_2.forward_bn(t, self.convtmp_2bn, ACT_LRELU, a)                      # :44-46
+        t = self.convtmp_1.forward(self._y1)                                                     # :41
+        t = self.convtmp_1bn.forward(t, ACT_LRELU, a)                                            # :42-43
+        t = self.convtmp_2.forward(t)                                                            # :44
+        t = self.convtmp_2bn.forward(t, ACT_LRELU, a)                                            # :45-46
         t = self.conv1_pool.forward(t)                                                           # :47
         x_1 = self.conv_1.forward(t)                                                             # :48
         x_2 = self.conv_2.forward(self.conv2_pool.forward(x_1))                                  # :49-50

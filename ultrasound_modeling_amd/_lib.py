@@ -50,11 +50,6 @@ class GemmDesc(C.Structure):
                 ("xs1", c_i64), ("xs2", c_i64), ("ws1", c_i64), ("ws2", c_i64), ("ys1", c_i64), ("ys2", c_i64), ("flags", c_i32)]
 
 
-class BnEpilogue(C.Structure):
-    _fields_ = [("y_act", c_vp), ("ldy_act", c_i32), ("gamma", c_vp), ("beta", c_vp), ("mean", c_vp), ("var", c_vp), ("eps", c_f32),
-                ("act", c_i32), ("alpha", c_f32)]
-
-
 class LossDesc(C.Structure):
     _fields_ = [("M", c_i64), ("HW", c_i32), ("C", c_i32), ("ldl", c_i32), ("lddl", c_i32), ("loss_kind", c_i32),
                 ("label_smoothing", c_f32), ("clip_eps", c_f32), ("inv_global_batch", c_f32)]
@@ -69,7 +64,6 @@ _PROTOS = {
     "usseg_last_error": (C.c_char_p, []),
     "usseg_version": (C.c_int, []),
     "usseg_conv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
-    "usseg_conv2d_fwd_bn": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, P(BnEpilogue), c_vp]),
     "usseg_conv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "usseg_tconv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),

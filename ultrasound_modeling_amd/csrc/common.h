@@ -51,32 +51,6 @@ __device__ __forceinline__ float act_grad(float v, int act, float alpha) {
   }
 }
 
-// Optional second output of a conv epilogue: BatchNormalization (inference affine) + activation of the bf16-rounded raw
-// result, written to y2 (the raw output is still stored: the backward needs it).  y2 == nullptr disables it.
-struct EpiBn {
-  bf16_t* y2;
-  int32_t ldy2;
-  const float *gamma, *beta, *mean, *var;
-  float eps;
-  int32_t act;
-  float alpha;
-};
-__device__ __forceinline__ void epi_bn_store(const EpiBn& e, const float* v, int64_t opix, int n) {
-  const float4 g = *reinterpret_cast<const float4*>(e.gamma + n), b = *reinterpret_cast<const float4*>(e.beta + n);
-  const float4 m = *reinterpret_cast<const float4*>(e.mean + n), va = *reinterpret_cast<const float4*>(e.var + n);
-  const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {va.x, va.y, va.z, va.w};
-  float o[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float raw = bf2f(f2bf(v[j]));   // what the norm kernel would read back
-    o[j] = apply_act(gg[j] * ((raw - mm[j]) * rsqrtf(vv[j] + e.eps)) + bb[j], e.act, e.alpha);
-  }
-  uint2 q;
-  q.x = pack2bf(o[0], o[1]);
-  q.y = pack2bf(o[2], o[3]);
-  *reinterpret_cast<uint2*>(e.y2 + opix * e.ldy2 + n) = q;
-}
-
 void usseg_set_error(const char* fmt, ...);
 #define USSEG_CHECK_ARG(cond, ...)                 \
   do {                                             \
@@ -98,7 +72,7 @@ void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int 
 // 3x3 conv with an LDS halo tile (conv_halo.hip): returns 1 if it took the launch, 0 if the geometry does not fit
 int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
                                int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
-                               int accumulate, int flip, const EpiBn* bn, hipStream_t s);
+                               int accumulate, int flip, hipStream_t s);
 
 // 3x3 weight gradient with an LDS halo tile (wgrad_halo.hip): 1 if it took the launch, 0 otherwise
 int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, int B, int H, int W, int d, int Ma, int Nb, int ldx, int lddy,

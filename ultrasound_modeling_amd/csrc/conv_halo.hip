@@ -32,7 +32,6 @@ struct HaloParams {
   int32_t act;
   float alpha;
   int32_t out_f32, accumulate, flip;
-  EpiBn bn;
 };
 
 template <int NT>
@@ -206,7 +205,6 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
         o.x = pack2bf(v[0], v[1]);
         o.y = pack2bf(v[2], v[3]);
         *reinterpret_cast<uint2*>(dst) = o;
-        if (p.bn.y2) epi_bn_store(p.bn, v, opix[a], n);
       }
     }
   }
@@ -378,7 +376,6 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel
           o.x = pack2bf(v[0], v[1]);
           o.y = pack2bf(v[2], v[3]);
           *reinterpret_cast<uint2*>(dst) = o;
-          if (p.bn.y2) epi_bn_store(p.bn, v, opix, n);
         }
       }
     }
@@ -388,7 +385,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel
 // Returns 1 and launches if the geometry fits the halo kernel, 0 if the caller must use the gather kernel.
 int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
                                int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
-                               int accumulate, int flip, const EpiBn* bn, hipStream_t s) {
+                               int accumulate, int flip, hipStream_t s) {
   static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
   if (disabled) return 0;
   if (d < 1 || H % d || W % d) return 0;
@@ -411,7 +408,6 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
   p.npatches = B * d * d * p.tiles_per_v;
   p.ldx = ldx; p.ldy = ldy; p.ldr = ldr; p.Cin = Cin; p.nchunks = (Cin + 31) / 32;
   p.Nw = Nw; p.Kw = Kw; p.Nout = Nout; p.act = act; p.alpha = alpha; p.out_f32 = out_f32; p.accumulate = accumulate; p.flip = flip;
-  if (bn) p.bn = *bn;
   const int gx = (p.npatches + NV - 1) / NV;
   // pick the channel tile: the widest that still gives the chip a few hundred workgroups
   int nt = Nout <= 16 ? 1 : (Nout <= 32 ? 2 : 4);

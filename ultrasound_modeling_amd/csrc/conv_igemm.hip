@@ -42,7 +42,6 @@ struct IgemmParams {
   // batched GEMM (attention): blockIdx.z = b1*nb2 + b2 selects operand bases x + b1*xs1 + b2*xs2 etc. (elements)
   int32_t nb2, nbatch;
   int64_t xs1, xs2, ws1, ws2, ys1, ys2;
-  EpiBn bn;
 };
 
 template <int NT>
@@ -217,7 +216,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         o.x = pack2bf(v[0], v[1]);
         o.y = pack2bf(v[2], v[3]);
         *reinterpret_cast<uint2*>(dst) = o;
-        if (p.bn.y2) epi_bn_store(p.bn, v, opix, n);
       }
     }
   }
@@ -255,35 +253,17 @@ static int check_desc(const UssegConvDesc* d, bool tconv) {
   return USSEG_OK;
 }
 
-static int conv2d_fwd_impl(const UssegConvDesc* d, const void* x, const void* wp, const float* bias, const void* residual, int32_t ldr, void* y,
-                           const EpiBn* bn, usseg_stream_t stream);
-
 extern "C" int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const void* wp, const float* bias,
                                 const void* residual, int32_t ldr, void* y, usseg_stream_t stream) {
-  return conv2d_fwd_impl(d, x, wp, bias, residual, ldr, y, nullptr, stream);
-}
-
-// Conv2D + BatchNormalization(inference) + activation in one launch: raw conv output AND the activated tensor are written.
-extern "C" int usseg_conv2d_fwd_bn(const UssegConvDesc* d, const void* x, const void* wp, const float* bias, void* y_raw,
-                                   const UssegBnEpilogue* e, usseg_stream_t stream) {
-  USSEG_CHECK_ARG(e && e->y_act && e->gamma && e->beta && e->mean && e->var && e->ldy_act % 8 == 0, "conv2d_fwd_bn: bad epilogue");
-  USSEG_CHECK_ARG(d && !(d->flags & (USSEG_OUT_F32 | USSEG_ACCUMULATE)) && d->act == USSEG_ACT_NONE, "conv2d_fwd_bn: raw output must be plain bf16");
-  EpiBn bn = {(bf16_t*)e->y_act, e->ldy_act, e->gamma, e->beta, e->mean, e->var, e->eps, e->act, e->alpha};
-  return conv2d_fwd_impl(d, x, wp, bias, nullptr, 0, y_raw, &bn, stream);
-}
-
-static int conv2d_fwd_impl(const UssegConvDesc* d, const void* x, const void* wp, const float* bias, const void* residual, int32_t ldr, void* y,
-                           const EpiBn* bn, usseg_stream_t stream) {
   int rc = check_desc(d, false);
   if (rc) return rc;
   USSEG_CHECK_ARG(x && wp && y, "null pointer");
   if (d->ksize == 3 &&
       usseg_try_launch_conv_halo((const bf16_t*)x, (const bf16_t*)wp, y, bias, (const bf16_t*)residual, d->B, d->H, d->W, d->dilation, d->Cin,
                                  d->ldx, d->Cout, d->ldy, ldr, roundup(d->Cout, 16), 9 * d->Cin, d->act, d->alpha,
-                                 (d->flags & USSEG_OUT_F32) ? 1 : 0, (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 0, bn, (hipStream_t)stream))
+                                 (d->flags & USSEG_OUT_F32) ? 1 : 0, (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 0, (hipStream_t)stream))
     return usseg_check_launch("conv_halo");
   IgemmParams p = {};
-  if (bn) p.bn = *bn;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.y = y; p.bias = bias; p.res = (const bf16_t*)residual; p.ldr = ldr;
   p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
   p.Hi = d->H; p.Wi = d->W; p.ldx = d->ldx; p.isy = p.isx = 1;
@@ -314,7 +294,7 @@ extern "C" int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const 
   if (d->ksize == 3 &&
       usseg_try_launch_conv_halo((const bf16_t*)dy, (const bf16_t*)wp, dx, nullptr, (const bf16_t*)residual, d->B, d->H, d->W, d->dilation,
                                  d->Cout, d->ldy, d->Cin, d->ldx, ldr, roundup(d->Cin, 16), 9 * d->Cout, USSEG_ACT_NONE, 0.f, 0,
-                                 (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 1, nullptr, (hipStream_t)stream))
+                                 (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 1, (hipStream_t)stream))
     return usseg_check_launch("conv_halo_dgrad");
   IgemmParams p = {};
   p.x = (const bf16_t*)dy; p.w = (const bf16_t*)wp; p.y = dx; p.bias = nullptr; p.res = (const bf16_t*)residual; p.ldr = ldr;

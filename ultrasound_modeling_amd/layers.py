@@ -149,22 +149,6 @@ class Conv2D(nn.Module):
         self._x = x
         return ops.conv2d_fwd(x, self.wp_f, self.bias.data if use_bias else None, self.k, self.dil, out, act, alpha, residual, out_f32)
 
-    def forward_bn(self, x, bn, act=ACT_NONE, alpha=0.0, out_raw=None, out_act=None):
-        """conv -> BatchNormalization (inference) -> activation in ONE launch (the epilogue stores both the raw conv output,
-        which the backward needs, and the activated tensor).  Falls back to two launches for training-mode BN."""
-        B, H, W, C, _ = ops.geom(x)
-        assert C == self.cin_p and not self.transposed
-        out_raw = out_raw if out_raw is not None else ops.new_act(B, H, W, self.cout_p, x.device)
-        if getattr(bn, "training_mode", False):
-            self.forward(x, out=out_raw)
-            return out_raw, bn.forward(out_raw, act, alpha, out=out_act)
-        out_act = out_act if out_act is not None else ops.new_act(B, H, W, self.cout_p, x.device)
-        self._x = x
-        bn._x, bn._act = out_raw, (act, alpha)
-        ops.conv2d_fwd_bn(x, self.wp_f, self.bias.data, self.k, self.dil, out_raw, out_act, bn.gamma.data, bn.beta.data,
-                          bn.moving_mean_p, bn.moving_variance_p, bn.eps, act, alpha)
-        return out_raw, out_act
-
     def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False, skip_bias=False):
         """dy: gradient w.r.t. the conv output (before any fused activation).  Accumulates kernel/bias grads.
         ``skip_bias``: the bias gradient was already produced by the following norm layer's backward (its ``dbias``)."""

@@ -92,17 +92,6 @@ def conv2d_fwd(x, wp, bias, ksize, dilation, out, act=ACT_NONE, alpha=0.0, resid
     return out
 
 
-def conv2d_fwd_bn(x, wp, bias, ksize, dilation, out_raw, out_act, gamma, beta, mean, var, eps, act, alpha):
-    """conv + BatchNormalization(inference) + activation in one launch; writes the raw conv output AND the activated tensor."""
-    B, H, W, Cin, ldx = geom(x)
-    _, _, _, Cout, ldy = geom(out_raw)
-    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation)
-    e = L.BnEpilogue(out_act.data_ptr(), geom(out_act)[4], gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, act, alpha)
-    L.check(L.load().usseg_conv2d_fwd_bn(C.byref(d), x.data_ptr(), wp.data_ptr(), _ptr(bias), out_raw.data_ptr(), C.byref(e), _stream()),
-            "conv2d_fwd_bn")
-    return out_raw, out_act
-
-
 def conv2d_dgrad(dy, wp_d, ksize, dilation, dx, residual=None, accumulate=False):
     B, H, W, Cout, ldy = geom(dy)
     _, _, _, Cin, ldx = geom(dx)
