@@ -80,6 +80,24 @@ int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp_dg
 int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw_scratch, float* ws,
                        int64_t ws_floats, usseg_stream_t stream);
 
+/* Several independent 3x3 convolutions in ONE launch: the DecoderBlock's parallel dilation branches
+ * (Decoder.py:14-25,39-50: the conv2_x / conv3_x / conv4_x layers read the same input and write disjoint channel slices of the
+ * concatenated output, Decoder.py:67-75,79-87).  Semantics = usseg_conv2d_fwd / usseg_conv2d_dgrad called once per job
+ * in order; the jobs must not depend on each other (disjoint outputs).  1 <= njobs <= 4.  Jobs that cannot share a
+ * grid are launched one after the other. */
+typedef struct UssegConvJob {
+  UssegConvDesc desc;
+  const void* x;        /* fwd: input x;  dgrad: dy */
+  const void* wp;       /* packed operand (forward packing for fwd, in/out-swapped packing for dgrad) */
+  const float* bias;    /* fwd only, may be NULL */
+  const void* residual; /* bf16, may be NULL */
+  int32_t ldr;
+  int32_t reserved;
+  void* y;              /* fwd: y;  dgrad: dx */
+} UssegConvJob;
+int usseg_conv2d_fwd_multi(int32_t njobs, const UssegConvJob* jobs, usseg_stream_t stream);
+int usseg_conv2d_dgrad_multi(int32_t njobs, const UssegConvJob* jobs, usseg_stream_t stream);
+
 /* ---- transposed convolution: Conv2DTranspose 3x3 s2 (Decoder.py:57,120) and 4x4 s2 (TBI_ResNest.py:124,210),
  * padding 'same' (k=3: out[2i+k] += x[i] w[k], last row/col cropped; k=4: out[2i+k-1]).  Four parity-class
  * implicit GEMMs, no zero insertion. */

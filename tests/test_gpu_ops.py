@@ -66,6 +66,13 @@ CONV_CASES = [
     (1, 24, 24, 128, 16, 3, 4),
     (1, 20, 20, 72, 136, 3, 8),   # dilation larger than half the image, Cout spans two N tiles
     (1, 1, 1, 10, 5, 1, 1),       # dense on a [B,1,1,C] tensor
+    # 256-pixel LDS-DMA kernel (conv_big.hip): Cin > 32, lattice width 16 / 8 / 4, ragged channel tails, partial groups
+    (2, 16, 16, 72, 136, 3, 2),   # 8x8 lattices (4 per workgroup), Cin tail 72 = 2*32 + 8, three N tiles (last partial)
+    (3, 16, 16, 96, 40, 3, 4),    # 4x4 lattices (16 per workgroup)
+    (1, 32, 16, 40, 64, 3, 1),    # two 16x16 patches, second channel chunk partial
+    (5, 8, 8, 64, 24, 3, 1),      # 5 patches -> last workgroup has one valid patch of four
+    (1, 8, 16, 64, 32, 3, 1),     # one 8x16 patch in a two-patch workgroup
+    (2, 32, 32, 256, 64, 3, 1),   # eight channel chunks through the double buffer
     # halo-tile kernel variants (conv_halo.hip): lattice patches 8x16, 8x8 (2 per workgroup), 4x4 (8 per workgroup), 4x8
     (2, 32, 32, 64, 64, 3, 8),    # d=8 on 32x32: 4x4 virtual images
     (1, 32, 32, 48, 24, 3, 4),    # d=4 on 32x32: 8x8 virtual images, Cin not a multiple of 32

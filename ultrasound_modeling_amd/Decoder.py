@@ -81,6 +81,18 @@ class DecoderBlock(nn.Module):
         return ops.norm_act_bwd(raw, dy, self.out_channels, d["gamma"], d["beta"], dx, d["dgamma"], d["dbeta"], 1, 1, KERAS_BN_EPS,
                                 ACT_LRELU, KERAS_LRELU_ALPHA, d["mean"], d["var"], dbias=d["dbias"])
 
+    def _branches_fwd(self, st, x, raw):
+        """The four parallel convs of a stage: the 1x1, then the three dilated 3x3 convs as ONE multi-job launch."""
+        q = self.out_channels // 4
+        convs = [getattr(self, f"conv{st}_{j}") for j in range(4)]
+        convs[0].forward(x, out=raw[..., :q])
+        jobs = []
+        for j in (1, 2, 3):
+            c = convs[j]
+            c._x = x
+            jobs.append((x, c.wp_f, c.bias.data, c.k, c.dil, raw[..., j * q:(j + 1) * q], ACT_NONE, 0.0))
+        ops.conv2d_fwd_multi(jobs)
+
     def forward(self, x, skip=None, out=None):
         """x [B,h,w,in]; skip [B,2h,2w,skip] or None; ``out``: optional [B,2h,2w,oc] slice to write the result into."""
         B, H, W, _, _ = ops.geom(x)
@@ -94,12 +106,10 @@ class DecoderBlock(nn.Module):
         if has_skip:
             ops.copy_channels(skip, cat[..., oc:])                                    # :66
         raw1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
-        for j in range(4):                                                            # :67-74 convs write their channel slice
-            getattr(self, f"conv1_{j}").forward(cat, out=raw1[..., j * q:(j + 1) * q])
+        self._branches_fwd("1", cat, raw1)                                            # :67-74 convs write their channel slice
         act1 = self._bn_fwd("1", raw1, ops.new_act(B, 2 * H, 2 * W, oc, dev))        # :68-76 four BNs + LeakyReLU, one launch
         raw2 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
-        for j in range(4):                                                            # :79-86
-            getattr(self, f"conv2_{j}").forward(act1, out=raw2[..., j * q:(j + 1) * q])
+        self._branches_fwd("2", act1, raw2)                                           # :79-86
         out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, oc, dev)
         self._bn_fwd("2", raw2, out)                                                  # :80-88
         self._has_skip, self._raw = has_skip, (raw1, raw2)

@@ -26,6 +26,11 @@ class ConvDesc(C.Structure):
                 ("flags", c_i32)]
 
 
+class ConvJob(C.Structure):
+    _fields_ = [("desc", ConvDesc), ("x", c_vp), ("wp", c_vp), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i32),
+                ("reserved", c_i32), ("y", c_vp)]
+
+
 class NormDesc(C.Structure):
     _fields_ = [("M", c_i64), ("C", c_i32), ("Cphys", c_i32), ("ldx", c_i32), ("ldy", c_i32), ("G", c_i32),
                 ("mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32)]
@@ -66,6 +71,8 @@ _PROTOS = {
     "usseg_conv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_conv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "usseg_conv2d_fwd_multi": (C.c_int, [c_i32, c_vp, c_vp]),
+    "usseg_conv2d_dgrad_multi": (C.c_int, [c_i32, c_vp, c_vp]),
     "usseg_tconv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_tconv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_tconv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp]),

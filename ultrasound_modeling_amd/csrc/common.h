@@ -74,6 +74,14 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
                                int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
                                int accumulate, int flip, hipStream_t s);
 
+// 3x3 conv, 256-pixel tiles with double-buffered LDS-DMA stages (conv_big.hip): 1 if it took the launch, 0 otherwise
+int usseg_try_launch_conv_big(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
+                              int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
+                              int accumulate, int flip, hipStream_t s);
+
+int usseg_try_launch_conv_halo_multi(int njobs, const UssegConvJob* jobs, int flip, hipStream_t s);
+int usseg_try_launch_conv_big_multi(int njobs, const UssegConvJob* jobs, int flip, hipStream_t s);
+
 // 3x3 weight gradient with an LDS halo tile (wgrad_halo.hip): 1 if it took the launch, 0 otherwise
 int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, int B, int H, int W, int d, int Ma, int Nb, int ldx, int lddy,
                                 float* ws, int64_t ws_floats, hipStream_t s);

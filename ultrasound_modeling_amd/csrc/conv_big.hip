@@ -1,0 +1,334 @@
+// 3x3 convolution for the channel-rich (MFMA / L2-fill bound) layers: 256-pixel x 16*NT-channel workgroup tile,
+// LDS-DMA (global_load_lds) double-buffered operand stages, bf16 MFMA, gfx950.
+//
+// Why a third conv kernel: conv_halo.hip moves (halo tile + 9 x BN weight rows) from L2 to LDS per 32-channel chunk
+// for only 128 x BN outputs (64-86 FLOP per staged byte); at the measured ~70 GB/s per CU of L2->LDS fill that caps
+// the decoder's 512->64 / 256->64 / concats_2 layers at 15-20 % of the MFMA peak.  Here a workgroup owns 256 pixels
+// (halo tile <= 576 pixels) x 64 channels: 165-250 FLOP per staged byte, the operands never pass through VGPRs
+// (no ds_write pass, no staging registers) and the next chunk's DMA flies under the current chunk's 144 MFMAs per wave.
+//
+// LDS image of a stage (no padding: a DMA wave-instruction writes 1 KiB = 16 rows x 64 B linearly):
+//   A: [halo pixel][32 ch] 64-B rows;  W: [tap*BN + n][32 k] 64-B rows.
+//   16-B slot j of row r holds k-group q = j ^ (2*((r>>2)&1)) - the source address is permuted, the read applies the
+//   same involution; with it every ds_read_b128 fragment read (16 consecutive rows) is bank-conflict free.
+// Up to 4 independent jobs (the DecoderBlock's parallel dilation branches) share one launch: blockIdx.z = job.
+#include "common.h"
+
+struct BigJob {
+  const bf16_t* x;
+  const bf16_t* w;
+  void* y;
+  const float* bias;
+  const bf16_t* res;
+  int32_t H, W, d, Hl, Wl, PH, PW, NV;
+  int32_t tiles_x, tiles_per_v, npatches;
+  int32_t ldx, ldy, ldr, Cin, nchunks, Nw, Kw, Nout, act;
+  float alpha;
+  int32_t out_f32, accumulate, flip;
+  int32_t gx, gy, npa, nstages;   // this job's grid extent; A pieces (16 halo pixels each) per stage; LDS stages (1 or 2)
+  uint32_t x_bytes, w_bytes;   // buffer extents for the range-checked DMA
+};
+struct BigParams {
+  BigJob job[4];
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// LDS-DMA through raw buffer loads: a lane whose byte offset is out of range (>= num_records) deposits ZEROS, which is
+// how the halo's out-of-image pixels, the channel tail and the weight rows past Nw are filled (no zero page, no select
+// between pointers).  OOB_OFF stays out of range after a chunk offset (< 64 KB) is added.
+#define OOB_OFF 0x80000000u
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
+  constexpr int BN = 16 * NT;
+  constexpr int W_BYTES = 9 * BN * 64;
+  constexpr int NPW = 9 * BN / 16;            // W pieces per stage
+  constexpr int W_IT = (NPW + 3) / 4;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const BigJob& p = P.job[blockIdx.z];
+  if ((int)blockIdx.x >= p.gx || (int)blockIdx.y >= p.gy) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.y * BN;
+  const int HW2 = p.PW + 2, HPP = (p.PH + 2) * HW2, NHP = p.NV * HPP;
+  const int a_bytes = p.npa * 1024, stage_bytes = a_bytes + W_BYTES;
+  const int dd = p.d * p.d;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  // ---- DMA source byte offsets, fixed for the kernel (OOB_OFF = zero fill).  Lane -> (row = 16*piece + lane/4, slot = lane%4)
+  const int slot_q = (lane & 3) ^ (((lane >> 4) & 1) << 1);   // k-group this lane's slot holds (row bit 2 == lane bit 4)
+  uint32_t a_off[9], w_off[W_IT];
+#pragma unroll
+  for (int it = 0; it < 9; ++it) {
+    const int hp = 16 * (wv + 4 * it) + (lane >> 2);
+    uint32_t off = OOB_OFF;
+    if (hp < NHP) {
+      int pi = hp / HPP, rem = hp - pi * HPP;
+      int hy = rem / HW2, hx = rem - hy * HW2;
+      int gp = blockIdx.x * p.NV + pi;
+      if (gp < p.npatches) {
+        int v = gp / p.tiles_per_v, tt = gp - v * p.tiles_per_v;
+        int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+        int b = v / dd, ab = v - b * dd;
+        int la = ab / p.d, lb = ab - la * p.d;
+        int ly = ty * p.PH + hy - 1, lx = tx * p.PW + hx - 1;
+        if ((unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl)
+          off = (uint32_t)(((b * p.H + la + p.d * ly) * p.W + lb + p.d * lx) * p.ldx + slot_q * 8) * 2u;
+      }
+    }
+    a_off[it] = off;
+  }
+#pragma unroll
+  for (int it = 0; it < W_IT; ++it) {
+    const int row = 16 * (wv + 4 * it) + (lane >> 2);   // t*BN + n
+    uint32_t off = OOB_OFF;
+    if (row < 9 * BN) {
+      int t = row / BN, n = row - t * BN;
+      int tw = p.flip ? 8 - t : t;
+      if (n0 + n < p.Nw) off = (uint32_t)((n0 + n) * p.Kw + tw * p.Cin + slot_q * 8) * 2u;
+    }
+    w_off[it] = off;
+  }
+  const int cq = slot_q * 8;
+
+  auto issue = [&](int ck, int stage) {
+    char* abuf = lds + stage * stage_bytes;
+    char* wbuf = abuf + a_bytes;
+    const uint32_t cb = ck * 64;                 // bytes
+    const bool cok = ck * 32 + cq < p.Cin;
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+      const int j = wv + 4 * it;
+      if (j < p.npa) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(abuf + j * 1024), 16, cok ? a_off[it] + cb : OOB_OFF, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int j = wv + 4 * it;
+      if (j < NPW) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wbuf + j * 1024), 16, cok ? w_off[it] + cb : OOB_OFF, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- this lane's four output pixels (one per 16-pixel strip of the wave)
+  const int pl = lane & 15, qk = lane >> 4;
+  const int rows_per_strip = 16 / p.PW, spp = (p.PH * p.PW) >> 4;
+  int hb[4];
+  int64_t opix[4];
+  bool ovalid[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    int s = wv * 4 + a;
+    int pi = s / spp, sl = s - pi * spp;
+    int r = pl / p.PW, c = pl - r * p.PW;
+    int row = sl * rows_per_strip + r;
+    hb[a] = pi * HPP + row * HW2 + c;
+    int gp = blockIdx.x * p.NV + pi;
+    ovalid[a] = gp < p.npatches;
+    int gpc = ovalid[a] ? gp : 0;
+    int v = gpc / p.tiles_per_v, tt = gpc - v * p.tiles_per_v;
+    int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+    int b = v / dd, ab = v - b * dd;
+    int la = ab / p.d, lb = ab - la * p.d;
+    int iy = la + p.d * (ty * p.PH + row), ix = lb + p.d * (tx * p.PW + c);
+    opix[a] = ((int64_t)b * p.H + iy) * p.W + ix;
+  }
+  const int w_lane = pl * 64 + ((qk ^ (((pl >> 2) & 1) << 1)) << 4);
+
+  f32x4_t acc[4][NT];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const bool dbuf = p.nstages == 2;
+  issue(0, 0);
+  for (int ck = 0; ck < p.nchunks; ++ck) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // chunk ck has landed for every wave; everyone is done reading the other stage
+    if (dbuf && ck + 1 < p.nchunks) issue(ck + 1, (ck + 1) & 1);
+    const char* abuf = lds + (dbuf ? (ck & 1) * stage_bytes : 0);
+    const char* wbuf = abuf + a_bytes + w_lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int toff = (t / 3) * HW2 + (t % 3);
+      bf16x8_t xf[4], wf[NT];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int hp = hb[a] + toff;
+        xf[a] = *reinterpret_cast<const bf16x8_t*>(abuf + (hp << 6) + ((qk << 4) ^ ((hp & 4) << 3)));
+      }
+#pragma unroll
+      for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8_t*>(wbuf + (t * BN + b * 16) * 64);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    }
+    if (!dbuf && ck + 1 < p.nchunks) {     // single stage (two workgroups per CU overlap each other): refill after everyone has read
+      __syncthreads();
+      issue(ck + 1, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds Y[its pixel][n = 4*(lane>>4) + j] per n-tile
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (!ovalid[a]) continue;
+#pragma unroll
+    for (int bt = 0; bt < NT; ++bt) {
+      int n = n0 + bt * 16 + qk * 4;
+      if (n >= p.Nout) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
+      if (p.bias) {
+        float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (p.act != USSEG_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act, p.alpha);
+      }
+      if (p.res) {
+        uint2 rr = *reinterpret_cast<const uint2*>(p.res + opix[a] * p.ldr + n);
+        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+      }
+      if (p.out_f32) {
+        float* dst = reinterpret_cast<float*>(p.y) + opix[a] * p.ldy + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < p.Nout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+      } else {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + opix[a] * p.ldy + n;
+        if (p.accumulate) {
+          uint2 o = *reinterpret_cast<const uint2*>(dst);
+          v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
+          v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(dst) = o;
+      }
+    }
+  }
+#endif
+}
+
+// Fills a job from a conv geometry; returns 0 if the geometry does not fit the 256-pixel tiling.
+static int big_fill_job(BigJob& p, const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W,
+                        int d, int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
+                        int accumulate, int flip) {
+  if (d < 1 || H % d || W % d || Cin <= 32) return 0;
+  const int Hl = H / d, Wl = W / d;
+  int PW;
+  if (Wl % 16 == 0) PW = 16;
+  else if (Wl == 8 || Wl == 4) PW = Wl;
+  else return 0;
+  int PH = 256 / PW;
+  if (PH > Hl) PH = Hl;
+  if (Hl % PH || (PH * PW) % 16 || 256 % (PH * PW)) return 0;
+  const int NV = 256 / (PH * PW);
+  const int NHP = NV * (PH + 2) * (PW + 2);
+  if (NHP > 576) return 0;
+  if ((int64_t)B * H * W * ldx >= (1ll << 30) || (int64_t)Nw * Kw >= (1ll << 30)) return 0;   // byte offsets < 2^31
+  p = {};
+  p.x = x; p.w = w; p.y = y; p.bias = bias; p.res = res;
+  p.H = H; p.W = W; p.d = d; p.Hl = Hl; p.Wl = Wl; p.PH = PH; p.PW = PW; p.NV = NV;
+  p.tiles_x = Wl / PW;
+  p.tiles_per_v = (Hl / PH) * p.tiles_x;
+  p.npatches = B * d * d * p.tiles_per_v;
+  p.ldx = ldx; p.ldy = ldy; p.ldr = ldr; p.Cin = Cin; p.nchunks = (Cin + 31) / 32;
+  p.Nw = Nw; p.Kw = Kw; p.Nout = Nout; p.act = act; p.alpha = alpha; p.out_f32 = out_f32; p.accumulate = accumulate; p.flip = flip;
+  p.gx = (p.npatches + NV - 1) / NV;
+  p.x_bytes = (uint32_t)((int64_t)B * H * W * ldx * 2);
+  p.w_bytes = (uint32_t)((int64_t)Nw * Kw * 2);
+  p.npa = (NHP + 15) / 16;
+  return 1;
+}
+
+// Workgroups the launch would have (the dispatcher wants >= ~1.5 per CU: two co-resident workgroups hide each other's DMA).
+static int64_t big_workgroups(const BigParams& P, int njobs) {
+  int nt = 1;
+  for (int j = 0; j < njobs; ++j) {
+    int n = P.job[j].Nout, t = n <= 16 ? 1 : (n <= 32 ? 2 : 4);
+    if (t > nt) nt = t;
+  }
+  int64_t tot = 0;
+  for (int j = 0; j < njobs; ++j) tot += (int64_t)P.job[j].gx * ((P.job[j].Nout + 16 * nt - 1) / (16 * nt));
+  return tot;
+}
+
+static int big_launch(BigParams& P, int njobs, hipStream_t s) {
+  int nt = 1, gx = 0, gy = 0, npa = 0;
+  for (int j = 0; j < njobs; ++j) {
+    int n = P.job[j].Nout;
+    int t = n <= 16 ? 1 : (n <= 32 ? 2 : 4);
+    if (t > nt) nt = t;
+  }
+  for (int j = 0; j < njobs; ++j) {
+    BigJob& p = P.job[j];
+    p.gy = (p.Nout + 16 * nt - 1) / (16 * nt);
+    if (p.gx > gx) gx = p.gx;
+    if (p.gy > gy) gy = p.gy;
+    if (p.npa > npa) npa = p.npa;
+  }
+  // one LDS stage and two workgroups per CU measured 1.3-1.4x faster than a double-buffered single workgroup
+  static const int stages_env = getenv("USSEG_BIG_STAGES") ? atoi(getenv("USSEG_BIG_STAGES")) : 1;
+  const int nstages = stages_env == 2 ? 2 : 1;
+  for (int j = 0; j < njobs; ++j) { P.job[j].npa = npa; P.job[j].nstages = nstages; }   // one stage layout for the whole launch
+  const size_t dyn = nstages * ((size_t)npa * 1024 + (size_t)9 * 16 * nt * 64);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_big_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int slot = usseg_prof_start(1, s);
+  if (nt == 1) hipLaunchKernelGGL(conv_big_kernel<1>, dim3(gx, gy, njobs), dim3(256), dyn, s, P);
+  else if (nt == 2) hipLaunchKernelGGL(conv_big_kernel<2>, dim3(gx, gy, njobs), dim3(256), dyn, s, P);
+  else hipLaunchKernelGGL(conv_big_kernel<4>, dim3(gx, gy, njobs), dim3(256), dyn, s, P);
+  usseg_prof_stop(1, slot, s);
+  return 1;
+}
+
+// Returns 1 and launches if the geometry fits, 0 if the caller must use another kernel.
+int usseg_try_launch_conv_big(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
+                              int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
+                              int accumulate, int flip, hipStream_t s) {
+  static const int mode = getenv("USSEG_BIG") ? atoi(getenv("USSEG_BIG")) : 1;
+  static const int min_wg = getenv("USSEG_BIG_MIN_WG") ? atoi(getenv("USSEG_BIG_MIN_WG")) : 384;
+  if (!mode) return 0;
+  BigParams P;
+  if (!big_fill_job(P.job[0], x, w, y, bias, res, B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act, alpha, out_f32, accumulate, flip))
+    return 0;
+  // alone, the 256-pixel tiling only pays with a long K loop (>= 8 channel chunks) and two workgroups per CU
+  if (P.job[0].nchunks < 8 || big_workgroups(P, 1) < (min_wg > 512 ? min_wg : 512)) return 0;
+  return big_launch(P, 1, s);
+}
+
+int usseg_try_launch_conv_big_multi(int njobs, const UssegConvJob* jobs, int flip, hipStream_t s) {
+  static const int mode = getenv("USSEG_BIG") ? atoi(getenv("USSEG_BIG")) : 1;
+  static const int min_wg = getenv("USSEG_BIG_MIN_WG") ? atoi(getenv("USSEG_BIG_MIN_WG")) : 384;
+  if (!mode || njobs < 1 || njobs > 4) return 0;
+  BigParams P;
+  for (int j = 0; j < njobs; ++j) {
+    const UssegConvJob& q = jobs[j];
+    const UssegConvDesc& d = q.desc;
+    const int out_f32 = (d.flags & USSEG_OUT_F32) ? 1 : 0, acc = (d.flags & USSEG_ACCUMULATE) ? 1 : 0;
+    int ok = flip ? big_fill_job(P.job[j], (const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, nullptr, (const bf16_t*)q.residual, d.B, d.H, d.W,
+                                 d.dilation, d.Cout, d.ldy, d.Cin, d.ldx, q.ldr, roundup(d.Cin, 16), 9 * d.Cout, USSEG_ACT_NONE, 0.f, 0, acc, 1)
+                  : big_fill_job(P.job[j], (const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, q.bias, (const bf16_t*)q.residual, d.B, d.H, d.W,
+                                 d.dilation, d.Cin, d.ldx, d.Cout, d.ldy, q.ldr, roundup(d.Cout, 16), 9 * d.Cin, d.act, d.alpha, out_f32, acc, 0);
+    if (!ok) return 0;
+  }
+  if (big_workgroups(P, njobs) < min_wg) return 0;
+  return big_launch(P, njobs, s);
+}

@@ -34,8 +34,16 @@ struct HaloParams {
   int32_t out_f32, accumulate, flip;
 };
 
+// Up to 4 independent convolutions of identical grid shape (the DecoderBlock's parallel dilation branches) share one
+// launch, blockIdx.z = job: three times the workgroups of one branch, so 2-3 of them are resident per CU and hide each
+// other's staging latency (one branch alone is a single wave of 256 one-per-CU workgroups at batch 16).
+struct HaloMulti {
+  HaloParams job[4];
+};
+
 template <int NT>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
+__global__ __launch_bounds__(256) void conv_halo_kernel(const HaloMulti P) {
+  const HaloParams& p = P.job[blockIdx.z];
   constexpr int BN = 16 * NT, LDSS = 40;
   constexpr int MAXHP = 288;                    // halo pixels per workgroup (8 patches of 6x6 is the maximum)
   constexpr int A_IT = (MAXHP * 4 + 255) / 256;  // 5
@@ -216,7 +224,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
 // kernel a 128-pixel workgroup of the 32->32 stem conv moves 18 KB of weights for 11 KB of activations.)
 // `gpb` consecutive pixel groups per workgroup; their patch geometry is decoded once into LDS.
 template <int NT>
-__global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel(const HaloParams p, const int gpb) {
+__global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel(const HaloMulti P, const int gpb) {
+  const HaloParams& p = P.job[blockIdx.z];
   constexpr int BN = 16 * NT, LDSS = 40, MAXHP = 288, MAXG = 16;
   constexpr int A_IT = (MAXHP * 4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];   // [nchunks][9*BN][LDSS] weights, then the halo tile
@@ -382,12 +391,10 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel
   }
 }
 
-// Returns 1 and launches if the geometry fits the halo kernel, 0 if the caller must use the gather kernel.
-int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
-                               int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
-                               int accumulate, int flip, hipStream_t s) {
-  static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
-  if (disabled) return 0;
+// Fills p from a conv geometry; returns 0 if the geometry does not fit the halo tiling.
+static int halo_fill(HaloParams& p, const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
+                     int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32, int accumulate,
+                     int flip) {
   if (d < 1 || H % d || W % d) return 0;
   const int Hl = H / d, Wl = W / d;
   int PW;
@@ -400,7 +407,7 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
   const int NV = 128 / (PH * PW);
   if (NV * (PH + 2) * (PW + 2) > 288) return 0;
   if ((int64_t)B * H * W * ldx >= (1ll << 31)) return 0;
-  HaloParams p = {};
+  p = {};
   p.x = x; p.w = w; p.y = y; p.bias = bias; p.res = res;
   p.B = B; p.H = H; p.W = W; p.d = d; p.Hl = Hl; p.Wl = Wl; p.PH = PH; p.PW = PW; p.NV = NV;
   p.tiles_x = Wl / PW;
@@ -408,20 +415,34 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
   p.npatches = B * d * d * p.tiles_per_v;
   p.ldx = ldx; p.ldy = ldy; p.ldr = ldr; p.Cin = Cin; p.nchunks = (Cin + 31) / 32;
   p.Nw = Nw; p.Kw = Kw; p.Nout = Nout; p.act = act; p.alpha = alpha; p.out_f32 = out_f32; p.accumulate = accumulate; p.flip = flip;
-  const int gx = (p.npatches + NV - 1) / NV;
+  return 1;
+}
+
+// Launches njobs jobs of identical (npatches/NV, Nout, nchunks) as one grid; returns 0 if they do not match.
+static int halo_launch(HaloMulti& P, int njobs, hipStream_t s) {
+  const HaloParams& p0 = P.job[0];
+  const int gx = (p0.npatches + p0.NV - 1) / p0.NV;
+  int maxhp = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const HaloParams& p = P.job[j];
+    if ((p.npatches + p.NV - 1) / p.NV != gx || p.Nout != p0.Nout || p.nchunks != p0.nchunks) return 0;
+    int hp = p.NV * (p.PH + 2) * (p.PW + 2);
+    if (hp > maxhp) maxhp = hp;
+  }
+  const int Nout = p0.Nout;
   // pick the channel tile: the widest that still gives the chip a few hundred workgroups
   int nt = Nout <= 16 ? 1 : (Nout <= 32 ? 2 : 4);
-  while (nt > 1 && (int64_t)gx * ((Nout + 16 * nt - 1) / (16 * nt)) < 256 && Nout > 16 * (nt / 2)) nt >>= 1;
+  while (nt > 1 && (int64_t)gx * njobs * ((Nout + 16 * nt - 1) / (16 * nt)) < 256 && Nout > 16 * (nt / 2)) nt >>= 1;
   const int gy = (Nout + 16 * nt - 1) / (16 * nt);
   const int slot = usseg_prof_start(1, s);
   // persistent variant: the tile's whole weight operand fits in 46 KB of LDS and there are pixel groups to amortise it over
   static const int no_persist = getenv("USSEG_NO_PERSIST") != nullptr;
-  const size_t wbytes = (size_t)p.nchunks * 9 * 16 * nt * 40 * sizeof(bf16_t);
+  const size_t wbytes = (size_t)p0.nchunks * 9 * 16 * nt * 40 * sizeof(bf16_t);
   if (!no_persist && wbytes <= 46080 && gx >= 1024) {
-    int gpb = (gx + 1023) / 1024;          // ~1024 workgroups (2 per CU resident, two waves of them)
+    int gpb = (gx * njobs + 1023) / 1024;          // ~1024 workgroups (2 per CU resident, two waves of them)
     if (gpb > 16) gpb = 16;
     const int pgx = (gx + gpb - 1) / gpb;
-    const size_t dyn = wbytes + (size_t)NV * (PH + 2) * (PW + 2) * 40 * sizeof(bf16_t);   // weights + this geometry's halo tile
+    const size_t dyn = wbytes + (size_t)maxhp * 40 * sizeof(bf16_t);   // weights + the largest halo tile of the jobs
     static bool attr_done = false;   // > 64 KB of LDS per workgroup needs the opt-in (one-time host call, never a stream op)
     if (!attr_done) {
       (void)hipFuncSetAttribute((const void*)conv_halo_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -429,15 +450,44 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
       (void)hipFuncSetAttribute((const void*)conv_halo_persist_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       attr_done = true;
     }
-    if (nt == 1) hipLaunchKernelGGL(conv_halo_persist_kernel<1>, dim3(pgx, gy), dim3(256), dyn, s, p, gpb);
-    else if (nt == 2) hipLaunchKernelGGL(conv_halo_persist_kernel<2>, dim3(pgx, gy), dim3(256), dyn, s, p, gpb);
-    else hipLaunchKernelGGL(conv_halo_persist_kernel<4>, dim3(pgx, gy), dim3(256), dyn, s, p, gpb);
+    if (nt == 1) hipLaunchKernelGGL(conv_halo_persist_kernel<1>, dim3(pgx, gy, njobs), dim3(256), dyn, s, P, gpb);
+    else if (nt == 2) hipLaunchKernelGGL(conv_halo_persist_kernel<2>, dim3(pgx, gy, njobs), dim3(256), dyn, s, P, gpb);
+    else hipLaunchKernelGGL(conv_halo_persist_kernel<4>, dim3(pgx, gy, njobs), dim3(256), dyn, s, P, gpb);
     usseg_prof_stop(1, slot, s);
     return 1;
   }
-  if (nt == 1) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(gx, gy), dim3(256), 0, s, p);
-  else if (nt == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(gx, gy), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(gx, gy), dim3(256), 0, s, p);
+  if (nt == 1) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(gx, gy, njobs), dim3(256), 0, s, P);
+  else if (nt == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(gx, gy, njobs), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(gx, gy, njobs), dim3(256), 0, s, P);
   usseg_prof_stop(1, slot, s);
   return 1;
+}
+
+// Returns 1 and launches if the geometry fits the halo kernel, 0 if the caller must use the gather kernel.
+int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
+                               int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
+                               int accumulate, int flip, hipStream_t s) {
+  static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
+  if (disabled) return 0;
+  HaloMulti P;
+  if (!halo_fill(P.job[0], x, w, y, bias, res, B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act, alpha, out_f32, accumulate, flip)) return 0;
+  return halo_launch(P, 1, s);
+}
+
+// Multi-job form (usseg_conv2d_fwd_multi / _dgrad_multi): every job must fit and share the grid shape.
+int usseg_try_launch_conv_halo_multi(int njobs, const UssegConvJob* jobs, int flip, hipStream_t s) {
+  static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
+  if (disabled || njobs < 1 || njobs > 4) return 0;
+  HaloMulti P;
+  for (int j = 0; j < njobs; ++j) {
+    const UssegConvJob& q = jobs[j];
+    const UssegConvDesc& d = q.desc;
+    const int out_f32 = (d.flags & USSEG_OUT_F32) ? 1 : 0, acc = (d.flags & USSEG_ACCUMULATE) ? 1 : 0;
+    int ok = flip ? halo_fill(P.job[j], (const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, nullptr, (const bf16_t*)q.residual, d.B, d.H, d.W,
+                              d.dilation, d.Cout, d.ldy, d.Cin, d.ldx, q.ldr, roundup(d.Cin, 16), 9 * d.Cout, USSEG_ACT_NONE, 0.f, 0, acc, 1)
+                  : halo_fill(P.job[j], (const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, q.bias, (const bf16_t*)q.residual, d.B, d.H, d.W,
+                              d.dilation, d.Cin, d.ldx, d.Cout, d.ldy, q.ldr, roundup(d.Cout, 16), 9 * d.Cin, d.act, d.alpha, out_f32, acc, 0);
+    if (!ok) return 0;
+  }
+  return halo_launch(P, njobs, s);
 }

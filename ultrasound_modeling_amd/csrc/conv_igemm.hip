@@ -259,6 +259,11 @@ extern "C" int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const voi
   if (rc) return rc;
   USSEG_CHECK_ARG(x && wp && y, "null pointer");
   if (d->ksize == 3 &&
+      usseg_try_launch_conv_big((const bf16_t*)x, (const bf16_t*)wp, y, bias, (const bf16_t*)residual, d->B, d->H, d->W, d->dilation, d->Cin,
+                                d->ldx, d->Cout, d->ldy, ldr, roundup(d->Cout, 16), 9 * d->Cin, d->act, d->alpha,
+                                (d->flags & USSEG_OUT_F32) ? 1 : 0, (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 0, (hipStream_t)stream))
+    return usseg_check_launch("conv_big");
+  if (d->ksize == 3 &&
       usseg_try_launch_conv_halo((const bf16_t*)x, (const bf16_t*)wp, y, bias, (const bf16_t*)residual, d->B, d->H, d->W, d->dilation, d->Cin,
                                  d->ldx, d->Cout, d->ldy, ldr, roundup(d->Cout, 16), 9 * d->Cin, d->act, d->alpha,
                                  (d->flags & USSEG_OUT_F32) ? 1 : 0, (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 0, (hipStream_t)stream))
@@ -292,6 +297,11 @@ extern "C" int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const 
   USSEG_CHECK_ARG(dy && wp && dx, "null pointer");
   USSEG_CHECK_ARG(!(d->flags & USSEG_OUT_F32) && d->Cout % 8 == 0, "dgrad needs bf16 dy with Cout % 8 == 0");
   if (d->ksize == 3 &&
+      usseg_try_launch_conv_big((const bf16_t*)dy, (const bf16_t*)wp, dx, nullptr, (const bf16_t*)residual, d->B, d->H, d->W, d->dilation,
+                                d->Cout, d->ldy, d->Cin, d->ldx, ldr, roundup(d->Cin, 16), 9 * d->Cout, USSEG_ACT_NONE, 0.f, 0,
+                                (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 1, (hipStream_t)stream))
+    return usseg_check_launch("conv_big_dgrad");
+  if (d->ksize == 3 &&
       usseg_try_launch_conv_halo((const bf16_t*)dy, (const bf16_t*)wp, dx, nullptr, (const bf16_t*)residual, d->B, d->H, d->W, d->dilation,
                                  d->Cout, d->ldy, d->Cin, d->ldx, ldr, roundup(d->Cin, 16), 9 * d->Cout, USSEG_ACT_NONE, 0.f, 0,
                                  (d->flags & USSEG_ACCUMULATE) ? 1 : 0, 1, (hipStream_t)stream))
@@ -315,6 +325,35 @@ extern "C" int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const 
   p.Nw = roundup(d->Cin, 16); p.Kw = p.ntaps * d->Cout; p.Nout = d->Cin;
   p.act = USSEG_ACT_NONE; p.alpha = 0.f; p.out_f32 = 0; p.accumulate = (d->flags & USSEG_ACCUMULATE) ? 1 : 0;
   return launch_igemm(p, (hipStream_t)stream);
+}
+
+static int conv_multi(int32_t njobs, const UssegConvJob* jobs, int flip, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(jobs && njobs >= 1 && njobs <= 4, "conv multi: 1 <= njobs <= 4");
+  bool all3 = true;
+  for (int j = 0; j < njobs; ++j) {
+    int rc = check_desc(&jobs[j].desc, false);
+    if (rc) return rc;
+    USSEG_CHECK_ARG(jobs[j].x && jobs[j].wp && jobs[j].y, "conv multi: null pointer");
+    if (flip) USSEG_CHECK_ARG(!(jobs[j].desc.flags & USSEG_OUT_F32) && jobs[j].desc.Cout % 8 == 0, "dgrad needs bf16 dy with Cout % 8 == 0");
+    all3 = all3 && jobs[j].desc.ksize == 3;
+  }
+  if (njobs > 1 && all3) {
+    if (usseg_try_launch_conv_big_multi(njobs, jobs, flip, (hipStream_t)stream)) return usseg_check_launch("conv_big_multi");
+    if (usseg_try_launch_conv_halo_multi(njobs, jobs, flip, (hipStream_t)stream)) return usseg_check_launch("conv_halo_multi");
+  }
+  for (int j = 0; j < njobs; ++j) {
+    const UssegConvJob& q = jobs[j];
+    int rc = flip ? usseg_conv2d_dgrad(&q.desc, q.x, q.wp, q.residual, q.ldr, q.y, stream)
+                  : usseg_conv2d_fwd(&q.desc, q.x, q.wp, q.bias, q.residual, q.ldr, q.y, stream);
+    if (rc) return rc;
+  }
+  return USSEG_OK;
+}
+extern "C" int usseg_conv2d_fwd_multi(int32_t njobs, const UssegConvJob* jobs, usseg_stream_t stream) {
+  return conv_multi(njobs, jobs, 0, stream);
+}
+extern "C" int usseg_conv2d_dgrad_multi(int32_t njobs, const UssegConvJob* jobs, usseg_stream_t stream) {
+  return conv_multi(njobs, jobs, 1, stream);
 }
 
 // Conv2DTranspose stride 2 'same': out[2i + kh - pad] += x[i] * w[kh], pad = 0 (k=3, crop end) / 1 (k=4).

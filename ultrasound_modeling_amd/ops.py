@@ -102,6 +102,30 @@ def conv2d_dgrad(dy, wp_d, ksize, dilation, dx, residual=None, accumulate=False)
     return dx
 
 
+def conv2d_fwd_multi(jobs):
+    """jobs: list of (x, wp, bias, ksize, dilation, out, act, alpha) of INDEPENDENT convs -> one launch where possible."""
+    arr = (L.ConvJob * len(jobs))()
+    for j, (x, wp, bias, ksize, dilation, out, act, alpha) in enumerate(jobs):
+        B, H, W, Cin, ldx = geom(x)
+        Bo, Ho, Wo, Cout, ldy = geom(out)
+        assert (Bo, Ho, Wo) == (B, H, W) and x.dtype == BF16 and out.dtype == BF16
+        arr[j].desc = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation, act, alpha, 0)
+        arr[j].x, arr[j].wp, arr[j].bias, arr[j].residual, arr[j].ldr, arr[j].y = x.data_ptr(), wp.data_ptr(), _ptr(bias), None, 0, out.data_ptr()
+    L.check(L.load().usseg_conv2d_fwd_multi(len(jobs), C.addressof(arr), _stream()), "conv2d_fwd_multi")
+
+
+def conv2d_dgrad_multi(jobs):
+    """jobs: list of (dy, wp_d, ksize, dilation, dx, residual, accumulate) writing DISJOINT dx buffers -> one launch where possible."""
+    arr = (L.ConvJob * len(jobs))()
+    for j, (dy, wp_d, ksize, dilation, dx, residual, accumulate) in enumerate(jobs):
+        B, H, W, Cout, ldy = geom(dy)
+        _, _, _, Cin, ldx = geom(dx)
+        arr[j].desc = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation, flags=ACCUMULATE if accumulate else 0)
+        arr[j].x, arr[j].wp, arr[j].bias, arr[j].y = dy.data_ptr(), wp_d.data_ptr(), None, dx.data_ptr()
+        arr[j].residual, arr[j].ldr = _ptr(residual), (geom(residual)[4] if residual is not None else 0)
+    L.check(L.load().usseg_conv2d_dgrad_multi(len(jobs), C.addressof(arr), _stream()), "conv2d_dgrad_multi")
+
+
 def conv2d_wgrad(x, dy, ksize, dilation, dw: torch.Tensor):
     """dw (fp32, [ntaps, Cin_phys, Cout_phys], pre-zeroed or holding a running sum) += x^T dy."""
     B, H, W, Cin, ldx = geom(x)
