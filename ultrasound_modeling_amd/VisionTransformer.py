@@ -359,8 +359,9 @@ class VisionTransformer(nn.Module):
         """zero grads, forward, loss, backward (+ the per-replica clip when gradients are exchanged afterwards)."""
         self.flat.zero_grad()
         probs, dlogits = self._forward_loss(x, y, with_grad=True)                      # :240-241
-        d_hidden, d_feats = self.decoder.backward(dlogits)                             # :243
-        self.transformer.backward(d_hidden, d_feats)
+        with ops.overlap_region():              # weight gradients on the side stream, joined before the optimiser
+            d_hidden, d_feats = self.decoder.backward(dlogits)                         # :243
+            self.transformer.backward(d_hidden, d_feats)
         if self.grad_sync is not None:
             self.optimizer.clip_local()                                                # per-replica clip (:244) BEFORE the exchange
         return probs

@@ -38,13 +38,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // between pointers).  OOB_OFF stays out of range after a chunk offset (< 64 KB) is added.
 #define OOB_OFF 0x80000000u
 
-template <int NT>
+template <int NT, int NS>   // NS = 16-pixel strips per wave: workgroup tile = 64*NS pixels x 16*NT channels
 __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
   constexpr int BN = 16 * NT;
   constexpr int W_BYTES = 9 * BN * 64;
   constexpr int NPW = 9 * BN / 16;            // W pieces per stage
   constexpr int W_IT = (NPW + 3) / 4;
+  constexpr int A_IT = NS == 4 ? 9 : 5;       // A pieces per wave: halo tile <= 576 (NS=4) / 288 (NS=2) pixels
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const BigJob& p = P.job[blockIdx.z];
   if ((int)blockIdx.x >= p.gx || (int)blockIdx.y >= p.gy) return;
@@ -59,9 +60,9 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
   // ---- DMA source byte offsets, fixed for the kernel (OOB_OFF = zero fill).  Lane -> (row = 16*piece + lane/4, slot = lane%4)
   const int slot_q = (lane & 3) ^ (((lane >> 4) & 1) << 1);   // k-group this lane's slot holds (row bit 2 == lane bit 4)
-  uint32_t a_off[9], w_off[W_IT];
+  uint32_t a_off[A_IT], w_off[W_IT];
 #pragma unroll
-  for (int it = 0; it < 9; ++it) {
+  for (int it = 0; it < A_IT; ++it) {
     const int hp = 16 * (wv + 4 * it) + (lane >> 2);
     uint32_t off = OOB_OFF;
     if (hp < NHP) {
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
     const uint32_t cb = ck * 64;                 // bytes
     const bool cok = ck * 32 + cq < p.Cin;
 #pragma unroll
-    for (int it = 0; it < 9; ++it) {
+    for (int it = 0; it < A_IT; ++it) {
       const int j = wv + 4 * it;
       if (j < p.npa) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(abuf + j * 1024), 16, cok ? a_off[it] + cb : OOB_OFF, 0, 0, 0);
@@ -114,15 +115,15 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
     }
   };
 
-  // ---- this lane's four output pixels (one per 16-pixel strip of the wave)
+  // ---- this lane's NS output pixels (one per 16-pixel strip of the wave)
   const int pl = lane & 15, qk = lane >> 4;
   const int rows_per_strip = 16 / p.PW, spp = (p.PH * p.PW) >> 4;
-  int hb[4];
-  int64_t opix[4];
-  bool ovalid[4];
+  int hb[NS];
+  int64_t opix[NS];
+  bool ovalid[NS];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    int s = wv * 4 + a;
+  for (int a = 0; a < NS; ++a) {
+    int s = wv * NS + a;
     int pi = s / spp, sl = s - pi * spp;
     int r = pl / p.PW, c = pl - r * p.PW;
     int row = sl * rows_per_strip + r;
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
   }
   const int w_lane = pl * 64 + ((qk ^ (((pl >> 2) & 1) << 1)) << 4);
 
-  f32x4_t acc[4][NT];
+  f32x4_t acc[NS][NT];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NS; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -156,16 +157,16 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int toff = (t / 3) * HW2 + (t % 3);
-      bf16x8_t xf[4], wf[NT];
+      bf16x8_t xf[NS], wf[NT];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < NS; ++a) {
         const int hp = hb[a] + toff;
         xf[a] = *reinterpret_cast<const bf16x8_t*>(abuf + (hp << 6) + ((qk << 4) ^ ((hp & 4) << 3)));
       }
 #pragma unroll
       for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8_t*>(wbuf + (t * BN + b * 16) * 64);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < NS; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
     }
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
 
   // ---- epilogue: lane holds Y[its pixel][n = 4*(lane>>4) + j] per n-tile
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int a = 0; a < NS; ++a) {
     if (!ovalid[a]) continue;
 #pragma unroll
     for (int bt = 0; bt < NT; ++bt) {
@@ -224,19 +225,19 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
 // Fills a job from a conv geometry; returns 0 if the geometry does not fit the 256-pixel tiling.
 static int big_fill_job(BigJob& p, const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W,
                         int d, int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
-                        int accumulate, int flip) {
+                        int accumulate, int flip, int PX) {
   if (d < 1 || H % d || W % d || Cin <= 32) return 0;
   const int Hl = H / d, Wl = W / d;
   int PW;
   if (Wl % 16 == 0) PW = 16;
   else if (Wl == 8 || Wl == 4) PW = Wl;
   else return 0;
-  int PH = 256 / PW;
+  int PH = PX / PW;
   if (PH > Hl) PH = Hl;
-  if (Hl % PH || (PH * PW) % 16 || 256 % (PH * PW)) return 0;
-  const int NV = 256 / (PH * PW);
+  if (Hl % PH || (PH * PW) % 16 || PX % (PH * PW)) return 0;
+  const int NV = PX / (PH * PW);
   const int NHP = NV * (PH + 2) * (PW + 2);
-  if (NHP > 576) return 0;
+  if (NHP > (PX == 256 ? 576 : 288)) return 0;
   if ((int64_t)B * H * W * ldx >= (1ll << 30) || (int64_t)Nw * Kw >= (1ll << 30)) return 0;   // byte offsets < 2^31
   p = {};
   p.x = x; p.w = w; p.y = y; p.bias = bias; p.res = res;
@@ -253,25 +254,20 @@ static int big_fill_job(BigJob& p, const bf16_t* x, const bf16_t* w, void* y, co
   return 1;
 }
 
-// Workgroups the launch would have (the dispatcher wants >= ~1.5 per CU: two co-resident workgroups hide each other's DMA).
-static int64_t big_workgroups(const BigParams& P, int njobs) {
-  int nt = 1;
-  for (int j = 0; j < njobs; ++j) {
-    int n = P.job[j].Nout, t = n <= 16 ? 1 : (n <= 32 ? 2 : 4);
-    if (t > nt) nt = t;
+static int nt_for(int nout) { return nout <= 16 ? 1 : (nout <= 32 ? 2 : 4); }
+
+template <int NT, int NS>
+static void big_launch_t(const BigParams& P, dim3 grid, size_t dyn, hipStream_t s) {
+  static bool attr_done = false;   // > 64 KB of LDS per workgroup needs the opt-in (one-time host call, never a stream op)
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_big_kernel<NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
   }
-  int64_t tot = 0;
-  for (int j = 0; j < njobs; ++j) tot += (int64_t)P.job[j].gx * ((P.job[j].Nout + 16 * nt - 1) / (16 * nt));
-  return tot;
+  hipLaunchKernelGGL((conv_big_kernel<NT, NS>), grid, dim3(256), dyn, s, P);
 }
 
-static int big_launch(BigParams& P, int njobs, hipStream_t s) {
-  int nt = 1, gx = 0, gy = 0, npa = 0;
-  for (int j = 0; j < njobs; ++j) {
-    int n = P.job[j].Nout;
-    int t = n <= 16 ? 1 : (n <= 32 ? 2 : 4);
-    if (t > nt) nt = t;
-  }
+static void big_launch(BigParams& P, int njobs, int nt, int PX, hipStream_t s) {
+  int gx = 0, gy = 0, npa = 0;
   for (int j = 0; j < njobs; ++j) {
     BigJob& p = P.job[j];
     p.gy = (p.Nout + 16 * nt - 1) / (16 * nt);
@@ -279,23 +275,69 @@ static int big_launch(BigParams& P, int njobs, hipStream_t s) {
     if (p.gy > gy) gy = p.gy;
     if (p.npa > npa) npa = p.npa;
   }
-  // one LDS stage and two workgroups per CU measured 1.3-1.4x faster than a double-buffered single workgroup
+  // one LDS stage with two or more workgroups per CU measured 1.3-1.4x faster than a double-buffered single workgroup
   static const int stages_env = getenv("USSEG_BIG_STAGES") ? atoi(getenv("USSEG_BIG_STAGES")) : 1;
   const int nstages = stages_env == 2 ? 2 : 1;
   for (int j = 0; j < njobs; ++j) { P.job[j].npa = npa; P.job[j].nstages = nstages; }   // one stage layout for the whole launch
   const size_t dyn = nstages * ((size_t)npa * 1024 + (size_t)9 * 16 * nt * 64);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_big_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  const dim3 grid(gx, gy, njobs);
   const int slot = usseg_prof_start(1, s);
-  if (nt == 1) hipLaunchKernelGGL(conv_big_kernel<1>, dim3(gx, gy, njobs), dim3(256), dyn, s, P);
-  else if (nt == 2) hipLaunchKernelGGL(conv_big_kernel<2>, dim3(gx, gy, njobs), dim3(256), dyn, s, P);
-  else hipLaunchKernelGGL(conv_big_kernel<4>, dim3(gx, gy, njobs), dim3(256), dyn, s, P);
+  if (PX == 256) {
+    if (nt == 1) big_launch_t<1, 4>(P, grid, dyn, s);
+    else if (nt == 2) big_launch_t<2, 4>(P, grid, dyn, s);
+    else big_launch_t<4, 4>(P, grid, dyn, s);
+  } else {
+    if (nt == 1) big_launch_t<1, 2>(P, grid, dyn, s);
+    else if (nt == 2) big_launch_t<2, 2>(P, grid, dyn, s);
+    else big_launch_t<4, 2>(P, grid, dyn, s);
+  }
   usseg_prof_stop(1, slot, s);
+}
+
+struct BigGeom {   // what big_fill_job needs, so that a job can be re-filled for another pixel tile
+  const bf16_t* x; const bf16_t* w; void* y; const float* bias; const bf16_t* res;
+  int B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act; float alpha; int out_f32, accumulate, flip;
+};
+
+// Chooses the tile (pixels per workgroup, channel tile) and launches; 0 if no tiling fits or the launch would be too small.
+static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
+  static const int mode = getenv("USSEG_BIG") ? atoi(getenv("USSEG_BIG")) : 1;
+  static const int px_env = getenv("USSEG_BIG_PX") ? atoi(getenv("USSEG_BIG_PX")) : 0;
+  static const int nt_env = getenv("USSEG_BIG_NT") ? atoi(getenv("USSEG_BIG_NT")) : 0;
+  static const int min_wg = getenv("USSEG_BIG_MIN_WG") ? atoi(getenv("USSEG_BIG_MIN_WG")) : 128;
+  if (!mode) return 0;
+  int nt_max = 1;
+  for (int j = 0; j < njobs; ++j) nt_max = nt_for(g[j].Nout) > nt_max ? nt_for(g[j].Nout) : nt_max;
+  BigParams P;
+  // Tile policy (measured at batch 16 and 128, tools/bench_conv.py): 128-pixel tiles unless the launch is large enough to
+  // give every CU eight 256-pixel workgroups; then the widest channel tile that still yields two workgroups per CU.
+  int best_px = 0, best_nt = 0;
+  int64_t best_wg = 0;
+  for (int PX = 256; PX >= 128 && !best_px; PX >>= 1) {
+    if (px_env && PX != px_env) continue;
+    bool ok = true;
+    for (int j = 0; j < njobs && ok; ++j)
+      ok = big_fill_job(P.job[j], g[j].x, g[j].w, g[j].y, g[j].bias, g[j].res, g[j].B, g[j].H, g[j].W, g[j].d, g[j].Cin, g[j].ldx, g[j].Nout,
+                        g[j].ldy, g[j].ldr, g[j].Nw, g[j].Kw, g[j].act, g[j].alpha, g[j].out_f32, g[j].accumulate, g[j].flip, PX);
+    if (!ok) continue;
+    for (int nt = nt_max; nt >= 1; nt >>= 1) {
+      if (nt_env && nt != nt_env) continue;
+      int64_t wg = 0;
+      for (int j = 0; j < njobs; ++j) wg += (int64_t)P.job[j].gx * ((P.job[j].Nout + 16 * nt - 1) / (16 * nt));
+      if (PX == 256 && !px_env) {
+        if (nt == nt_max && wg >= 2048) { best_px = PX; best_nt = nt; best_wg = wg; }
+        break;
+      }
+      best_px = PX; best_nt = nt; best_wg = wg;      // narrower tiles only add workgroups: keep the last one tried
+      if (wg >= 512 || nt_env) break;
+    }
+  }
+  if (!best_px || (best_wg < min_wg && !(px_env || nt_env))) return 0;
+  for (int j = 0; j < njobs; ++j)
+    if (!big_fill_job(P.job[j], g[j].x, g[j].w, g[j].y, g[j].bias, g[j].res, g[j].B, g[j].H, g[j].W, g[j].d, g[j].Cin, g[j].ldx, g[j].Nout,
+                      g[j].ldy, g[j].ldr, g[j].Nw, g[j].Kw, g[j].act, g[j].alpha, g[j].out_f32, g[j].accumulate, g[j].flip, best_px))
+      return 0;
+  big_launch(P, njobs, best_nt, best_px, s);
   return 1;
 }
 
@@ -303,32 +345,23 @@ static int big_launch(BigParams& P, int njobs, hipStream_t s) {
 int usseg_try_launch_conv_big(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,
                               int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
                               int accumulate, int flip, hipStream_t s) {
-  static const int mode = getenv("USSEG_BIG") ? atoi(getenv("USSEG_BIG")) : 1;
-  static const int min_wg = getenv("USSEG_BIG_MIN_WG") ? atoi(getenv("USSEG_BIG_MIN_WG")) : 384;
-  if (!mode) return 0;
-  BigParams P;
-  if (!big_fill_job(P.job[0], x, w, y, bias, res, B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act, alpha, out_f32, accumulate, flip))
-    return 0;
-  // alone, the 256-pixel tiling only pays with a long K loop (>= 8 channel chunks) and two workgroups per CU
-  if (P.job[0].nchunks < 8 || big_workgroups(P, 1) < (min_wg > 512 ? min_wg : 512)) return 0;
-  return big_launch(P, 1, s);
+  BigGeom g = {x, w, y, bias, res, B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act, alpha, out_f32, accumulate, flip};
+  return big_plan_and_launch(&g, 1, s);
 }
 
 int usseg_try_launch_conv_big_multi(int njobs, const UssegConvJob* jobs, int flip, hipStream_t s) {
-  static const int mode = getenv("USSEG_BIG") ? atoi(getenv("USSEG_BIG")) : 1;
-  static const int min_wg = getenv("USSEG_BIG_MIN_WG") ? atoi(getenv("USSEG_BIG_MIN_WG")) : 384;
-  if (!mode || njobs < 1 || njobs > 4) return 0;
-  BigParams P;
+  if (njobs < 1 || njobs > 4) return 0;
+  BigGeom g[4];
   for (int j = 0; j < njobs; ++j) {
     const UssegConvJob& q = jobs[j];
     const UssegConvDesc& d = q.desc;
     const int out_f32 = (d.flags & USSEG_OUT_F32) ? 1 : 0, acc = (d.flags & USSEG_ACCUMULATE) ? 1 : 0;
-    int ok = flip ? big_fill_job(P.job[j], (const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, nullptr, (const bf16_t*)q.residual, d.B, d.H, d.W,
-                                 d.dilation, d.Cout, d.ldy, d.Cin, d.ldx, q.ldr, roundup(d.Cin, 16), 9 * d.Cout, USSEG_ACT_NONE, 0.f, 0, acc, 1)
-                  : big_fill_job(P.job[j], (const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, q.bias, (const bf16_t*)q.residual, d.B, d.H, d.W,
-                                 d.dilation, d.Cin, d.ldx, d.Cout, d.ldy, q.ldr, roundup(d.Cout, 16), 9 * d.Cin, d.act, d.alpha, out_f32, acc, 0);
-    if (!ok) return 0;
+    if (flip)
+      g[j] = {(const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, nullptr, (const bf16_t*)q.residual, d.B, d.H, d.W, d.dilation, d.Cout, d.ldy,
+              d.Cin, d.ldx, q.ldr, roundup(d.Cin, 16), 9 * d.Cout, USSEG_ACT_NONE, 0.f, 0, acc, 1};
+    else
+      g[j] = {(const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, q.bias, (const bf16_t*)q.residual, d.B, d.H, d.W, d.dilation, d.Cin, d.ldx,
+              d.Cout, d.ldy, q.ldr, roundup(d.Cout, 16), 9 * d.Cin, d.act, d.alpha, out_f32, acc, 0};
   }
-  if (big_workgroups(P, njobs) < min_wg) return 0;
-  return big_launch(P, njobs, s);
+  return big_plan_and_launch(g, njobs, s);
 }

@@ -32,7 +32,7 @@ class _Workspace:
 
     @classmethod
     def get(cls, device, nfloats: int) -> torch.Tensor:
-        key = str(device)
+        key = ops._ws_key(device)
         buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nfloats:
             if torch.cuda.is_current_stream_capturing():
@@ -153,9 +153,10 @@ class Conv2D(nn.Module):
         """dy: gradient w.r.t. the conv output (before any fused activation).  Accumulates kernel/bias grads.
         ``skip_bias``: the bias gradient was already produced by the following norm layer's backward (its ``dbias``)."""
         x = self._x
-        self._wgrad(x, dy)
-        if not skip_bias:
-            ops.colsum(dy, self.bias.grad, self.cout)
+        with ops.side_stream(x, dy):          # parameter gradients: beside the backward-data chain
+            self._wgrad(x, dy)
+            if not skip_bias:
+                ops.colsum(dy, self.bias.grad, self.cout)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)
@@ -202,12 +203,13 @@ class Conv2DTranspose(Conv2D):
     def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False):
         x = self._x
         T = self.k * self.k
-        scratch = _Workspace.get(dy.device, T * self.cin_p * self.cout_p)
-        ops.fill_f32(scratch, 0.0)
-        ops.tconv2d_wgrad(x, dy, self.k, scratch)
-        sT, sI, sO = self._strides_tio()
-        ops.unpack_wgrad(scratch, self.cin_p, self.cout_p, T, self.cout, self.cin, 0, 0, self.kernel.grad, sT, sO, sI)
-        ops.colsum(dy, self.bias.grad, self.cout)
+        with ops.side_stream(x, dy):
+            scratch = _Workspace.get(dy.device, T * self.cin_p * self.cout_p)
+            ops.fill_f32(scratch, 0.0)
+            ops.tconv2d_wgrad(x, dy, self.k, scratch)
+            sT, sI, sO = self._strides_tio()
+            ops.unpack_wgrad(scratch, self.cin_p, self.cout_p, T, self.cout, self.cin, 0, 0, self.kernel.grad, sT, sO, sI)
+            ops.colsum(dy, self.bias.grad, self.cout)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)

@@ -8,7 +8,9 @@ Activation tensors are bf16 ``[B,H,W,Cphys]`` (NHWC) or channel-slice views of s
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -37,8 +39,65 @@ _WGRAD_WS = {}
 WGRAD_WS_FLOATS = 64 << 20   # 256 MB of the 288 GB: split-K partial slabs of the 3x3 weight-gradient kernel
 
 
+# ------------------------------------------------------------------------------------------------ side stream
+# Weight gradients never feed the backward-data chain, so inside an ``overlap_region`` (the model's backward pass) they
+# are enqueued on a second HIP stream and run beside the dgrad / norm-backward kernels of the main stream (which leave
+# most CUs under-occupied at batch 16).  Both streams are captured into the same HIP graph (fork by event, join at the
+# end of the region).  Workspaces are per stream; the tensors a side launch reads are kept alive until the join so the
+# caching allocator cannot hand their memory to a later main-stream tensor.
+class _Side:
+    enabled = os.environ.get("USSEG_SIDE_STREAM", "1") != "0"
+    depth = 0
+    stream = None
+    keep = []
+    dirty = False
+
+
+@contextlib.contextmanager
+def overlap_region():
+    _Side.depth += 1
+    try:
+        yield
+    finally:
+        _Side.depth -= 1
+        if _Side.depth == 0:
+            side_join()
+
+
+@contextlib.contextmanager
+def side_stream(*keep):
+    """Enqueue the enclosed launches on the side stream, ordered after everything already on the current stream."""
+    if not (_Side.enabled and _Side.depth > 0):
+        yield
+        return
+    if _Side.stream is None:
+        _Side.stream = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    _Side.stream.wait_event(ev)
+    _Side.keep.extend(keep)
+    _Side.dirty = True
+    with torch.cuda.stream(_Side.stream):
+        yield
+
+
+def side_join():
+    if _Side.dirty:
+        ev = torch.cuda.Event()
+        ev.record(_Side.stream)
+        torch.cuda.current_stream().wait_event(ev)
+        _Side.dirty = False
+    _Side.keep.clear()
+
+
+def _ws_key(device):
+    on_side = _Side.stream is not None and torch.cuda.current_stream() == _Side.stream
+    return (str(device), on_side)
+
+
 def wgrad_ws(device) -> torch.Tensor:
-    key = str(device)
+    key = _ws_key(device)
     ws = _WGRAD_WS.get(key)
     if ws is None:
         ws = torch.empty(WGRAD_WS_FLOATS, dtype=torch.float32, device=device)
@@ -48,8 +107,8 @@ def wgrad_ws(device) -> torch.Tensor:
 
 
 def reduce_ws(device) -> torch.Tensor:
-    """fp32 workspace for the library's two-pass per-channel reductions (one per device; stream order serialises its users)."""
-    key = str(device)
+    """fp32 workspace for the library's two-pass per-channel reductions (one per device and stream; stream order serialises its users)."""
+    key = _ws_key(device)
     ws = _REDUCE_WS.get(key)
     if ws is None:
         ws = torch.empty(int(L.load().usseg_reduce_ws_floats()), dtype=torch.float32, device=device)
