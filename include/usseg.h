@@ -143,7 +143,8 @@ typedef struct UssegNormDesc {
   float alpha;
 } UssegNormDesc;
 /* mask (may be NULL): bf16 tensor [M][ldm] multiplied into the ACTIVATED output (dropout: 0 or 1/keep; since the mask is
- * non-negative relu(bn(x)*mask) == relu(bn(x))*mask, TBI_ResNest.py:213-218); the backward applies it to dy. */
+ * non-negative relu(bn(x)*mask) == relu(bn(x))*mask, TBI_ResNest.py:213-218); the backward applies it to dy.
+ * gamma / beta / mean / var: fp32, 16-byte aligned, readable up to Cphys floats (only the first C are used). */
 int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const float* gamma, const float* beta,
                        const float* mean, const float* var, const void* mask, int32_t ldm, void* y, usseg_stream_t stream);
 /* tf.nn.dropout mask (TBI_ResNest.py:216): mask = keep ? 1/(1-rate) : 0 from a counter-based hash of (seed, index). */

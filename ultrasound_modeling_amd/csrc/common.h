@@ -64,7 +64,7 @@ int usseg_check_launch(const char* what);
 int usseg_prof_start(int kind, hipStream_t s);
 void usseg_prof_stop(int kind, int slot, hipStream_t s);
 
-#define USSEG_REDUCE_MAX_BLOCKS 512
+#define USSEG_REDUCE_MAX_BLOCKS 1024
 // adds the per-workgroup partial rows written by a reduction kernel to up to three destinations (pointwise.hip)
 void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0, float* d1, float* d2,
                                 hipStream_t s);

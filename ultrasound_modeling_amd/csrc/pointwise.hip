@@ -59,7 +59,15 @@ __global__ __launch_bounds__(256) void reduce_finish_kernel(const float* ws, int
       c = i % C;
       k = (i / C) % K;
       g = i / (C * K);
-      for (int j = sl; j < nb; j += 16) s += ws[((int64_t)(g * nb + j) * K + k) * Cp + c];
+      const float* src = ws + ((int64_t)g * nb * K + k) * Cp + c;
+      const int64_t rs = (int64_t)K * Cp;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;    // four independent chains: the loads of a slice are in flight together
+      int j = sl;
+      for (; j + 48 < nb; j += 64) {
+        s += src[j * rs]; s1 += src[(j + 16) * rs]; s2 += src[(j + 32) * rs]; s3 += src[(j + 48) * rs];
+      }
+      for (; j < nb; j += 16) s += src[j * rs];
+      s += s1 + s2 + s3;
     }
     s_part[sl][o] = s;
     __syncthreads();
@@ -96,7 +104,7 @@ struct NormParams {
   float eps, alpha;
 };
 
-template <bool BWD>
+template <bool BWD, int MODE>   // MODE 0: per-pixel (grouped) LayerNormalization; 1: per-channel affine with given statistics
 __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int LPP = p.LPP, ppw = 64 / LPP;
@@ -104,21 +112,32 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
   const int CH = p.Cphys >> 3;
   const bool chunk_ok = chunk < CH;
   const int c0 = chunk * 8;
-  // per-lane channel constants
+  // per-lane channel constants: unconditional 16-byte loads, masked afterwards (a load under a per-element condition
+  // compiles to a branch + wait per element: 32 dependent L2 round trips, ~10 us before the first pixel)
   float ga[8], be[8], mu_c[8], rs_c[8];
   int grp[8];
+  {
+    const int cl = chunk_ok ? c0 : 0;
+    float gv[8], bv[8], mv[8], vv[8];
+    *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(p.gamma + cl);
+    *reinterpret_cast<float4*>(gv + 4) = *reinterpret_cast<const float4*>(p.gamma + cl + 4);
+    *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(p.beta + cl);
+    *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(p.beta + cl + 4);
+    if (MODE == 1) {
+      *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(p.mean + cl);
+      *reinterpret_cast<float4*>(mv + 4) = *reinterpret_cast<const float4*>(p.mean + cl + 4);
+      *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(p.var + cl);
+      *reinterpret_cast<float4*>(vv + 4) = *reinterpret_cast<const float4*>(p.var + cl + 4);
+    }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int c = c0 + j;
-    bool ok = chunk_ok && c < p.C;
-    ga[j] = ok ? p.gamma[c] : 0.f;
-    be[j] = ok ? p.beta[c] : 0.f;
-    grp[j] = ok ? c / p.Cg : -1;
-    if (p.mode == 1) {
-      mu_c[j] = ok ? p.mean[c] : 0.f;
-      rs_c[j] = ok ? rsqrtf(p.var[c] + p.eps) : 0.f;
-    } else {
-      mu_c[j] = 0.f; rs_c[j] = 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      const bool ok = chunk_ok && c < p.C;
+      ga[j] = ok ? gv[j] : 0.f;
+      be[j] = ok ? bv[j] : 0.f;
+      grp[j] = ok ? c / p.Cg : -1;
+      mu_c[j] = (MODE == 1 && ok) ? mv[j] : 0.f;
+      rs_c[j] = (MODE == 1 && ok) ? rsqrtf(vv[j] + p.eps) : 0.f;
     }
   }
   __shared__ float s_red[BWD ? 4 * 512 : 1];
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
     }
     float xh[8];  // normalised value
     float rstd_g[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.mode == 0) {
+    if (MODE == 0) {
       float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 8; ++j)
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
         dxh[j] = dh * ga[j];
       }
       float o[8];
-      if (p.mode == 0) {
+      if (MODE == 0) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -280,12 +299,15 @@ extern "C" int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const f
   int rc = norm_common(d, p);
   if (rc) return rc;
   USSEG_CHECK_ARG(x && y && gamma && beta && (d->mode == 0 || (mean && var)), "norm fwd: null pointer");
+  USSEG_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0,
+                  "norm: gamma/beta/mean/var must be 16-byte aligned (and readable up to Cphys floats)");
   p.x = (const bf16_t*)x; p.y = (bf16_t*)y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
   p.mask = (const bf16_t*)mask; p.ldm = ldm;
   p.ldx = d->ldx; p.ldy = d->ldy;
   if (p.M <= 0) return USSEG_OK;
   int ppb = 4 * (64 / p.LPP);
-  hipLaunchKernelGGL(norm_act_kernel<false>, dim3(grid_for(p.M, ppb * 4)), dim3(256), 0, (hipStream_t)stream, p);
+  if (p.mode == 0) hipLaunchKernelGGL((norm_act_kernel<false, 0>), dim3(grid_for(p.M, ppb * 4)), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((norm_act_kernel<false, 1>), dim3(grid_for(p.M, ppb * 4)), dim3(256), 0, (hipStream_t)stream, p);
   return usseg_check_launch("norm_act_fwd");
 }
 
@@ -296,6 +318,8 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   int rc = norm_common(d, p);
   if (rc) return rc;
   USSEG_CHECK_ARG(x && dy && dx && gamma && beta && dgamma && dbeta && ws && (d->mode == 0 || (mean && var)), "norm bwd: null pointer");
+  USSEG_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0,
+                  "norm: gamma/beta/mean/var must be 16-byte aligned (and readable up to Cphys floats)");
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
   p.mask = (const bf16_t*)mask; p.ldm = ldm;
   p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias; p.ws = ws;
@@ -304,7 +328,8 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   int ppb = 4 * (64 / p.LPP);
   // small tensors are latency bound (each loop trip is a dependent load -> store): spread them over many workgroups
   unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
-  hipLaunchKernelGGL(norm_act_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  if (p.mode == 0) hipLaunchKernelGGL((norm_act_kernel<true, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((norm_act_kernel<true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
   return usseg_check_launch("norm_act_bwd");
 }
