@@ -80,6 +80,25 @@ int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp_dg
 int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw_scratch, float* ws,
                        int64_t ws_floats, usseg_stream_t stream);
 
+/* Weight gradient written straight into the framework's variables: up to 4 rectangular blocks of the physical
+ * [ntaps][Cin_phys][Cout_phys] gradient go to strided destinations (Keras kernel [k,k,Cin,Cout] / [k,k,Cout,Cin] with the
+ * LOGICAL channel counts; one block per cardinal path for the block-diagonal grouped convs, ResNest.py:91-96).  Elements
+ * outside every block (channel padding, off-diagonal blocks) are dropped.  dst[t*sT + i*sI + o*sO] += dW[t][i_off+i][o_off+o]. */
+typedef struct UssegWgradBlock {
+  float* dst;
+  int64_t sT, sI, sO;          /* element strides of the destination per tap / input channel / output channel */
+  int32_t i_off, o_off, ni, no; /* the block: input channels [i_off, i_off+ni), output channels [o_off, o_off+no) */
+} UssegWgradBlock;
+typedef struct UssegWgradDst {
+  int32_t nblocks;             /* 1..4 */
+  int32_t reserved;
+  UssegWgradBlock blk[4];
+} UssegWgradDst;
+int usseg_conv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, const void* dy, const UssegWgradDst* dst, float* ws,
+                              int64_t ws_floats, usseg_stream_t stream);
+int usseg_tconv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, const void* dy, const UssegWgradDst* dst, float* ws,
+                               int64_t ws_floats, usseg_stream_t stream);
+
 /* Several independent 3x3 convolutions in ONE launch: the DecoderBlock's parallel dilation branches
  * (Decoder.py:14-25,39-50: the conv2_x / conv3_x / conv4_x layers read the same input and write disjoint channel slices of the
  * concatenated output, Decoder.py:67-75,79-87).  Semantics = usseg_conv2d_fwd / usseg_conv2d_dgrad called once per job

@@ -167,6 +167,17 @@ class _CardinalGroup:
         jobs = self.pack_jobs()
         ops.pack_weights_batched(ops.make_pack_table(jobs, self.w1_f.device), len(jobs))
 
+    def _maps(self):
+        """Destination maps of the two grouped weight gradients: one block per cardinal path (Keras [k,k,in,out] variables)."""
+        key = self.cards[0].conv1.kernel.grad.data_ptr()
+        if getattr(self, "_wmaps_key", None) != key:
+            sT = self.cv11 * self.cvkk
+            m1 = ops.wgrad_dst([(c.conv1.kernel.grad, 0, self.cv11, 1, 0, p * self.cv11, self.cin, self.cv11) for p, c in enumerate(self.cards)])
+            m2 = ops.wgrad_dst([(c.conv2.kernel.grad, sT, self.cvkk, 1, p * self.cv11, p * self.cvkk, self.cv11, self.cvkk)
+                                for p, c in enumerate(self.cards)])
+            self._wmaps, self._wmaps_key = (m1, m2), key
+        return self._wmaps
+
     def _sa_desc(self, B, HW):
         use_sigmoid = self.radix == 1   # ResNest.py:189-190
         return ops.splitattn_desc(B, HW, self.P, 1, self.cvkk, self.hid, self.Vp, self.Vp, self.Vp, self.Vp, float(self.radix), 0,
@@ -199,23 +210,14 @@ class _CardinalGroup:
         dv = ops.norm_act_bwd(v_raw, dy, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, 0, self.P,
                               KERAS_LN_EPS, ACT_LRELU, a, dbias=self.db2)
         # grouped 3x3: dense wgrad into scratch, keep the diagonal blocks
+        # grouped 3x3: the dense [T][Up][Vp] gradient is never materialised - only the diagonal blocks are scattered
         with ops.side_stream(u, dv):
-            scratch = _Workspace.get(dev, T * self.Up * self.Vp)
-            ops.fill_f32(scratch, 0.0)
-            ops.conv2d_wgrad(u, dv, self.k, self.dil, scratch)
-            sT = self.cv11 * self.cvkk
-            for p, c in enumerate(self.cards):
-                ops.unpack_wgrad(scratch, self.Up, self.Vp, T, self.cvkk, self.cv11, p * self.cvkk, p * self.cv11, c.conv2.kernel.grad,
-                                 sT, 1, self.cvkk)
+            ops.conv2d_wgrad_mapped(u, dv, self.k, self.dil, self._maps()[1])
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, self.dil, torch.empty_like(u))
         du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, 0, self.P,
                                   KERAS_LN_EPS, ACT_LRELU, a, dbias=self.db1)
         with ops.side_stream(x, du_raw):
-            scratch = _Workspace.get(dev, self.cin_p * self.Up)
-            ops.fill_f32(scratch, 0.0)
-            ops.conv2d_wgrad(x, du_raw, 1, 1, scratch)
-            for p, c in enumerate(self.cards):
-                ops.unpack_wgrad(scratch, self.cin_p, self.Up, 1, self.cv11, self.cin, p * self.cv11, 0, c.conv1.kernel.grad, 0, 1, self.cv11)
+            ops.conv2d_wgrad_mapped(x, du_raw, 1, 1, self._maps()[0])
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
 
 

@@ -31,6 +31,14 @@ class ConvJob(C.Structure):
                 ("reserved", c_i32), ("y", c_vp)]
 
 
+class WgradBlock(C.Structure):
+    _fields_ = [("dst", c_vp), ("sT", c_i64), ("sI", c_i64), ("sO", c_i64), ("i_off", c_i32), ("o_off", c_i32), ("ni", c_i32), ("no", c_i32)]
+
+
+class WgradDst(C.Structure):
+    _fields_ = [("nblocks", c_i32), ("reserved", c_i32), ("blk", WgradBlock * 4)]
+
+
 class NormDesc(C.Structure):
     _fields_ = [("M", c_i64), ("C", c_i32), ("Cphys", c_i32), ("ldx", c_i32), ("ldy", c_i32), ("G", c_i32),
                 ("mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32)]
@@ -71,6 +79,8 @@ _PROTOS = {
     "usseg_conv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_conv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "usseg_conv2d_wgrad_mapped": (C.c_int, [P(ConvDesc), c_vp, c_vp, P(WgradDst), c_vp, c_i64, c_vp]),
+    "usseg_tconv2d_wgrad_mapped": (C.c_int, [P(ConvDesc), c_vp, c_vp, P(WgradDst), c_vp, c_i64, c_vp]),
     "usseg_conv2d_fwd_multi": (C.c_int, [c_i32, c_vp, c_vp]),
     "usseg_conv2d_dgrad_multi": (C.c_int, [c_i32, c_vp, c_vp]),
     "usseg_tconv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -321,8 +321,11 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const bf16_t* in, const f
       if (R == 1) {
         float v[8];
         unpack8(*reinterpret_cast<const uint4*>(in + pix * ldi + c0), v);
+        float sv[8];   // unconditional loads at clamped indices (a load under a per-element condition serialises: one L2 round trip each)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Co) ? mult * v[j] * s[(int64_t)b * Cy + c0 + j] : 0.f;
+        for (int j = 0; j < 8; ++j) sv[j] = s[(int64_t)b * Cy + min(c0 + j, Co - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Co) ? mult * v[j] * sv[j] : 0.f;
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -342,9 +345,15 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const bf16_t* in, const f
       if (R == 1) {
         float v[8];
         unpack8(*reinterpret_cast<const uint4*>(in + pix * ldi + c0), v);
+        float sv[8], dv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          o[j] = (c0 + j < Cy) ? mult * v[j] * s[(int64_t)b * Cy + c0 + j] + dg[(int64_t)b * Cy + c0 + j] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const int64_t ix = (int64_t)b * Cy + min(c0 + j, Cy - 1);
+          sv[j] = s[ix];
+          dv[j] = dg[ix];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Cy) ? mult * v[j] * sv[j] + dv[j] : 0.f;
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -485,10 +494,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, f
   float s = 0.f;
   int64_t n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(g);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (; i + 3 * stride < n4; i += 4 * stride) {   // four loads in flight per thread
+    float4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
+    s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+    s3 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+  }
+  for (; i < n4; i += stride) {
     float4 v = g4[i];
     s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
+  s += s1 + s2 + s3;
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
   for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -499,7 +519,7 @@ extern "C" int usseg_sumsq(const float* g, int64_t n, float* out, usseg_stream_t
   USSEG_CHECK_ARG(g && out && n >= 0 && ((uintptr_t)g % 16) == 0, "sumsq: bad args (g must be 16-byte aligned)");
   if (n == 0) return USSEG_OK;
   int64_t grid = cdiv64(n, 256 * 16);
-  if (grid > 1024) grid = 1024;
+  if (grid > 256) grid = 256;          // one same-address atomic per workgroup at the end: keep them few
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
   return usseg_check_launch("sumsq");
 }

@@ -51,6 +51,35 @@ __device__ __forceinline__ float act_grad(float v, int act, float alpha) {
   }
 }
 
+// destination map of a weight gradient (UssegWgradDst by value in the kernel parameters); nblocks == 0: identity
+struct WgMap {
+  int32_t nblocks, pad;
+  UssegWgradBlock blk[4];
+};
+__device__ __forceinline__ float* wg_map_dst(const WgMap& m, float* ident, int64_t ident_idx, int t, int mi, int n) {
+  if (m.nblocks == 0) return ident + ident_idx;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (b < m.nblocks) {
+      const UssegWgradBlock& k = m.blk[b];
+      if ((unsigned)(mi - k.i_off) < (unsigned)k.ni && (unsigned)(n - k.o_off) < (unsigned)k.no)
+        return k.dst + t * k.sT + (mi - k.i_off) * k.sI + (n - k.o_off) * k.sO;
+    }
+  }
+  return nullptr;
+}
+static inline int wg_map_fill(WgMap& m, const UssegWgradDst* d) {
+  m = {};
+  if (!d) return 1;
+  if (d->nblocks < 1 || d->nblocks > 4) return 0;
+  m.nblocks = d->nblocks;
+  for (int b = 0; b < d->nblocks; ++b) {
+    if (!d->blk[b].dst) return 0;
+    m.blk[b] = d->blk[b];
+  }
+  return 1;
+}
+
 void usseg_set_error(const char* fmt, ...);
 #define USSEG_CHECK_ARG(cond, ...)                 \
   do {                                             \
@@ -83,8 +112,11 @@ int usseg_try_launch_conv_halo_multi(int njobs, const UssegConvJob* jobs, int fl
 int usseg_try_launch_conv_big_multi(int njobs, const UssegConvJob* jobs, int flip, hipStream_t s);
 
 // 3x3 weight gradient with an LDS halo tile (wgrad_halo.hip): 1 if it took the launch, 0 otherwise
-int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, int B, int H, int W, int d, int Ma, int Nb, int ldx, int lddy,
-                                float* ws, int64_t ws_floats, hipStream_t s);
+int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, const WgMap& map, int B, int H, int W, int d, int Ma, int Nb,
+                                int ldx, int lddy, float* ws, int64_t ws_floats, hipStream_t s);
+
+// out (identity or mapped) += sum over the split slabs ws[split][slab_floats] (wgrad_halo.hip)
+void usseg_launch_wgrad_finish(const float* ws, int splits, int64_t slab_floats, float* out, const WgMap& map, int Ma, int Nb, hipStream_t s);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

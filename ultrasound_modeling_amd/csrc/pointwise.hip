@@ -615,19 +615,22 @@ extern "C" int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t N
 // ---- all operand packs of a model in ONE launch: blockIdx.y = job ---------------------------------------------
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const UssegPackJob* jobs) {
   const UssegPackJob j = jobs[blockIdx.y];
-  const int64_t total = (int64_t)j.T * j.Nn * j.Kk;
+  const int total = j.T * j.Nn * j.Kk;          // < 2^31 (checked on the host side of every caller: one conv kernel)
+  if ((int)blockIdx.x * 256 >= total) return;    // the grid is sized for the largest job
   bf16_t* dst = reinterpret_cast<bf16_t*>(j.dst);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    int k = (int)(i % j.Kk);
-    int64_t r = i / j.Kk;
-    int n = (int)(r % j.Nn);
-    int t = (int)(r / j.Nn);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int k = i % j.Kk;
+    int r = i / j.Kk;
+    int n = r % j.Nn;
+    int t = r / j.Nn;
     dst[(int64_t)(j.n_off + n) * j.Kw + (int64_t)t * j.tap_stride + j.k_off + k] = f2bf(j.src[t * j.sT + n * j.sN + k * j.sK]);
   }
 }
 extern "C" int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t njobs, usseg_stream_t stream) {
   USSEG_CHECK_ARG(jobs_dev && njobs > 0 && njobs < 65536, "pack_weights_batched: bad args");
-  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  // 512 x njobs workgroups; a workgroup whose first 256-element slice lies past its job's end exits at once, the others
+  // stride over the job (the largest Arch B operand, 3x3x512x256, is 1.2 M elements = 9 trips)
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(512, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return usseg_check_launch("pack_weights_batched");
 }
 

@@ -23,6 +23,9 @@ struct WgradParams {
   // batched form (attention): blockIdx.z = b1*nb2 + b2 instead of the tap; operand bases + b1*s1 + b2*s2 (elements)
   int32_t nb2;
   int64_t as1, as2, bs1, bs2, os1, os2;
+  WgMap map;   // where the result goes (identity: out[t][m][n])
+  float* ws;   // partial slabs [split][ntaps][Ma][Nb] (plain stores, summed + scattered by wgrad_finish_kernel) or NULL (atomics)
+  int32_t ntaps;
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   // D[row = m_local = 4*(lane>>4)+j][col = n_local = lane&15]
   float* out = p.out + (int64_t)t * p.Ma * p.Nb + bz1 * p.os1 + bz2 * p.os2;
+  float* slab = p.ws ? p.ws + ((int64_t)blockIdx.x * p.ntaps + t) * p.Ma * p.Nb : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -122,37 +126,61 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int m = m0 + wm * 32 + i * 16 + g * 4 + r;
-        if (m < p.Ma) atomicAdd(out + (int64_t)m * p.Nb + n, acc[i][j][r]);
+        if (m >= p.Ma) continue;
+        if (slab) slab[(int64_t)m * p.Nb + n] = acc[i][j][r];
+        else {
+          float* q = wg_map_dst(p.map, out, (int64_t)m * p.Nb + n, t, m, n);
+          if (q) atomicAdd(q, acc[i][j][r]);
+        }
       }
     }
 }
 
-static int launch_wgrad(WgradParams& p, int ntaps, hipStream_t s) {
+static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats, hipStream_t s) {
   p.mtiles = (p.Ma + 63) / 64;
   p.ntiles = (p.Nb + 63) / 64;
+  p.ntaps = ntaps;
   int64_t tiles = (int64_t)p.mtiles * p.ntiles * ntaps;
   // enough splits to give every CU a few workgroups, but at least 256 pixels of work per split
   int64_t want = (2048 + tiles - 1) / tiles;
   int64_t max_splits = cdiv64(p.M, 256);
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
+  // With a workspace every split stores its partial [ntaps][Ma][Nb] slab and wgrad_finish_kernel sums (and scatters)
+  // them: fp32 atomics from ~1000 workgroups into the few cache lines of a small gradient serialise at the L2 (the
+  // 32x16 cardinal conv1 gradient took 35-120 us that way).  Slab traffic is kept within ~8x the operand bytes.
+  const int64_t slab = (int64_t)ntaps * p.Ma * p.Nb;
+  p.ws = nullptr;
+  if (ws && want > 1) {
+    const int64_t in_bytes = p.M * (p.Ma + p.Nb) * 2;
+    int64_t cap = 8 * in_bytes / (slab * 4);
+    if (cap < 4) cap = 4;
+    if (cap > ws_floats / slab) cap = ws_floats / slab;
+    if (want > cap) want = cap;
+    if (want > 1) p.ws = ws;
+  }
+  if (want < 1) want = 1;
   p.chunk = cdiv64(cdiv64(p.M, want), 32) * 32;
   int64_t splits = cdiv64(p.M, p.chunk);
   const int slot = usseg_prof_start(2, s);
   hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)splits, (unsigned)(p.mtiles * p.ntiles), (unsigned)ntaps), dim3(256), 0, s, p);
+  if (p.ws) usseg_launch_wgrad_finish(p.ws, (int)splits, slab, p.out, p.map, p.Ma, p.Nb, s);
   usseg_prof_stop(2, slot, s);
   return usseg_check_launch("wgrad");
 }
 
-extern "C" int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw, float* ws, int64_t ws_floats,
-                                  usseg_stream_t stream) {
-  USSEG_CHECK_ARG(d && x && dy && dw, "null pointer");
+static int conv2d_wgrad_impl(const UssegConvDesc* d, const void* x, const void* dy, float* dw, const UssegWgradDst* dst, float* ws,
+                             int64_t ws_floats, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && x && dy && (dw || dst), "null pointer");
+  WgMap map;
+  USSEG_CHECK_ARG(wg_map_fill(map, dst), "wgrad: bad destination map (1..4 blocks, non-null dst)");
   USSEG_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "channels must be multiples of 8");
   USSEG_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "conv ksize must be 1 or 3");
-  if (d->ksize == 3 && usseg_try_launch_wgrad_halo((const bf16_t*)x, (const bf16_t*)dy, dw, d->B, d->H, d->W, d->dilation, d->Cin, d->Cout,
-                                                   d->ldx, d->ldy, ws, ws_floats, (hipStream_t)stream))
+  if (d->ksize == 3 && usseg_try_launch_wgrad_halo((const bf16_t*)x, (const bf16_t*)dy, dw, map, d->B, d->H, d->W, d->dilation, d->Cin,
+                                                   d->Cout, d->ldx, d->ldy, ws, ws_floats, (hipStream_t)stream))
     return usseg_check_launch("wgrad_halo");
   WgradParams p = {};
+  p.map = map;
   p.a = (const bf16_t*)x; p.b = (const bf16_t*)dy; p.out = dw;
   p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
   p.Ha = d->H; p.Wa = d->W; p.lda = d->ldx; p.asy = p.asx = 1;
@@ -165,27 +193,72 @@ extern "C" int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const v
       p.ady[t] = (int16_t)((kh - half) * d->dilation); p.adx[t] = (int16_t)((kw - half) * d->dilation);
       p.bdy[t] = 0; p.bdx[t] = 0;
     }
-  return launch_wgrad(p, k * k, (hipStream_t)stream);
+  return launch_wgrad(p, k * k, ws, ws_floats, (hipStream_t)stream);
 }
 
-extern "C" int usseg_tconv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw, usseg_stream_t stream) {
-  USSEG_CHECK_ARG(d && x && dy && dw, "null pointer");
+extern "C" int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw, float* ws, int64_t ws_floats,
+                                  usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dw, "null pointer");
+  return conv2d_wgrad_impl(d, x, dy, dw, nullptr, ws, ws_floats, stream);
+}
+extern "C" int usseg_conv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, const void* dy, const UssegWgradDst* dst, float* ws,
+                                         int64_t ws_floats, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dst, "null destination map");
+  return conv2d_wgrad_impl(d, x, dy, nullptr, dst, ws, ws_floats, stream);
+}
+
+static int tconv2d_wgrad_impl(const UssegConvDesc* d, const void* x, const void* dy, float* dw, const UssegWgradDst* dst, float* ws,
+                              int64_t ws_floats, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && x && dy && (dw || dst), "null pointer");
+  WgMap map;
+  USSEG_CHECK_ARG(wg_map_fill(map, dst), "wgrad: bad destination map (1..4 blocks, non-null dst)");
   USSEG_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "channels must be multiples of 8");
   USSEG_CHECK_ARG(d->ksize == 3 || d->ksize == 4, "tconv ksize must be 3 or 4");
   const int k = d->ksize, pad = (k == 4) ? 1 : 0;
   WgradParams p = {};
-  p.a = (const bf16_t*)x; p.b = (const bf16_t*)dy; p.out = dw;
   p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
-  p.Ha = d->H; p.Wa = d->W; p.lda = d->ldx; p.asy = p.asx = 1;
-  p.Hb = 2 * d->H; p.Wb = 2 * d->W; p.ldb = d->ldy; p.bsy = p.bsx = 2;
-  p.Ma = d->Cin; p.Nb = d->Cout;
-  for (int kh = 0; kh < k; ++kh)
-    for (int kw = 0; kw < k; ++kw) {
-      int t = kh * k + kw;
-      p.ady[t] = 0; p.adx[t] = 0;
-      p.bdy[t] = (int16_t)(kh - pad); p.bdx[t] = (int16_t)(kw - pad);
+  if (!dst) {
+    p.a = (const bf16_t*)x; p.b = (const bf16_t*)dy; p.out = dw;
+    p.Ha = d->H; p.Wa = d->W; p.lda = d->ldx; p.asy = p.asx = 1;
+    p.Hb = 2 * d->H; p.Wb = 2 * d->W; p.ldb = d->ldy; p.bsy = p.bsx = 2;
+    p.Ma = d->Cin; p.Nb = d->Cout;
+    for (int kh = 0; kh < k; ++kh)
+      for (int kw = 0; kw < k; ++kw) {
+        int t = kh * k + kw;
+        p.ady[t] = 0; p.adx[t] = 0;
+        p.bdy[t] = (int16_t)(kh - pad); p.bdx[t] = (int16_t)(kw - pad);
+      }
+  } else {
+    // Mapped: the Keras variable is [k,k,Cout,Cin] (input channel fastest).  The kernel's lanes run along its n axis, so
+    // the operands swap roles (A = dy, B = x): atomics of one wave-instruction then land on consecutive addresses.
+    p.a = (const bf16_t*)dy; p.b = (const bf16_t*)x; p.out = nullptr;
+    p.Ha = 2 * d->H; p.Wa = 2 * d->W; p.lda = d->ldy; p.asy = p.asx = 2;
+    p.Hb = d->H; p.Wb = d->W; p.ldb = d->ldx; p.bsy = p.bsx = 1;
+    p.Ma = d->Cout; p.Nb = d->Cin;
+    for (int kh = 0; kh < k; ++kh)
+      for (int kw = 0; kw < k; ++kw) {
+        int t = kh * k + kw;
+        p.ady[t] = (int16_t)(kh - pad); p.adx[t] = (int16_t)(kw - pad);
+        p.bdy[t] = 0; p.bdx[t] = 0;
+      }
+    for (int b = 0; b < map.nblocks; ++b) {   // kernel axes (m, n) = (output channel, input channel)
+      UssegWgradBlock u = map.blk[b];
+      map.blk[b].sI = u.sO; map.blk[b].sO = u.sI;
+      map.blk[b].i_off = u.o_off; map.blk[b].o_off = u.i_off;
+      map.blk[b].ni = u.no; map.blk[b].no = u.ni;
     }
-  return launch_wgrad(p, k * k, (hipStream_t)stream);
+  }
+  p.map = map;
+  return launch_wgrad(p, k * k, ws, ws_floats, (hipStream_t)stream);
+}
+extern "C" int usseg_tconv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dw, "null pointer");
+  return tconv2d_wgrad_impl(d, x, dy, dw, nullptr, nullptr, 0, stream);
+}
+extern "C" int usseg_tconv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, const void* dy, const UssegWgradDst* dst, float* ws,
+                                          int64_t ws_floats, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dst, "null destination map");
+  return tconv2d_wgrad_impl(d, x, dy, nullptr, dst, ws, ws_floats, stream);
 }
 
 // ---- batched "TN" GEMM: OUT[b1,b2][m][n] += sum_r A[b1,b2][r][m] * B[b1,b2][r][n]  (contraction over ROWS of both operands,

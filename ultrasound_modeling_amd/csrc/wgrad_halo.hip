@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p
 // out[i] += sum_s ws[s][i]  (n floats per slab, n % 4 == 0)
 // Workgroup = 64 float4 outputs x 4 slab slices; blockIdx.y splits the slabs further when the output is small, and
 // those partial sums meet in `out` through a handful of atomics per element.
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* ws, int splits, int64_t n4, float* out) {
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* ws, int splits, int64_t n4, float* out, const WgMap map, int Ma,
+                                                            int Nb) {
   __shared__ float4 s_part[4][64];
   const float4* w4 = reinterpret_cast<const float4*>(ws);
   const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -208,17 +209,42 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* ws, int 
       float4 t = s_part[0][o];
 #pragma unroll
       for (int q = 1; q < 4; ++q) { t.x += s_part[q][o].x; t.y += s_part[q][o].y; t.z += s_part[q][o].z; t.w += s_part[q][o].w; }
-      float* d = out + i * 4;
-      if (gridDim.y == 1) { d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
-      else { atomicAdd(d, t.x); atomicAdd(d + 1, t.y); atomicAdd(d + 2, t.z); atomicAdd(d + 3, t.w); }
+      if (map.nblocks == 0) {
+        float* d = out + i * 4;
+        if (gridDim.y == 1) { d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
+        else { atomicAdd(d, t.x); atomicAdd(d + 1, t.y); atomicAdd(d + 2, t.z); atomicAdd(d + 3, t.w); }
+      } else {   // scatter into the framework's variables (logical channels, Keras strides); the four elements share (tap, ci)
+        const int64_t e = i * 4;
+        const int tap = (int)(e / ((int64_t)Ma * Nb));
+        const int rem = (int)(e - (int64_t)tap * Ma * Nb);
+        const int mi = rem / Nb, n = rem - mi * Nb;
+        const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float* d = wg_map_dst(map, nullptr, 0, tap, mi, n + q);
+          if (d) {
+            if (gridDim.y == 1) *d += v[q];
+            else atomicAdd(d, v[q]);
+          }
+        }
+      }
     }
     __syncthreads();
   }
 }
 
+void usseg_launch_wgrad_finish(const float* ws, int splits, int64_t slab_floats, float* out, const WgMap& map, int Ma, int Nb, hipStream_t s) {
+  int64_t n4 = slab_floats / 4;
+  int gx = (int)((n4 + 63) / 64);
+  if (gx > 2048) gx = 2048;
+  int gy = 1;  // small outputs: also split the slab axis so a few hundred workgroups share the walk
+  while (gx * gy < 256 && splits / (gy * 2) >= 8) gy *= 2;
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(gx, gy), dim3(256), 0, s, ws, splits, n4, out, map, Ma, Nb);
+}
+
 // Returns 1 and launches if the geometry fits, 0 if the caller must use the per-tap kernel.
-int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, int B, int H, int W, int d, int Ma, int Nb, int ldx, int lddy,
-                                float* ws, int64_t ws_floats, hipStream_t s) {
+int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, const WgMap& map, int B, int H, int W, int d, int Ma, int Nb,
+                                int ldx, int lddy, float* ws, int64_t ws_floats, hipStream_t s) {
   static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
   if (disabled) return 0;
   if (d < 1 || H % d || W % d) return 0;
@@ -265,7 +291,9 @@ int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, i
   else if ((int64_t)max_splits * slab > ws_floats) max_splits = (int)(ws_floats / slab);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  p.ws = (ws && splits > 1 && (int64_t)splits * slab <= ws_floats) ? ws : nullptr;
+  // a mapped destination is scattered by the finishing kernel, so it always goes through a slab
+  p.ws = (ws && (splits > 1 || map.nblocks) && (int64_t)splits * slab <= ws_floats) ? ws : nullptr;
+  if (map.nblocks && !p.ws) return 0;
   p.groups_per_block = (p.ngroups + splits - 1) / splits;
   splits = (p.ngroups + p.groups_per_block - 1) / p.groups_per_block;
   const int slot = usseg_prof_start(2, s);
@@ -273,14 +301,7 @@ int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, i
   else if (shape == 2) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1>), dim3(splits, tiles), dim3(256), 0, s, p);
   else if (shape == 3) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
-  if (p.ws) {
-    int64_t n4 = slab / 4;
-    int gx = (int)((n4 + 63) / 64);
-    if (gx > 2048) gx = 2048;
-    int gy = 1;  // small outputs: also split the slab axis so a few hundred workgroups share the walk
-    while (gx * gy < 256 && splits / (gy * 2) >= 8) gy *= 2;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(gx, gy), dim3(256), 0, s, p.ws, splits, n4, out);
-  }
+  if (p.ws) usseg_launch_wgrad_finish(p.ws, splits, slab, out, map, Ma, Nb, s);
   usseg_prof_stop(2, slot, s);
   return 1;
 }

@@ -168,11 +168,15 @@ class Conv2D(nn.Module):
         if self.cin_p == self.cin and self.cout_p == self.cout:
             ops.conv2d_wgrad(x, dy, self.k, self.dil, self.kernel.grad)   # Keras layout == [T][Cin][Cout]: accumulate in place
             return
-        scratch = _Workspace.get(dy.device, T * self.cin_p * self.cout_p)
-        ops.fill_f32(scratch, 0.0)
-        ops.conv2d_wgrad(x, dy, self.k, self.dil, scratch)
-        sT, sI, sO = self._strides_tio()
-        ops.unpack_wgrad(scratch, self.cin_p, self.cout_p, T, self.cout, self.cin, 0, 0, self.kernel.grad, sT, sO, sI)
+        ops.conv2d_wgrad_mapped(x, dy, self.k, self.dil, self._wgrad_map())   # padded channels: scatter the logical block, no scratch
+
+    def _wgrad_map(self):
+        m = getattr(self, "_wmap", None)
+        if m is None or self._wmap_ptr != self.kernel.grad.data_ptr():
+            sT, sI, sO = self._strides_tio()
+            m = self._wmap = ops.wgrad_dst([(self.kernel.grad, sT, sI, sO, 0, 0, self.cin, self.cout)])
+            self._wmap_ptr = self.kernel.grad.data_ptr()
+        return m
 
 
 class Conv2DTranspose(Conv2D):
@@ -204,11 +208,7 @@ class Conv2DTranspose(Conv2D):
         x = self._x
         T = self.k * self.k
         with ops.side_stream(x, dy):
-            scratch = _Workspace.get(dy.device, T * self.cin_p * self.cout_p)
-            ops.fill_f32(scratch, 0.0)
-            ops.tconv2d_wgrad(x, dy, self.k, scratch)
-            sT, sI, sO = self._strides_tio()
-            ops.unpack_wgrad(scratch, self.cin_p, self.cout_p, T, self.cout, self.cin, 0, 0, self.kernel.grad, sT, sO, sI)
+            ops.tconv2d_wgrad_mapped(x, dy, self.k, self._wgrad_map())
             ops.colsum(dy, self.bias.grad, self.cout)
         if not need_dx:
             return None

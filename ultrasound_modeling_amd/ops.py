@@ -197,6 +197,36 @@ def conv2d_wgrad(x, dy, ksize, dilation, dw: torch.Tensor):
     return dw
 
 
+def wgrad_dst(blocks) -> "L.WgradDst":
+    """blocks: list of (dst tensor, sT, sI, sO, i_off, o_off, ni, no) -> destination map of a mapped weight gradient."""
+    m = L.WgradDst()
+    m.nblocks = len(blocks)
+    for b, (dst, sT, sI, sO, i_off, o_off, ni, no) in enumerate(blocks):
+        assert dst.dtype == torch.float32
+        m.blk[b].dst, m.blk[b].sT, m.blk[b].sI, m.blk[b].sO = dst.data_ptr(), sT, sI, sO
+        m.blk[b].i_off, m.blk[b].o_off, m.blk[b].ni, m.blk[b].no = i_off, o_off, ni, no
+    return m
+
+
+def conv2d_wgrad_mapped(x, dy, ksize, dilation, dst_map):
+    """dW (physical [ntaps][Cin_phys][Cout_phys]) accumulated straight into the variables named by ``dst_map`` (no scratch pass)."""
+    B, H, W, Cin, ldx = geom(x)
+    _, _, _, Cout, ldy = geom(dy)
+    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation)
+    ws = wgrad_ws(x.device)
+    L.check(L.load().usseg_conv2d_wgrad_mapped(C.byref(d), x.data_ptr(), dy.data_ptr(), C.byref(dst_map), ws.data_ptr(), ws.numel(),
+                                               _stream()), "conv2d_wgrad_mapped")
+
+
+def tconv2d_wgrad_mapped(x, dy, ksize, dst_map):
+    B, H, W, Cin, ldx = geom(x)
+    _, _, _, Cout, ldy = geom(dy)
+    d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, 1)
+    ws = wgrad_ws(x.device)
+    L.check(L.load().usseg_tconv2d_wgrad_mapped(C.byref(d), x.data_ptr(), dy.data_ptr(), C.byref(dst_map), ws.data_ptr(), ws.numel(),
+                                                _stream()), "tconv2d_wgrad_mapped")
+
+
 def tconv2d_fwd(x, wp, bias, ksize, out, act=ACT_NONE, alpha=0.0, out_f32=False):
     B, H, W, Cin, ldx = geom(x)
     Bo, Ho, Wo, Cout, ldy = geom(out)
