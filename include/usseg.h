@@ -99,6 +99,28 @@ int usseg_conv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, const void*
 int usseg_tconv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, const void* dy, const UssegWgradDst* dst, float* ws,
                                int64_t ws_floats, usseg_stream_t stream);
 
+/* Several independent 3x3 weight gradients of identical shape in one launch (the DecoderBlock's dilation branches): same
+ * semantics as usseg_conv2d_wgrad / usseg_conv2d_wgrad_mapped per job (dst NULL: accumulate into dw; dst set: dw ignored). */
+typedef struct UssegWgradJob {
+  UssegConvDesc desc;
+  const void* x;
+  const void* dy;
+  float* dw;
+  const UssegWgradDst* dst;
+} UssegWgradJob;
+int usseg_conv2d_wgrad_multi(int32_t njobs, const UssegWgradJob* jobs, float* ws, int64_t ws_floats, usseg_stream_t stream);
+
+/* Deferred finishing reductions.  Between usseg_defer_begin(stream, ...) and usseg_defer_end(stream) the small kernels
+ * that add per-workgroup partial sums into gradient variables (the tail of usseg_norm_act_bwd, usseg_colsum,
+ * usseg_conv2d_wgrad[_mapped], usseg_tconv2d_wgrad_mapped on that stream) are queued and run as a few batched launches at
+ * usseg_defer_flush / _end (or earlier when a workspace fills).  The gradients those calls produce are therefore complete only
+ * after the flush: flush before anything on the stream reads them (the optimiser; training-mode BatchNorm's backward fix).
+ * The two workspaces (fp32, caller-owned, must outlive the end call) replace the per-call ws arguments while deferring;
+ * either may be NULL to keep that family immediate.  One context per stream. */
+int usseg_defer_begin(usseg_stream_t stream, float* reduce_ws, int64_t reduce_floats, float* wgrad_ws, int64_t wgrad_floats);
+int usseg_defer_flush(usseg_stream_t stream);
+int usseg_defer_end(usseg_stream_t stream);
+
 /* Several independent 3x3 convolutions in ONE launch: the DecoderBlock's parallel dilation branches
  * (Decoder.py:14-25,39-50: the conv2_x / conv3_x / conv4_x layers read the same input and write disjoint channel slices of the
  * concatenated output, Decoder.py:67-75,79-87).  Semantics = usseg_conv2d_fwd / usseg_conv2d_dgrad called once per job

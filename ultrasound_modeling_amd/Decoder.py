@@ -93,6 +93,17 @@ class DecoderBlock(nn.Module):
             jobs.append((x, c.wp_f, c.bias.data, c.k, c.dil, raw[..., j * q:(j + 1) * q], ACT_NONE, 0.0))
         ops.conv2d_fwd_multi(jobs)
 
+    def _branches_bwd(self, st, draw, dx):
+        """Backward of the four parallel convs: the three dilated weight gradients as ONE multi-job launch on the side
+        stream (a third of the split-K slabs each), the backward-data passes accumulating into ``dx`` on the main stream."""
+        q = self.out_channels // 4
+        convs = [getattr(self, f"conv{st}_{j}") for j in range(4)]
+        dys = [draw[..., j * q:(j + 1) * q] for j in range(4)]
+        with ops.side_stream(convs[1]._x, draw):
+            ops.conv2d_wgrad_multi([convs[j].wgrad_job(dys[j]) for j in (1, 2, 3)])
+        for j in range(4):
+            convs[j].backward(dys[j], dx=dx, accumulate_dx=(j > 0), skip_bias=True, skip_wgrad=(j > 0))
+
     def forward(self, x, skip=None, out=None):
         """x [B,h,w,in]; skip [B,2h,2w,skip] or None; ``out``: optional [B,2h,2w,oc] slice to write the result into."""
         B, H, W, _, _ = ops.geom(x)
@@ -123,13 +134,11 @@ class DecoderBlock(nn.Module):
         raw1, raw2 = self._raw
         draw2 = self._bn_bwd("2", raw2, dout, ops.new_act(B, H2, W2, oc, dev))
         dact1 = ops.new_act(B, H2, W2, oc, dev)
-        for j in range(4):
-            getattr(self, f"conv2_{j}").backward(draw2[..., j * q:(j + 1) * q], dx=dact1, accumulate_dx=(j > 0), skip_bias=True)
+        self._branches_bwd("2", draw2, dact1)
         draw1 = self._bn_bwd("1", raw1, dact1, ops.new_act(B, H2, W2, oc, dev))
         c1 = oc + (self.skip_channels if self._has_skip else 0)
         dcat = ops.new_act(B, H2, W2, c1, dev)
-        for j in range(4):
-            getattr(self, f"conv1_{j}").backward(draw1[..., j * q:(j + 1) * q], dx=dcat, accumulate_dx=(j > 0), skip_bias=True)
+        self._branches_bwd("1", draw1, dcat)
         dx = self.up.backward(dcat[..., :oc])
         dskip = dcat[..., oc:] if self._has_skip else None
         return dx, dskip

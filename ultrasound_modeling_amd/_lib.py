@@ -39,6 +39,13 @@ class WgradDst(C.Structure):
     _fields_ = [("nblocks", c_i32), ("reserved", c_i32), ("blk", WgradBlock * 4)]
 
 
+P_WgradDst = C.POINTER(WgradDst)
+
+
+class WgradJob(C.Structure):
+    _fields_ = [("desc", ConvDesc), ("x", c_vp), ("dy", c_vp), ("dw", c_vp), ("dst", P_WgradDst)]
+
+
 class NormDesc(C.Structure):
     _fields_ = [("M", c_i64), ("C", c_i32), ("Cphys", c_i32), ("ldx", c_i32), ("ldy", c_i32), ("G", c_i32),
                 ("mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32)]
@@ -81,6 +88,7 @@ _PROTOS = {
     "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "usseg_conv2d_wgrad_mapped": (C.c_int, [P(ConvDesc), c_vp, c_vp, P(WgradDst), c_vp, c_i64, c_vp]),
     "usseg_tconv2d_wgrad_mapped": (C.c_int, [P(ConvDesc), c_vp, c_vp, P(WgradDst), c_vp, c_i64, c_vp]),
+    "usseg_conv2d_wgrad_multi": (C.c_int, [c_i32, c_vp, c_vp, c_i64, c_vp]),
     "usseg_conv2d_fwd_multi": (C.c_int, [c_i32, c_vp, c_vp]),
     "usseg_conv2d_dgrad_multi": (C.c_int, [c_i32, c_vp, c_vp]),
     "usseg_tconv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -126,6 +134,9 @@ _PROTOS = {
     "usseg_softmax_rows_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp]),
     "usseg_transpose_batched": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp]),
     "usseg_cast_f32_to_bf16_batched": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
+    "usseg_defer_begin": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64]),
+    "usseg_defer_flush": (C.c_int, [c_vp]),
+    "usseg_defer_end": (C.c_int, [c_vp]),
     "usseg_prof_enable": (C.c_int, [c_i32, c_i32]),
     "usseg_prof_read": (C.c_int, [c_i32, P(C.c_double), P(c_i64)]),
     "usseg_prof_disable": (C.c_int, []),

@@ -94,7 +94,7 @@ int usseg_prof_start(int kind, hipStream_t s);
 void usseg_prof_stop(int kind, int slot, hipStream_t s);
 
 #define USSEG_REDUCE_MAX_BLOCKS 1024
-// adds the per-workgroup partial rows written by a reduction kernel to up to three destinations (pointwise.hip)
+// adds the per-workgroup partial rows written by a reduction kernel to up to three destinations (defer.hip)
 void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0, float* d1, float* d2,
                                 hipStream_t s);
 
@@ -115,8 +115,13 @@ int usseg_try_launch_conv_big_multi(int njobs, const UssegConvJob* jobs, int fli
 int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, const WgMap& map, int B, int H, int W, int d, int Ma, int Nb,
                                 int ldx, int lddy, float* ws, int64_t ws_floats, hipStream_t s);
 
+// deferral of the finishing reductions (defer.hip): workspace regions for producers between usseg_defer_begin and _flush
+float* usseg_defer_reduce_ws(hipStream_t s, float* caller_ws, int64_t need);
+float* usseg_defer_wgrad_ws(hipStream_t s, float* caller_ws, int64_t caller_floats, int64_t* avail);
 // out (identity or mapped) += sum over the split slabs ws[split][slab_floats] (wgrad_halo.hip)
 void usseg_launch_wgrad_finish(const float* ws, int splits, int64_t slab_floats, float* out, const WgMap& map, int Ma, int Nb, hipStream_t s);
+
+int usseg_try_launch_wgrad_halo_multi(int njobs, const UssegWgradJob* jobs, float* ws, int64_t ws_floats, hipStream_t s);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

@@ -1,0 +1,262 @@
+// Finishing reductions of the two-pass (no-atomics) kernels, and their DEFERRED, batched form.
+//
+// Every norm backward / bias column sum / weight gradient ends in a small "sum the per-workgroup partial rows (or the
+// split-K slabs) into the variable's gradient" kernel.  Alone each is a 4-14 us launch (one dependent L2 round trip plus
+// launch overhead) and a training step has ~90 of them: 0.6 ms of a 6.2 ms step.  Their results are only read by the
+// optimiser, so between usseg_defer_begin() and usseg_defer_flush() on a stream the library queues them instead, hands
+// every producer its own region of the caller's workspace (bump allocation, so partials stay intact) and runs the whole
+// queue as a few batched launches (job table in the kernel arguments, blockIdx.y / .z = job).
+#include <vector>
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ per-channel partial rows
+// dst_k[g*C + c] += scale * sum_{j<nb} ws[((g*nb + j)*K + k)*Cp + c]   for k < K (dst_k may be NULL)
+struct RJob {
+  const float* ws;
+  float *d0, *d1, *d2;
+  int32_t groups, nb, K, Cp, C, nblocks;
+  float scale;
+  int32_t pad;
+};
+struct RBatch {
+  int32_t njobs, pad;
+  RJob job[48];
+};
+
+// workgroup = 16 outputs x 16 row slices: the nb partial rows of an output are summed by 16 threads in parallel
+// (a serial walk over 512 rows is a 512-deep chain of dependent loads: 45 us; this form is ~3 us)
+__device__ __forceinline__ void reduce_finish_body(const RJob& q, int bx, int nbx) {
+  __shared__ float s_part[16][17];
+  const int total = q.groups * q.K * q.C;
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (int base = bx * 16; base < total; base += nbx * 16) {
+    const int i = base + o;
+    float s = 0.f;
+    int c = 0, k = 0, g = 0;
+    if (i < total) {
+      c = i % q.C;
+      k = (i / q.C) % q.K;
+      g = i / (q.C * q.K);
+      const float* src = q.ws + ((int64_t)g * q.nb * q.K + k) * q.Cp + c;
+      const int64_t rs = (int64_t)q.K * q.Cp;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;    // four independent chains: the loads of a slice are in flight together
+      int j = sl;
+      for (; j + 48 < q.nb; j += 64) {
+        s += src[j * rs]; s1 += src[(j + 16) * rs]; s2 += src[(j + 32) * rs]; s3 += src[(j + 48) * rs];
+      }
+      for (; j < q.nb; j += 16) s += src[j * rs];
+      s += s1 + s2 + s3;
+    }
+    s_part[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += s_part[r][o];
+      float* dst = k == 0 ? q.d0 : (k == 1 ? q.d1 : q.d2);
+      if (dst) dst[g * q.C + c] += q.scale * t;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void reduce_finish_kernel(const RJob q) { reduce_finish_body(q, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void reduce_finish_batched_kernel(const RBatch b) {
+  const RJob& q = b.job[blockIdx.y];
+  if ((int)blockIdx.x >= q.nblocks) return;
+  reduce_finish_body(q, blockIdx.x, q.nblocks);
+}
+
+// ------------------------------------------------------------------------------------------ split-K slabs of a weight gradient
+// out (identity) or the mapped variables += sum_s ws[s][i]  (n floats per slab, n % 4 == 0)
+// Workgroup = 64 float4 outputs x 4 slab slices; gy splits the slabs further when the output is small, and those
+// partial sums meet in the destination through a handful of atomics per element.
+struct WJob {
+  const float* ws;
+  float* out;
+  int64_t n4;
+  int32_t splits, Ma, Nb, gx, gy, pad;
+  WgMap map;
+};
+struct WBatch {
+  int32_t njobs, pad;
+  WJob job[14];
+};
+
+__device__ __forceinline__ void wgrad_finish_body(const WJob& q, int bx, int by) {
+  __shared__ float4 s_part[4][64];
+  const float4* w4 = reinterpret_cast<const float4*>(q.ws);
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int per_y = (q.splits + q.gy - 1) / q.gy;
+  const int s0 = by * per_y;
+  int s1 = s0 + per_y;
+  if (s1 > q.splits) s1 = q.splits;
+  for (int64_t base = (int64_t)bx * 64; base < q.n4; base += (int64_t)q.gx * 64) {
+    const int64_t i = base + o;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < q.n4) {
+#pragma unroll 4
+      for (int s = s0 + sl; s < s1; s += 4) {
+        float4 v = w4[(int64_t)s * q.n4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    s_part[sl][o] = a;
+    __syncthreads();
+    if (sl == 0 && i < q.n4) {
+      float4 t = s_part[0][o];
+#pragma unroll
+      for (int r = 1; r < 4; ++r) { t.x += s_part[r][o].x; t.y += s_part[r][o].y; t.z += s_part[r][o].z; t.w += s_part[r][o].w; }
+      if (q.map.nblocks == 0) {
+        float* d = q.out + i * 4;
+        if (q.gy == 1) { d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
+        else { atomicAdd(d, t.x); atomicAdd(d + 1, t.y); atomicAdd(d + 2, t.z); atomicAdd(d + 3, t.w); }
+      } else {   // scatter into the framework's variables (logical channels, Keras strides); the four elements share (tap, ci)
+        const int64_t e = i * 4;
+        const int tap = (int)(e / ((int64_t)q.Ma * q.Nb));
+        const int rem = (int)(e - (int64_t)tap * q.Ma * q.Nb);
+        const int mi = rem / q.Nb, n = rem - mi * q.Nb;
+        const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* d = wg_map_dst(q.map, nullptr, 0, tap, mi, n + r);
+          if (d) {
+            if (q.gy == 1) *d += v[r];
+            else atomicAdd(d, v[r]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WJob q) { wgrad_finish_body(q, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void wgrad_finish_batched_kernel(const WBatch b) {
+  const WJob& q = b.job[blockIdx.z];
+  if ((int)blockIdx.x >= q.gx || (int)blockIdx.y >= q.gy) return;
+  wgrad_finish_body(q, blockIdx.x, blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------ deferral context (host)
+struct DeferCtx {
+  hipStream_t s;
+  float* rws; int64_t rcap, rused;
+  float* wws; int64_t wcap, wused;
+  std::vector<RJob> rj;
+  std::vector<WJob> wj;
+};
+static std::vector<DeferCtx> g_ctx;   // one per stream between begin and end (a handful at most)
+
+static DeferCtx* find_ctx(hipStream_t s) {
+  for (auto& c : g_ctx)
+    if (c.s == s) return &c;
+  return nullptr;
+}
+
+static void flush_reduce(DeferCtx& c) {
+  for (size_t i = 0; i < c.rj.size(); i += 48) {
+    RBatch b = {};
+    int gx = 1;
+    b.njobs = (int)(c.rj.size() - i < 48 ? c.rj.size() - i : 48);
+    for (int j = 0; j < b.njobs; ++j) {
+      b.job[j] = c.rj[i + j];
+      if (b.job[j].nblocks > gx) gx = b.job[j].nblocks;
+    }
+    hipLaunchKernelGGL(reduce_finish_batched_kernel, dim3(gx, b.njobs), dim3(256), 0, c.s, b);
+  }
+  c.rj.clear();
+  c.rused = 0;
+}
+static void flush_wgrad(DeferCtx& c) {
+  for (size_t i = 0; i < c.wj.size(); i += 14) {
+    WBatch b = {};
+    int gx = 1, gy = 1;
+    b.njobs = (int)(c.wj.size() - i < 14 ? c.wj.size() - i : 14);
+    for (int j = 0; j < b.njobs; ++j) {
+      b.job[j] = c.wj[i + j];
+      if (b.job[j].gx > gx) gx = b.job[j].gx;
+      if (b.job[j].gy > gy) gy = b.job[j].gy;
+    }
+    hipLaunchKernelGGL(wgrad_finish_batched_kernel, dim3(gx, gy, b.njobs), dim3(256), 0, c.s, b);
+  }
+  c.wj.clear();
+  c.wused = 0;
+}
+
+// Workspace for `need` floats of per-workgroup partial rows: the caller's own ws, or (deferring) a private region.
+float* usseg_defer_reduce_ws(hipStream_t s, float* caller_ws, int64_t need) {
+  DeferCtx* c = find_ctx(s);
+  if (!c || !c->rws || need > c->rcap) return caller_ws;
+  if (c->rused + need > c->rcap) flush_reduce(*c);
+  float* r = c->rws + c->rused;
+  c->rused += (need + 63) & ~(int64_t)63;
+  return r;
+}
+
+void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0, float* d1, float* d2,
+                                hipStream_t s) {
+  RJob q = {};
+  q.ws = ws; q.d0 = d0; q.d1 = d1; q.d2 = d2; q.groups = groups; q.nb = nb; q.K = K; q.Cp = Cp; q.C = C; q.scale = scale;
+  int total = groups * K * C;
+  int grid = (total + 15) / 16;
+  if (grid > 1024) grid = 1024;
+  q.nblocks = grid;
+  DeferCtx* c = find_ctx(s);
+  if (c && c->rws && ws >= c->rws && ws < c->rws + c->rcap) {   // partials live in the deferred region: queue
+    c->rj.push_back(q);
+    return;
+  }
+  hipLaunchKernelGGL(reduce_finish_kernel, dim3(grid), dim3(256), 0, s, q);
+}
+
+// Slab workspace for a weight gradient: base pointer and capacity (floats) the launcher may use right now.
+float* usseg_defer_wgrad_ws(hipStream_t s, float* caller_ws, int64_t caller_floats, int64_t* avail) {
+  DeferCtx* c = find_ctx(s);
+  if (!c || !c->wws) { *avail = caller_floats; return caller_ws; }
+  if (c->wcap - c->wused < c->wcap / 4 && !c->wj.empty()) flush_wgrad(*c);   // keep at least a quarter free for the next producer
+  *avail = c->wcap - c->wused;
+  return c->wws + c->wused;
+}
+
+void usseg_launch_wgrad_finish(const float* ws, int splits, int64_t slab_floats, float* out, const WgMap& map, int Ma, int Nb, hipStream_t s) {
+  WJob q = {};
+  q.ws = ws; q.out = out; q.n4 = slab_floats / 4; q.splits = splits; q.Ma = Ma; q.Nb = Nb; q.map = map;
+  int gx = (int)((q.n4 + 63) / 64);
+  if (gx > 2048) gx = 2048;
+  int gy = 1;  // small outputs: also split the slab axis so a few hundred workgroups share the walk
+  while (gx * gy < 256 && splits / (gy * 2) >= 8) gy *= 2;
+  q.gx = gx; q.gy = gy;
+  DeferCtx* c = find_ctx(s);
+  if (c && c->wws && ws >= c->wws && ws < c->wws + c->wcap) {
+    c->wused = (ws - c->wws) + (((int64_t)splits * slab_floats + 63) & ~(int64_t)63);   // commit the slabs this producer wrote
+    c->wj.push_back(q);
+    return;
+  }
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(gx, gy), dim3(256), 0, s, q);
+}
+
+extern "C" int usseg_defer_begin(usseg_stream_t stream, float* reduce_ws, int64_t reduce_floats, float* wgrad_ws, int64_t wgrad_floats) {
+  USSEG_CHECK_ARG((!reduce_ws || reduce_floats > 0) && (!wgrad_ws || wgrad_floats > 0), "defer_begin: bad workspace sizes");
+  hipStream_t s = (hipStream_t)stream;
+  DeferCtx* c = find_ctx(s);
+  if (c) { flush_reduce(*c); flush_wgrad(*c); }
+  else { g_ctx.push_back(DeferCtx()); c = &g_ctx.back(); c->s = s; }
+  c->rws = reduce_ws; c->rcap = reduce_ws ? reduce_floats : 0; c->rused = 0;
+  c->wws = wgrad_ws; c->wcap = wgrad_ws ? wgrad_floats : 0; c->wused = 0;
+  return USSEG_OK;
+}
+extern "C" int usseg_defer_flush(usseg_stream_t stream) {
+  DeferCtx* c = find_ctx((hipStream_t)stream);
+  if (c) { flush_reduce(*c); flush_wgrad(*c); }
+  return usseg_check_launch("defer_flush");
+}
+extern "C" int usseg_defer_end(usseg_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  for (size_t i = 0; i < g_ctx.size(); ++i)
+    if (g_ctx[i].s == s) {
+      flush_reduce(g_ctx[i]);
+      flush_wgrad(g_ctx[i]);
+      g_ctx.erase(g_ctx.begin() + i);
+      break;
+    }
+  return usseg_check_launch("defer_end");
+}

@@ -43,53 +43,6 @@ __device__ __forceinline__ void block_chunk_partial(float* acc8, int LPP, int ch
   for (int c = threadIdx.x; c < Cphys; c += 256) ws_row[c] = s_red[c] + s_red[512 + c] + s_red[1024 + c] + s_red[1536 + c];
 }
 
-// dst_k[g*C + c] += scale * sum_{j<nb} ws[((g*nb + j)*K + k)*Cp + c]   for k < K (dst_k may be NULL)
-__global__ __launch_bounds__(256) void reduce_finish_kernel(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0,
-                                                             float* d1, float* d2) {
-  // workgroup = 16 outputs x 16 row slices: the nb partial rows of an output are summed by 16 threads in parallel
-  // (a serial walk over 512 rows is a 512-deep chain of dependent loads: 45 us; this form is ~3 us)
-  __shared__ float s_part[16][17];
-  const int total = groups * K * C;
-  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  for (int base = blockIdx.x * 16; base < total; base += gridDim.x * 16) {
-    const int i = base + o;
-    float s = 0.f;
-    int c = 0, k = 0, g = 0;
-    if (i < total) {
-      c = i % C;
-      k = (i / C) % K;
-      g = i / (C * K);
-      const float* src = ws + ((int64_t)g * nb * K + k) * Cp + c;
-      const int64_t rs = (int64_t)K * Cp;
-      float s1 = 0.f, s2 = 0.f, s3 = 0.f;    // four independent chains: the loads of a slice are in flight together
-      int j = sl;
-      for (; j + 48 < nb; j += 64) {
-        s += src[j * rs]; s1 += src[(j + 16) * rs]; s2 += src[(j + 32) * rs]; s3 += src[(j + 48) * rs];
-      }
-      for (; j < nb; j += 16) s += src[j * rs];
-      s += s1 + s2 + s3;
-    }
-    s_part[sl][o] = s;
-    __syncthreads();
-    if (sl == 0 && i < total) {
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) t += s_part[q][o];
-      float* dst = k == 0 ? d0 : (k == 1 ? d1 : d2);
-      if (dst) dst[g * C + c] += scale * t;
-    }
-    __syncthreads();
-  }
-}
-
-void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0, float* d1, float* d2,
-                                hipStream_t s) {
-  int total = groups * K * C;
-  int grid = (total + 15) / 16;
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(reduce_finish_kernel, dim3(grid), dim3(256), 0, s, ws, groups, nb, K, Cp, C, scale, d0, d1, d2);
-}
-
 extern "C" int64_t usseg_reduce_ws_floats(void) { return (int64_t)USSEG_REDUCE_MAX_BLOCKS * 3 * 512; }
 
 // ------------------------------------------------------------------------------------------ norm + act
@@ -328,6 +281,7 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   int ppb = 4 * (64 / p.LPP);
   // small tensors are latency bound (each loop trip is a dependent load -> store): spread them over many workgroups
   unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
+  p.ws = ws = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * 3 * p.Cphys);
   if (p.mode == 0) hipLaunchKernelGGL((norm_act_kernel<true, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((norm_act_kernel<true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
@@ -371,8 +325,9 @@ extern "C" int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, fl
     int LPP = lanes_per_pixel(cwp / 8);
     int ppb = 4 * (64 / LPP);
     unsigned grid = grid_for(M, ppb * 8, USSEG_REDUCE_MAX_BLOCKS);
-    hipLaunchKernelGGL(colsum_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy + c0, M, cw, ld, LPP, ws);
-    usseg_launch_reduce_finish(ws, 1, (int)grid, 1, cwp, cw, 1.f, db + c0, nullptr, nullptr, (hipStream_t)stream);
+    float* wsr = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * cwp);
+    hipLaunchKernelGGL(colsum_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy + c0, M, cw, ld, LPP, wsr);
+    usseg_launch_reduce_finish(wsr, 1, (int)grid, 1, cwp, cw, 1.f, db + c0, nullptr, nullptr, (hipStream_t)stream);
   }
   return usseg_check_launch("colsum");
 }

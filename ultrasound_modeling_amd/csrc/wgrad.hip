@@ -151,6 +151,7 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
   // 32x16 cardinal conv1 gradient took 35-120 us that way).  Slab traffic is kept within ~8x the operand bytes.
   const int64_t slab = (int64_t)ntaps * p.Ma * p.Nb;
   p.ws = nullptr;
+  if (ws) ws = usseg_defer_wgrad_ws(s, ws, ws_floats, &ws_floats);
   if (ws && want > 1) {
     const int64_t in_bytes = p.M * (p.Ma + p.Nb) * 2;
     int64_t cap = 8 * in_bytes / (slab * 4);
@@ -205,6 +206,17 @@ extern "C" int usseg_conv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, 
                                          int64_t ws_floats, usseg_stream_t stream) {
   USSEG_CHECK_ARG(dst, "null destination map");
   return conv2d_wgrad_impl(d, x, dy, nullptr, dst, ws, ws_floats, stream);
+}
+
+extern "C" int usseg_conv2d_wgrad_multi(int32_t njobs, const UssegWgradJob* jobs, float* ws, int64_t ws_floats, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(jobs && njobs >= 1 && njobs <= 4, "wgrad multi: 1 <= njobs <= 4");
+  for (int j = 0; j < njobs; ++j) USSEG_CHECK_ARG(jobs[j].x && jobs[j].dy && (jobs[j].dw || jobs[j].dst), "wgrad multi: null pointer");
+  if (njobs > 1 && usseg_try_launch_wgrad_halo_multi(njobs, jobs, ws, ws_floats, (hipStream_t)stream)) return usseg_check_launch("wgrad_halo_multi");
+  for (int j = 0; j < njobs; ++j) {
+    int rc = conv2d_wgrad_impl(&jobs[j].desc, jobs[j].x, jobs[j].dy, jobs[j].dst ? nullptr : jobs[j].dw, jobs[j].dst, ws, ws_floats, stream);
+    if (rc) return rc;
+  }
+  return USSEG_OK;
 }
 
 static int tconv2d_wgrad_impl(const UssegConvDesc* d, const void* x, const void* dy, float* dw, const UssegWgradDst* dst, float* ws,

@@ -22,8 +22,15 @@ struct WgHaloParams {
 
 // WVM = waves along the input-channel axis (2 or 4; the other 4/WVM waves split the output channels),
 // WM x WN = 16x16 MFMA tiles per wave: workgroup tile = (16*WM*WVM) x (16*WN*(4/WVM)).
+// Up to 4 independent weight gradients of identical shape (the DecoderBlock's dilation branches) share one launch,
+// blockIdx.z = job: the same number of workgroups with a third of the split-K slabs per job.
+struct WgHaloMulti {
+  WgHaloParams job[4];
+};
+
 template <int WVM, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P) {
+  const WgHaloParams& p = P.job[blockIdx.z];
   constexpr int MAXHP = 288;
   constexpr int WVN = 4 / WVM;
   constexpr int BMc = 16 * WM * WVM, BNc = 16 * WN * WVN;      // channels per workgroup tile
@@ -181,91 +188,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloParams p
       }
 }
 
-// out[i] += sum_s ws[s][i]  (n floats per slab, n % 4 == 0)
-// Workgroup = 64 float4 outputs x 4 slab slices; blockIdx.y splits the slabs further when the output is small, and
-// those partial sums meet in `out` through a handful of atomics per element.
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* ws, int splits, int64_t n4, float* out, const WgMap map, int Ma,
-                                                            int Nb) {
-  __shared__ float4 s_part[4][64];
-  const float4* w4 = reinterpret_cast<const float4*>(ws);
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int per_y = (splits + gridDim.y - 1) / gridDim.y;
-  const int s0 = blockIdx.y * per_y;
-  int s1 = s0 + per_y;
-  if (s1 > splits) s1 = splits;
-  for (int64_t base = (int64_t)blockIdx.x * 64; base < n4; base += (int64_t)gridDim.x * 64) {
-    const int64_t i = base + o;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n4) {
-#pragma unroll 4
-      for (int s = s0 + sl; s < s1; s += 4) {
-        float4 v = w4[(int64_t)s * n4 + i];
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-      }
-    }
-    s_part[sl][o] = a;
-    __syncthreads();
-    if (sl == 0 && i < n4) {
-      float4 t = s_part[0][o];
-#pragma unroll
-      for (int q = 1; q < 4; ++q) { t.x += s_part[q][o].x; t.y += s_part[q][o].y; t.z += s_part[q][o].z; t.w += s_part[q][o].w; }
-      if (map.nblocks == 0) {
-        float* d = out + i * 4;
-        if (gridDim.y == 1) { d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
-        else { atomicAdd(d, t.x); atomicAdd(d + 1, t.y); atomicAdd(d + 2, t.z); atomicAdd(d + 3, t.w); }
-      } else {   // scatter into the framework's variables (logical channels, Keras strides); the four elements share (tap, ci)
-        const int64_t e = i * 4;
-        const int tap = (int)(e / ((int64_t)Ma * Nb));
-        const int rem = (int)(e - (int64_t)tap * Ma * Nb);
-        const int mi = rem / Nb, n = rem - mi * Nb;
-        const float v[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float* d = wg_map_dst(map, nullptr, 0, tap, mi, n + q);
-          if (d) {
-            if (gridDim.y == 1) *d += v[q];
-            else atomicAdd(d, v[q]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-void usseg_launch_wgrad_finish(const float* ws, int splits, int64_t slab_floats, float* out, const WgMap& map, int Ma, int Nb, hipStream_t s) {
-  int64_t n4 = slab_floats / 4;
-  int gx = (int)((n4 + 63) / 64);
-  if (gx > 2048) gx = 2048;
-  int gy = 1;  // small outputs: also split the slab axis so a few hundred workgroups share the walk
-  while (gx * gy < 256 && splits / (gy * 2) >= 8) gy *= 2;
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(gx, gy), dim3(256), 0, s, ws, splits, n4, out, map, Ma, Nb);
-}
-
 // Returns 1 and launches if the geometry fits, 0 if the caller must use the per-tap kernel.
-int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, const WgMap& map, int B, int H, int W, int d, int Ma, int Nb,
-                                int ldx, int lddy, float* ws, int64_t ws_floats, hipStream_t s) {
+struct WgHaloGeom {
+  const bf16_t* x; const bf16_t* dy; float* out; WgMap map;
+  int B, H, W, d, Ma, Nb, ldx, lddy;
+};
+
+// Launches njobs (1..4) weight gradients of identical (B,H,W,Ma,Nb) - dilations may differ as long as the group counts match -
+// as one grid; returns 0 if the geometry does not fit (the caller then uses the per-tap kernel, one job at a time).
+static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t ws_floats, hipStream_t s) {
   static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
-  if (disabled) return 0;
-  if (d < 1 || H % d || W % d) return 0;
-  const int Hl = H / d, Wl = W / d;
-  int PW;
-  if (Wl % 16 == 0) PW = 16;
-  else if (Wl == 8 || Wl == 4) PW = Wl;
-  else return 0;
-  int PH = 128 / PW;
-  if (PH > Hl) PH = Hl;
-  if (Hl % PH || (PH * PW) % 16) return 0;
-  const int NV = 128 / (PH * PW);
-  if (NV * (PH + 2) * (PW + 2) > 288) return 0;
-  WgHaloParams p = {};
-  p.x = x; p.dy = dy; p.out = out;
-  p.B = B; p.H = H; p.W = W; p.d = d; p.Hl = Hl; p.Wl = Wl; p.PH = PH; p.PW = PW; p.NV = NV;
-  p.tiles_x = Wl / PW;
-  p.tiles_per_v = (Hl / PH) * p.tiles_x;
-  p.npatches = B * d * d * p.tiles_per_v;
-  p.ngroups = (p.npatches + NV - 1) / NV;
-  p.ldx = ldx; p.lddy = lddy; p.Ma = Ma; p.Nb = Nb;
+  if (disabled || njobs < 1 || njobs > 4) return 0;
+  WgHaloMulti P;
+  const int Ma = gm[0].Ma, Nb = gm[0].Nb;
+  for (int j = 0; j < njobs; ++j) {
+    const WgHaloGeom& q = gm[j];
+    if (q.Ma != Ma || q.Nb != Nb || q.B != gm[0].B || q.H != gm[0].H || q.W != gm[0].W) return 0;
+    const int d = q.d;
+    if (d < 1 || q.H % d || q.W % d) return 0;
+    const int Hl = q.H / d, Wl = q.W / d;
+    int PW;
+    if (Wl % 16 == 0) PW = 16;
+    else if (Wl == 8 || Wl == 4) PW = Wl;
+    else return 0;
+    int PH = 128 / PW;
+    if (PH > Hl) PH = Hl;
+    if (Hl % PH || (PH * PW) % 16) return 0;
+    const int NV = 128 / (PH * PW);
+    if (NV * (PH + 2) * (PW + 2) > 288) return 0;
+    WgHaloParams& p = P.job[j];
+    p = {};
+    p.x = q.x; p.dy = q.dy; p.out = q.out;
+    p.B = q.B; p.H = q.H; p.W = q.W; p.d = d; p.Hl = Hl; p.Wl = Wl; p.PH = PH; p.PW = PW; p.NV = NV;
+    p.tiles_x = Wl / PW;
+    p.tiles_per_v = (Hl / PH) * p.tiles_x;
+    p.npatches = q.B * d * d * p.tiles_per_v;
+    p.ngroups = (p.npatches + NV - 1) / NV;
+    p.ldx = q.ldx; p.lddy = q.lddy; p.Ma = Ma; p.Nb = Nb;
+    if (p.ngroups != P.job[0].ngroups) return 0;
+  }
+  if (ws) ws = usseg_defer_wgrad_ws(s, ws, ws_floats, &ws_floats);   // deferred finishing: a private region of the step's workspace
   // tile shape by channel counts: 64x64, 32x32 (both small), 64x16 / 64x32 (few output channels, e.g. the decoder branches)
   int shape = 0;
   if (Ma <= 32 && Nb <= 32) shape = 1;
@@ -273,35 +235,65 @@ int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, c
   else if (Nb <= 32) shape = 3;
   const int bm = shape == 1 ? 32 : 64, bn = shape == 0 ? 64 : (shape == 2 ? 16 : 32);
   const int tm = (Ma + bm - 1) / bm;
-  p.ntiles_n = (Nb + bn - 1) / bn;
-  const int tiles = tm * p.ntiles_n;
-  // split-K over pixel chunks: aim for ~512 workgroups with >= 2 chunks each.  With a workspace every split writes its
-  // own partial slab (plain stores) and wgrad_finish_kernel sums them; fp32 atomics into a 9*64*64 tile from hundreds of
-  // workgroups run at the ~1.3 TB/s atomic rate and cost more than the MFMAs, so they are only the no-workspace fallback.
+  const int ntn = (Nb + bn - 1) / bn;
+  const int tiles = tm * ntn;
+  const int ngroups = P.job[0].ngroups;
+  // split-K over pixel chunks: aim for ~512 workgroups (over all jobs) with >= 2 chunks each.  With a workspace every
+  // split writes its own partial slab (plain stores) and the finishing kernel sums them; fp32 atomics into a 9*64*64 tile
+  // from hundreds of workgroups run at the ~1.3 TB/s atomic rate and cost more than the MFMAs (no-workspace fallback only).
   const int64_t slab = (int64_t)9 * Ma * Nb;
   // traffic guard (rocprofv3 FETCH/WRITE_SIZE showed the partial slabs costing ~2 GB/step): keep the slabs written and
   // re-read within a few times the bytes of the operands themselves.  (Sending the deep layers back to the per-tap
   // kernel, or capping at 1x, was measured slower: 7.5 vs 6.9 ms/step.)
-  const int64_t in_bytes = (int64_t)B * H * W * (Ma + Nb) * 2, slab_bytes = slab * 4;
-  int splits = (512 + tiles - 1) / tiles;
-  int max_splits = (p.ngroups + 1) / 2;
+  const int64_t in_bytes = (int64_t)gm[0].B * gm[0].H * gm[0].W * (Ma + Nb) * 2, slab_bytes = slab * 4;
+  int splits = (512 + tiles * njobs - 1) / (tiles * njobs);
+  int max_splits = (ngroups + 1) / 2;
   const int64_t traffic_cap = 8 * in_bytes / slab_bytes < 4 ? 4 : 8 * in_bytes / slab_bytes;
   if (max_splits > traffic_cap) max_splits = (int)traffic_cap;
-  if (!ws) max_splits = (p.ngroups + 15) / 16;
-  else if ((int64_t)max_splits * slab > ws_floats) max_splits = (int)(ws_floats / slab);
+  if (!ws) max_splits = (ngroups + 15) / 16;
+  else if ((int64_t)max_splits * slab * njobs > ws_floats) max_splits = (int)(ws_floats / (slab * njobs));
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  bool mapped = false;
+  for (int j = 0; j < njobs; ++j) mapped = mapped || gm[j].map.nblocks;
   // a mapped destination is scattered by the finishing kernel, so it always goes through a slab
-  p.ws = (ws && (splits > 1 || map.nblocks) && (int64_t)splits * slab <= ws_floats) ? ws : nullptr;
-  if (map.nblocks && !p.ws) return 0;
-  p.groups_per_block = (p.ngroups + splits - 1) / splits;
-  splits = (p.ngroups + p.groups_per_block - 1) / p.groups_per_block;
+  const bool use_ws = ws && (splits > 1 || mapped) && (int64_t)splits * slab * njobs <= ws_floats;
+  if (mapped && !use_ws) return 0;
+  const int gpb = (ngroups + splits - 1) / splits;
+  splits = (ngroups + gpb - 1) / gpb;
+  for (int j = 0; j < njobs; ++j) {
+    P.job[j].ntiles_n = ntn;
+    P.job[j].groups_per_block = gpb;
+    P.job[j].ws = use_ws ? ws + (int64_t)j * splits * slab : nullptr;
+  }
+  const dim3 grid(splits, tiles, njobs);
   const int slot = usseg_prof_start(2, s);
-  if (shape == 1) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1>), dim3(splits, tiles), dim3(256), 0, s, p);
-  else if (shape == 2) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1>), dim3(splits, tiles), dim3(256), 0, s, p);
-  else if (shape == 3) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2>), dim3(splits, tiles), dim3(256), 0, s, p);
-  if (p.ws) usseg_launch_wgrad_finish(p.ws, splits, slab, out, map, Ma, Nb, s);
+  if (shape == 1) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1>), grid, dim3(256), 0, s, P);
+  else if (shape == 2) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1>), grid, dim3(256), 0, s, P);
+  else if (shape == 3) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2>), grid, dim3(256), 0, s, P);
+  if (use_ws)
+    for (int j = 0; j < njobs; ++j) usseg_launch_wgrad_finish(P.job[j].ws, splits, slab, gm[j].out, gm[j].map, Ma, Nb, s);
   usseg_prof_stop(2, slot, s);
   return 1;
+}
+
+// Returns 1 and launches if the geometry fits, 0 if the caller must use the per-tap kernel.
+int usseg_try_launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* out, const WgMap& map, int B, int H, int W, int d, int Ma, int Nb,
+                                int ldx, int lddy, float* ws, int64_t ws_floats, hipStream_t s) {
+  WgHaloGeom g = {x, dy, out, map, B, H, W, d, Ma, Nb, ldx, lddy};
+  return wgrad_halo_launch(&g, 1, ws, ws_floats, s);
+}
+
+int usseg_try_launch_wgrad_halo_multi(int njobs, const UssegWgradJob* jobs, float* ws, int64_t ws_floats, hipStream_t s) {
+  if (njobs < 1 || njobs > 4) return 0;
+  WgHaloGeom g[4];
+  for (int j = 0; j < njobs; ++j) {
+    const UssegWgradJob& q = jobs[j];
+    const UssegConvDesc& d = q.desc;
+    if (d.ksize != 3) return 0;
+    g[j] = {(const bf16_t*)q.x, (const bf16_t*)q.dy, q.dw, WgMap(), d.B, d.H, d.W, d.dilation, d.Cin, d.Cout, d.ldx, d.ldy};
+    if (!wg_map_fill(g[j].map, q.dst)) return 0;
+  }
+  return wgrad_halo_launch(g, njobs, ws, ws_floats, s);
 }

@@ -149,14 +149,22 @@ class Conv2D(nn.Module):
         self._x = x
         return ops.conv2d_fwd(x, self.wp_f, self.bias.data if use_bias else None, self.k, self.dil, out, act, alpha, residual, out_f32)
 
-    def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False, skip_bias=False):
+    def wgrad_job(self, dy):
+        """(x, dy, k, dilation, dw, dst_map) for ops.conv2d_wgrad_multi."""
+        plain = self.cin_p == self.cin and self.cout_p == self.cout
+        return (self._x, dy, self.k, self.dil, self.kernel.grad if plain else None, None if plain else self._wgrad_map())
+
+    def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False, skip_bias=False, skip_wgrad=False):
         """dy: gradient w.r.t. the conv output (before any fused activation).  Accumulates kernel/bias grads.
-        ``skip_bias``: the bias gradient was already produced by the following norm layer's backward (its ``dbias``)."""
+        ``skip_bias``: the bias gradient was already produced by the following norm layer's backward (its ``dbias``).
+        ``skip_wgrad``: the caller runs the weight gradient itself (a multi-job launch with its sibling branches)."""
         x = self._x
-        with ops.side_stream(x, dy):          # parameter gradients: beside the backward-data chain
-            self._wgrad(x, dy)
-            if not skip_bias:
-                ops.colsum(dy, self.bias.grad, self.cout)
+        if not (skip_wgrad and skip_bias):
+            with ops.side_stream(x, dy):          # parameter gradients: beside the backward-data chain
+                if not skip_wgrad:
+                    self._wgrad(x, dy)
+                if not skip_bias:
+                    ops.colsum(dy, self.bias.grad, self.cout)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)
@@ -297,6 +305,7 @@ class BatchNormalization(LayerNormalization):
         cp = self.moving_mean_p.numel()
         tg, tb = torch.zeros(cp, device=x.device), torch.zeros(cp, device=x.device)
         ops.norm_act_bwd(x, dy, self.C, self.gamma.data, self.beta.data, dx, tg, tb, 1, 1, self.eps, act, alpha, self._bmean, self._bvar)
+        ops.defer_flush()                      # tg / tb are read right away
         ops.bn_train_bwd_fix(x, dx, self.C, self.gamma.data, self._bmean, self._bvar, self.eps, tg, tb)
         self.gamma.grad.add_(tg[:self.C])      # tiny [C] vectors: host-side glue, not a compute kernel of the path
         self.beta.grad.add_(tb[:self.C])

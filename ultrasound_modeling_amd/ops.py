@@ -47,21 +47,61 @@ WGRAD_WS_FLOATS = 64 << 20   # 256 MB of the 288 GB: split-K partial slabs of th
 # caching allocator cannot hand their memory to a later main-stream tensor.
 class _Side:
     enabled = os.environ.get("USSEG_SIDE_STREAM", "1") != "0"
+    defer = os.environ.get("USSEG_DEFER", "1") != "0"
     depth = 0
     stream = None
     keep = []
     dirty = False
+    deferring = set()      # stream handles with an open deferral context
+    bufs = {}
+
+
+DEFER_REDUCE_FLOATS = 32 << 20    # 128 MB of partial rows per stream
+DEFER_WGRAD_FLOATS = 256 << 20    # 1 GB of split-K slabs per stream (of 288 GB): the whole backward pass between flushes
+
+
+def _defer_begin():
+    """Queue the finishing reductions of the current stream (usseg_defer_begin) until _defer_end."""
+    if not _Side.defer:
+        return
+    h = _stream()
+    if h in _Side.deferring:
+        return
+    dev = torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream() == _Side.stream)
+    if key not in _Side.bufs:
+        _Side.bufs[key] = (torch.empty(DEFER_REDUCE_FLOATS, dtype=torch.float32, device="cuda"),
+                           torch.empty(DEFER_WGRAD_FLOATS, dtype=torch.float32, device="cuda"))
+    r, w = _Side.bufs[key]
+    L.check(L.load().usseg_defer_begin(h, r.data_ptr(), r.numel(), w.data_ptr(), w.numel()), "defer_begin")
+    _Side.deferring.add(h)
+
+
+def _defer_end():
+    h = _stream()
+    if h in _Side.deferring:
+        _Side.deferring.discard(h)
+        L.check(L.load().usseg_defer_end(h), "defer_end")
+
+
+def defer_flush():
+    """Run the queued finishing reductions of the current stream now (their gradients are about to be read)."""
+    if _stream() in _Side.deferring:
+        L.check(L.load().usseg_defer_flush(_stream()), "defer_flush")
 
 
 @contextlib.contextmanager
 def overlap_region():
     _Side.depth += 1
+    if _Side.depth == 1:
+        _defer_begin()
     try:
         yield
     finally:
         _Side.depth -= 1
         if _Side.depth == 0:
             side_join()
+            _defer_end()
 
 
 @contextlib.contextmanager
@@ -79,11 +119,14 @@ def side_stream(*keep):
     _Side.keep.extend(keep)
     _Side.dirty = True
     with torch.cuda.stream(_Side.stream):
+        _defer_begin()
         yield
 
 
 def side_join():
     if _Side.dirty:
+        with torch.cuda.stream(_Side.stream):
+            _defer_end()
         ev = torch.cuda.Event()
         ev.record(_Side.stream)
         torch.cuda.current_stream().wait_event(ev)
@@ -216,6 +259,19 @@ def conv2d_wgrad_mapped(x, dy, ksize, dilation, dst_map):
     ws = wgrad_ws(x.device)
     L.check(L.load().usseg_conv2d_wgrad_mapped(C.byref(d), x.data_ptr(), dy.data_ptr(), C.byref(dst_map), ws.data_ptr(), ws.numel(),
                                                _stream()), "conv2d_wgrad_mapped")
+
+
+def conv2d_wgrad_multi(jobs):
+    """jobs: list of (x, dy, ksize, dilation, dw or None, dst_map or None): independent weight gradients, one launch where possible."""
+    arr = (L.WgradJob * len(jobs))()
+    for j, (x, dy, ksize, dilation, dw, dst_map) in enumerate(jobs):
+        B, H, W, Cin, ldx = geom(x)
+        _, _, _, Cout, ldy = geom(dy)
+        arr[j].desc = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation)
+        arr[j].x, arr[j].dy, arr[j].dw = x.data_ptr(), dy.data_ptr(), _ptr(dw)
+        arr[j].dst = C.pointer(dst_map) if dst_map is not None else None
+    ws = wgrad_ws(jobs[0][0].device)
+    L.check(L.load().usseg_conv2d_wgrad_multi(len(jobs), C.addressof(arr), ws.data_ptr(), ws.numel(), _stream()), "conv2d_wgrad_multi")
 
 
 def tconv2d_wgrad_mapped(x, dy, ksize, dst_map):
