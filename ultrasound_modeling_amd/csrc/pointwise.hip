@@ -57,7 +57,11 @@ struct NormParams {
   float eps, alpha;
 };
 
-template <bool BWD, int MODE>   // MODE 0: per-pixel (grouped) LayerNormalization; 1: per-channel affine with given statistics
+// MODE 0: per-pixel LayerNormalization over NG groups of channels; MODE 1: per-channel affine with given statistics.
+// NG = 1 is the plain LayerNormalization (no group bookkeeping at all); NG = 4 handles up to four groups with 0/1
+// membership masks folded into FMAs (the cardinal paths' LN: 3 groups of 3..85 channels, not aligned to the 8-channel
+// chunks - per-element compare/select chains made that form VALU bound at ~1 TB/s).
+template <bool BWD, int MODE, int NG>
 __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int LPP = p.LPP, ppw = 64 / LPP;
@@ -67,8 +71,8 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
   const int c0 = chunk * 8;
   // per-lane channel constants: unconditional 16-byte loads, masked afterwards (a load under a per-element condition
   // compiles to a branch + wait per element: 32 dependent L2 round trips, ~10 us before the first pixel)
-  float ga[8], be[8], mu_c[8], rs_c[8];
-  int grp[8];
+  float ga[8], be[8], mu_c[8], rs_c[8], okf[8];
+  float gm[NG][8];   // gm[g][j] = 1 if channel c0+j belongs to group g (NG > 1 only)
   {
     const int cl = chunk_ok ? c0 : 0;
     float gv[8], bv[8], mv[8], vv[8];
@@ -82,15 +86,21 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
       *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(p.var + cl);
       *reinterpret_cast<float4*>(vv + 4) = *reinterpret_cast<const float4*>(p.var + cl + 4);
     }
+    const int g0 = c0 / p.Cg, r0 = c0 - g0 * p.Cg;   // group of the chunk's first channel, offset inside it
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c0 + j;
       const bool ok = chunk_ok && c < p.C;
+      okf[j] = ok ? 1.f : 0.f;
       ga[j] = ok ? gv[j] : 0.f;
       be[j] = ok ? bv[j] : 0.f;
-      grp[j] = ok ? c / p.Cg : -1;
       mu_c[j] = (MODE == 1 && ok) ? mv[j] : 0.f;
       rs_c[j] = (MODE == 1 && ok) ? rsqrtf(vv[j] + p.eps) : 0.f;
+      if (NG > 1) {
+        int gj = g0 + (r0 + j) / p.Cg;   // Cg >= 3 in every model, so a chunk spans at most 4 groups; general anyway
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gm[g][j] = (ok && gj == g) ? 1.f : 0.f;
+      }
     }
   }
   __shared__ float s_red[BWD ? 4 * 512 : 1];
@@ -103,48 +113,65 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
   for (int64_t base = (int64_t)blockIdx.x * ppb; base < p.M; base += (int64_t)gridDim.x * ppb) {
     const int64_t m = base + wv * ppw + slot;
     const bool valid = chunk_ok && m < p.M;
-    float xv[8];
+    float xv[8], dyv[8];
+    uint4 rawx = make_uint4(0, 0, 0, 0), rawd = make_uint4(0, 0, 0, 0);
     if (valid) {
-      uint4 raw = *reinterpret_cast<const uint4*>(p.x + m * p.ldx + c0);
-      unpack8(raw, xv);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xv[j] = 0.f;
+      rawx = *reinterpret_cast<const uint4*>(p.x + m * p.ldx + c0);
+      if (BWD) rawd = *reinterpret_cast<const uint4*>(p.dy + m * p.lddy + c0);
     }
-    float xh[8];  // normalised value
-    float rstd_g[4] = {0.f, 0.f, 0.f, 0.f};
+    unpack8(rawx, xv);
+    if (BWD) unpack8(rawd, dyv);
+    float xh[8];        // normalised value
+    float rstd_j[8];    // 1/sigma of each element's group (MODE 0)
     if (MODE == 0) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      float s[NG];
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi) s[gi] += (grp[j] == gi) ? xv[j] : 0.f;
-#pragma unroll
-      for (int gi = 0; gi < 4; ++gi)
-        if (gi < p.G)
-          for (int msk = 1; msk < LPP; msk <<= 1) s[gi] += __shfl_xor(s[gi], msk, 64);
-      float d[8];
-      float ss[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < NG; ++g) s[g] = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float mean = 0.f;
+        if (NG == 1) s[0] += xv[j] * okf[j];
+        else
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) mean = (grp[j] == gi) ? s[gi] * inv_cg : mean;
-        d[j] = (grp[j] >= 0) ? xv[j] - mean : 0.f;
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi) ss[gi] += (grp[j] == gi) ? d[j] * d[j] : 0.f;
+          for (int g = 0; g < NG; ++g) s[g] = fmaf(gm[g][j], xv[j], s[g]);
       }
+      for (int msk = 1; msk < LPP; msk <<= 1)
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi)
-        if (gi < p.G) {
-          for (int msk = 1; msk < LPP; msk <<= 1) ss[gi] += __shfl_xor(ss[gi], msk, 64);
-          rstd_g[gi] = rsqrtf(ss[gi] * inv_cg + p.eps);
-        }
+        for (int g = 0; g < NG; ++g) s[g] += __shfl_xor(s[g], msk, 64);
+      float d[8], ss[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ss[g] = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float r = 0.f;
+        float mean;
+        if (NG == 1) mean = s[0] * inv_cg;
+        else {
+          mean = 0.f;
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) r = (grp[j] == gi) ? rstd_g[gi] : r;
+          for (int g = 0; g < NG; ++g) mean = fmaf(gm[g][j], s[g], mean);
+          mean *= inv_cg;
+        }
+        d[j] = (xv[j] - mean) * okf[j];
+        if (NG == 1) ss[0] = fmaf(d[j], d[j], ss[0]);
+        else
+#pragma unroll
+          for (int g = 0; g < NG; ++g) ss[g] = fmaf(gm[g][j] * d[j], d[j], ss[g]);
+      }
+      for (int msk = 1; msk < LPP; msk <<= 1)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ss[g] += __shfl_xor(ss[g], msk, 64);
+      float rstd_g[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) rstd_g[g] = rsqrtf(ss[g] * inv_cg + p.eps);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float r;
+        if (NG == 1) r = rstd_g[0];
+        else {
+          r = 0.f;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) r = fmaf(gm[g][j], rstd_g[g], r);
+        }
+        rstd_j[j] = r;
         xh[j] = d[j] * r;
       }
     } else {
@@ -155,7 +182,7 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
     if (!BWD) {
       float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (grp[j] >= 0) ? apply_act(ga[j] * xh[j] + be[j], p.act, p.alpha) : 0.f;
+      for (int j = 0; j < 8; ++j) o[j] = okf[j] * apply_act(ga[j] * xh[j] + be[j], p.act, p.alpha);
       if (p.mask && valid) {
         float mk[8];
         unpack8(*reinterpret_cast<const uint4*>(p.mask + m * p.ldm + c0), mk);
@@ -164,56 +191,52 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
       }
       if (valid) *reinterpret_cast<uint4*>(p.y + m * p.ldy + c0) = pack8(o);
     } else {
-      float dyv[8];
-      if (valid) {
-        uint4 raw = *reinterpret_cast<const uint4*>(p.dy + m * p.lddy + c0);
-        unpack8(raw, dyv);
-        if (p.mask) {
-          float mk[8];
-          unpack8(*reinterpret_cast<const uint4*>(p.mask + m * p.ldm + c0), mk);
+      if (p.mask && valid) {
+        float mk[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.mask + m * p.ldm + c0), mk);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dyv[j] *= mk[j];
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dyv[j] = 0.f;
+        for (int j = 0; j < 8; ++j) dyv[j] *= mk[j];
       }
       float dxh[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float pre = ga[j] * xh[j] + be[j];
-        float dh = (grp[j] >= 0) ? dyv[j] * act_grad(pre, p.act, p.alpha) : 0.f;
-        dga[j] += dh * xh[j];
+        float dh = okf[j] * dyv[j] * act_grad(pre, p.act, p.alpha);
+        dga[j] = fmaf(dh, xh[j], dga[j]);
         dbe[j] += dh;
         dxh[j] = dh * ga[j];
       }
       float o[8];
       if (MODE == 0) {
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        float s1[NG], s2[NG];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int gi = 0; gi < 4; ++gi) {
-            s1[gi] += (grp[j] == gi) ? dxh[j] : 0.f;
-            s2[gi] += (grp[j] == gi) ? dxh[j] * xh[j] : 0.f;
-          }
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi)
-          if (gi < p.G)
-            for (int msk = 1; msk < LPP; msk <<= 1) {
-              s1[gi] += __shfl_xor(s1[gi], msk, 64);
-              s2[gi] += __shfl_xor(s2[gi], msk, 64);
-            }
+        for (int g = 0; g < NG; ++g) { s1[g] = 0.f; s2[g] = 0.f; }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float a1 = 0.f, a2 = 0.f, r = 0.f;
+          if (NG == 1) { s1[0] += dxh[j]; s2[0] = fmaf(dxh[j], xh[j], s2[0]); }
+          else
 #pragma unroll
-          for (int gi = 0; gi < 4; ++gi) {
-            a1 = (grp[j] == gi) ? s1[gi] * inv_cg : a1;
-            a2 = (grp[j] == gi) ? s2[gi] * inv_cg : a2;
-            r = (grp[j] == gi) ? rstd_g[gi] : r;
+            for (int g = 0; g < NG; ++g) {
+              s1[g] = fmaf(gm[g][j], dxh[j], s1[g]);
+              s2[g] = fmaf(gm[g][j] * dxh[j], xh[j], s2[g]);
+            }
+        }
+        for (int msk = 1; msk < LPP; msk <<= 1)
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            s1[g] += __shfl_xor(s1[g], msk, 64);
+            s2[g] += __shfl_xor(s2[g], msk, 64);
           }
-          o[j] = r * (dxh[j] - a1 - xh[j] * a2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a1, a2;
+          if (NG == 1) { a1 = s1[0]; a2 = s2[0]; }
+          else {
+            a1 = 0.f; a2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { a1 = fmaf(gm[g][j], s1[g], a1); a2 = fmaf(gm[g][j], s2[g], a2); }
+          }
+          o[j] = okf[j] * rstd_j[j] * (dxh[j] - a1 * inv_cg - xh[j] * a2 * inv_cg);
         }
       } else {
 #pragma unroll
@@ -230,6 +253,14 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
     block_chunk_partial(dbe, LPP, chunk, chunk_ok, row + p.Cphys, p.Cphys, s_red);
     block_chunk_partial(dbi, LPP, chunk, chunk_ok, row + 2 * p.Cphys, p.Cphys, s_red);
   }
+}
+
+template <bool BWD>
+static void norm_launch(const NormParams& p, unsigned grid, hipStream_t s) {
+  if (p.mode == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 1, 1>), dim3(grid), dim3(256), 0, s, p);
+  else if (p.G == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 1>), dim3(grid), dim3(256), 0, s, p);
+  else if (p.G <= 3) hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 3>), dim3(grid), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 4>), dim3(grid), dim3(256), 0, s, p);
 }
 
 static int norm_common(const UssegNormDesc* d, NormParams& p) {
@@ -259,8 +290,7 @@ extern "C" int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const f
   p.ldx = d->ldx; p.ldy = d->ldy;
   if (p.M <= 0) return USSEG_OK;
   int ppb = 4 * (64 / p.LPP);
-  if (p.mode == 0) hipLaunchKernelGGL((norm_act_kernel<false, 0>), dim3(grid_for(p.M, ppb * 4)), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((norm_act_kernel<false, 1>), dim3(grid_for(p.M, ppb * 4)), dim3(256), 0, (hipStream_t)stream, p);
+  norm_launch<false>(p, grid_for(p.M, ppb * 4), (hipStream_t)stream);
   return usseg_check_launch("norm_act_fwd");
 }
 
@@ -282,8 +312,7 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   // small tensors are latency bound (each loop trip is a dependent load -> store): spread them over many workgroups
   unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
   p.ws = ws = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * 3 * p.Cphys);
-  if (p.mode == 0) hipLaunchKernelGGL((norm_act_kernel<true, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((norm_act_kernel<true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  norm_launch<true>(p, grid, (hipStream_t)stream);
   usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
   return usseg_check_launch("norm_act_bwd");
 }
