@@ -80,6 +80,14 @@ int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp_dg
 int usseg_conv2d_wgrad(const UssegConvDesc* d, const void* x, const void* dy, float* dw_scratch, float* ws,
                        int64_t ws_floats, usseg_stream_t stream);
 
+/* Backward-data of several parallel convolutions that read the SAME input (Decoder.py:67-75,79-87: conv*_1 1x1 and the three
+ * dilated 3x3 convs) in one pass: dx = sum_b dgrad_b(dy[..., ch_off[b] : ch_off[b]+Cb]).  d: B,H,W, Cin/ldx of dx, ldy = channel
+ * stride of the concatenated dy tensor.  wp_cat: bf16 [roundup(Cin,16)][Ktot], Ktot = sum_b ksize_b^2 * Cb, branch b's taps at
+ * columns (taps before b)*Cb + tap*Cb + co (tap = kh*k + kw of the forward kernel).  At most 32 taps in total. */
+int usseg_conv2d_dgrad_branches(const UssegConvDesc* d, int32_t nbranches, const int32_t* ksize, const int32_t* dilation,
+                                const int32_t* ch_off, int32_t Cb, const void* dy, const void* wp_cat, const void* residual,
+                                int32_t ldr, void* dx, usseg_stream_t stream);
+
 /* Weight gradient written straight into the framework's variables: up to 4 rectangular blocks of the physical
  * [ntaps][Cin_phys][Cout_phys] gradient go to strided destinations (Keras kernel [k,k,Cin,Cout] / [k,k,Cout,Cin] with the
  * LOGICAL channel counts; one block per cardinal path for the block-diagonal grouped convs, ResNest.py:91-96).  Elements

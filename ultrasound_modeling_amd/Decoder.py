@@ -8,6 +8,7 @@ state) are copied in.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -17,6 +18,9 @@ from . import ops
 from .layers import (KERAS_BN_EPS, KERAS_LRELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, LayerNormalization,
                      LeakyReLU)
 from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
+
+
+_FUSED_DGRAD = os.environ.get("USSEG_FUSED_DGRAD", "1") != "0"
 
 
 class DecoderBlock(nn.Module):
@@ -70,6 +74,26 @@ class DecoderBlock(nn.Module):
                                 dgamma=span(bns[0].gamma.grad), dbeta=span(bns[0].beta.grad), dbias=span(c0.bias.grad))
             for a_, b_ in zip(bns[:-1], bns[1:]):
                 assert b_.gamma.data_ptr() == a_.gamma.data_ptr() + 4 * q and b_.beta.data_ptr() == a_.beta.data_ptr() + 4 * q
+        # backward-data operand of a stage's four branches, concatenated along K (one implicit GEMM, dx written once)
+        self._wd_cat = {}
+        for st in ("1", "2"):
+            cin_p = getattr(self, f"conv{st}_0").cin_p
+            self._wd_cat[st] = torch.zeros((roundup(cin_p, 16), 28 * q), dtype=BF16, device=device)
+        ops.pack_weights_batched(ops.make_pack_table(self.pack_jobs(), device), len(self.pack_jobs()))
+
+    def pack_jobs(self):
+        """Pack jobs of the concatenated backward-data operands (the per-conv operands are packed by the Conv2D layers)."""
+        q = self.out_channels // 4
+        jobs = []
+        for st in ("1", "2"):
+            base = 0
+            for j in range(4):
+                c = getattr(self, f"conv{st}_{j}")
+                T = c.k * c.k
+                sT, sI, sO = c._strides_tio()
+                jobs.append(ops.pack_job(c.kernel.data, sT, sI, sO, T, c.cin, c.cout, self._wd_cat[st], 28 * q, q, 0, base))
+                base += T * q
+        return jobs
 
     def _bn_fwd(self, st, raw, out):
         d = self._bn[st]
@@ -101,8 +125,12 @@ class DecoderBlock(nn.Module):
         dys = [draw[..., j * q:(j + 1) * q] for j in range(4)]
         with ops.side_stream(convs[1]._x, draw):
             ops.conv2d_wgrad_multi([convs[j].wgrad_job(dys[j]) for j in (1, 2, 3)])
-        for j in range(4):
-            convs[j].backward(dys[j], dx=dx, accumulate_dx=(j > 0), skip_bias=True, skip_wgrad=(j > 0))
+        convs[0].backward(dys[0], need_dx=False, skip_bias=True)
+        if _FUSED_DGRAD:
+            ops.conv2d_dgrad_branches(draw, self._wd_cat[st], [c.k for c in convs], [c.dil for c in convs], [j * q for j in range(4)], q, dx)
+        else:
+            for j in range(4):
+                ops.conv2d_dgrad(dys[j], convs[j].wp_d, convs[j].k, convs[j].dil, dx, None, j > 0)
 
     def forward(self, x, skip=None, out=None):
         """x [B,h,w,in]; skip [B,2h,2w,skip] or None; ``out``: optional [B,2h,2w,oc] slice to write the result into."""

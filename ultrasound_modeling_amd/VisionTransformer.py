@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .Decoder import DecoderCup
+from .Decoder import DecoderBlock, DecoderCup
 from .flat import AdamClip, FlatParams
 from .layers import BatchNormalization, Conv2D, LayerNormalization, _Workspace
 from .ResNest import ResNest, cardinal, residual_S
@@ -40,7 +40,7 @@ def repack_all(root: nn.Module):
             elif isinstance(m, cardinal):
                 if m._solo is not None:
                     jobs += m._solo.pack_jobs()
-            elif isinstance(m, Attention):
+            elif isinstance(m, (Attention, DecoderBlock)):
                 jobs += m.pack_jobs()
             elif isinstance(m, Conv2D) and m.wp_f is not None:
                 jobs += m.pack_jobs()

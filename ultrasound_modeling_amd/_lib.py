@@ -88,6 +88,7 @@ _PROTOS = {
     "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "usseg_conv2d_wgrad_mapped": (C.c_int, [P(ConvDesc), c_vp, c_vp, P(WgradDst), c_vp, c_i64, c_vp]),
     "usseg_tconv2d_wgrad_mapped": (C.c_int, [P(ConvDesc), c_vp, c_vp, P(WgradDst), c_vp, c_i64, c_vp]),
+    "usseg_conv2d_dgrad_branches": (C.c_int, [P(ConvDesc), c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_conv2d_wgrad_multi": (C.c_int, [c_i32, c_vp, c_vp, c_i64, c_vp]),
     "usseg_conv2d_fwd_multi": (C.c_int, [c_i32, c_vp, c_vp]),
     "usseg_conv2d_dgrad_multi": (C.c_int, [c_i32, c_vp, c_vp]),

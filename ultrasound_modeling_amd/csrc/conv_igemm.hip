@@ -34,7 +34,7 @@ struct IgemmParams {
   float alpha;
   int32_t out_f32;
   int32_t accumulate;
-  int16_t tap_dy[16], tap_dx[16], tap_w[16];
+  int16_t tap_dy[32], tap_dx[32], tap_w[32], tap_c[32];   // per tap: source offset, weight tap index, source channel base
   // Conv2DTranspose forward: the four output-parity classes run as blockIdx.z of ONE launch; class c owns the tap-table
   // entries [4c, 4c+4) (cls_ntaps[c] of them) and writes output pixels (2*gy + (c>>1), 2*gx + (c&1)).
   int32_t cls_mode;
@@ -49,14 +49,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int BM = 128, BN = 16 * NT, LDSS = 40;  // LDS row stride in elements (64 B data + 16 B pad)
   constexpr int WCH = (BN * 4 + 255) / 256;         // weight chunks per thread per K step
   __shared__ __attribute__((aligned(16))) bf16_t lds[2][(BM + BN) * LDSS];
-  __shared__ int s_tap[48];
+  __shared__ int s_tap[128];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
-  if (tid < 16) {
+  if (tid < 32) {
     s_tap[tid] = p.tap_dy[tid];
-    s_tap[16 + tid] = p.tap_dx[tid];
-    s_tap[32 + tid] = p.tap_w[tid];
+    s_tap[32 + tid] = p.tap_dx[tid];
+    s_tap[64 + tid] = p.tap_w[tid];
+    s_tap[96 + tid] = p.tap_c[tid];
   }
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
@@ -100,14 +101,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   auto load_step = [&]() {
     const bool tv = ti < ntaps;
-    int dy = 0, dx = 0, tw = 0;
-    if (tv) { dy = s_tap[tbase + ti]; dx = s_tap[16 + tbase + ti]; tw = s_tap[32 + tbase + ti]; }
+    int dy = 0, dx = 0, tw = 0, tc = 0;
+    if (tv) { dy = s_tap[tbase + ti]; dx = s_tap[32 + tbase + ti]; tw = s_tap[64 + tbase + ti]; tc = s_tap[96 + tbase + ti]; }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint4 v = make_uint4(0, 0, 0, 0);
       int iy = py[h] + dy, ix = px[h] + dx;
       if (tv && pv[h] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-        const bf16_t* src = xbase + ((int64_t)(pb[h] + iy) * p.Wi + ix) * p.ldx + c8 * 8;
+        const bf16_t* src = xbase + ((int64_t)(pb[h] + iy) * p.Wi + ix) * p.ldx + tc + c8 * 8;
         v = *reinterpret_cast<const uint4*>(src);
       }
       ra[h] = v;
@@ -354,6 +355,42 @@ extern "C" int usseg_conv2d_fwd_multi(int32_t njobs, const UssegConvJob* jobs, u
 }
 extern "C" int usseg_conv2d_dgrad_multi(int32_t njobs, const UssegConvJob* jobs, usseg_stream_t stream) {
   return conv_multi(njobs, jobs, 1, stream);
+}
+
+// dx = sum over parallel conv branches of their backward-data passes, as ONE implicit GEMM whose K axis walks every
+// (branch, tap, channel): dx is written once instead of once + a read-modify-write per further branch (for the 128-channel,
+// 128x128 decoder stage that is 470 MB of traffic -> 100 MB).
+extern "C" int usseg_conv2d_dgrad_branches(const UssegConvDesc* d, int32_t nbranches, const int32_t* ksize, const int32_t* dilation,
+                                           const int32_t* ch_off, int32_t Cb, const void* dy, const void* wp_cat, const void* residual,
+                                           int32_t ldr, void* dx, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && ksize && dilation && ch_off && dy && wp_cat && dx, "null pointer");
+  USSEG_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "bad geometry");
+  USSEG_CHECK_ARG(nbranches >= 1 && Cb > 0 && Cb % 8 == 0, "dgrad_branches: Cb must be a multiple of 8");
+  IgemmParams p = {};
+  p.x = (const bf16_t*)dy; p.w = (const bf16_t*)wp_cat; p.y = dx; p.bias = nullptr; p.res = (const bf16_t*)residual; p.ldr = ldr;
+  p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
+  p.Hi = d->H; p.Wi = d->W; p.ldx = d->ldy; p.isy = p.isx = 1;
+  p.Ho = d->H; p.Wo = d->W; p.ldy = d->ldx; p.osy = p.osx = 1; p.oay = p.oax = 0;
+  p.cpt = Cb / 8;
+  int t = 0;
+  for (int b = 0; b < nbranches; ++b) {
+    const int k = ksize[b], half = k / 2;
+    USSEG_CHECK_ARG((k == 1 || k == 3) && dilation[b] >= 1 && ch_off[b] % 8 == 0 && ch_off[b] + Cb <= d->ldy, "dgrad_branches: bad branch");
+    for (int kh = 0; kh < k; ++kh)
+      for (int kw = 0; kw < k; ++kw) {
+        USSEG_CHECK_ARG(t < 32, "dgrad_branches: at most 32 taps in total");
+        p.tap_dy[t] = (int16_t)(-(kh - half) * dilation[b]);     // y[p] uses x[p + off]  =>  dx[q] gathers dy[q - off]
+        p.tap_dx[t] = (int16_t)(-(kw - half) * dilation[b]);
+        p.tap_w[t] = (int16_t)t;                                  // K index = (running tap)*Cb + co in the concatenated operand
+        p.tap_c[t] = (int16_t)ch_off[b];
+        ++t;
+      }
+  }
+  p.ntaps = t;
+  p.nchunks = p.ntaps * p.cpt;
+  p.Nw = roundup(d->Cin, 16); p.Kw = p.ntaps * Cb; p.Nout = d->Cin;
+  p.act = USSEG_ACT_NONE; p.alpha = 0.f; p.out_f32 = 0; p.accumulate = (d->flags & USSEG_ACCUMULATE) ? 1 : 0;
+  return launch_igemm(p, (hipStream_t)stream);
 }
 
 // Conv2DTranspose stride 2 'same': out[2i + kh - pad] += x[i] * w[kh], pad = 0 (k=3, crop end) / 1 (k=4).

@@ -261,6 +261,19 @@ def conv2d_wgrad_mapped(x, dy, ksize, dilation, dst_map):
                                                _stream()), "conv2d_wgrad_mapped")
 
 
+def conv2d_dgrad_branches(dy_cat, wp_cat, ksizes, dilations, ch_offs, Cb, dx, residual=None, accumulate=False):
+    """dx = sum over the parallel branches of their backward-data passes (one implicit GEMM over every branch's taps)."""
+    B, H, W, _, ldy = geom(dy_cat)
+    _, _, _, Cin, ldx = geom(dx)
+    d = _conv_desc(B, H, W, Cin, Cb, ldx, ldy, 3, 1, flags=ACCUMULATE if accumulate else 0)
+    n = len(ksizes)
+    arr = lambda v: (C.c_int32 * n)(*v)
+    ldr = geom(residual)[4] if residual is not None else 0
+    L.check(L.load().usseg_conv2d_dgrad_branches(C.byref(d), n, arr(ksizes), arr(dilations), arr(ch_offs), Cb, dy_cat.data_ptr(),
+                                                 wp_cat.data_ptr(), _ptr(residual), ldr, dx.data_ptr(), _stream()), "conv2d_dgrad_branches")
+    return dx
+
+
 def conv2d_wgrad_multi(jobs):
     """jobs: list of (x, dy, ksize, dilation, dw or None, dst_map or None): independent weight gradients, one launch where possible."""
     arr = (L.WgradJob * len(jobs))()
