@@ -79,6 +79,7 @@ struct WJob {
 };
 struct WBatch {
   int32_t njobs, pad;
+  int32_t start[16];   // first flat workgroup id of each job (start[njobs] = total): no empty workgroups in the grid
   WJob job[14];
 };
 
@@ -131,9 +132,11 @@ __device__ __forceinline__ void wgrad_finish_body(const WJob& q, int bx, int by)
 }
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WJob q) { wgrad_finish_body(q, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(256) void wgrad_finish_batched_kernel(const WBatch b) {
-  const WJob& q = b.job[blockIdx.z];
-  if ((int)blockIdx.x >= q.gx || (int)blockIdx.y >= q.gy) return;
-  wgrad_finish_body(q, blockIdx.x, blockIdx.y);
+  int j = 0;
+  while (j + 1 < b.njobs && (int)blockIdx.x >= b.start[j + 1]) ++j;
+  const WJob& q = b.job[j];
+  const int local = blockIdx.x - b.start[j];
+  wgrad_finish_body(q, local % q.gx, local / q.gx);
 }
 
 // ------------------------------------------------------------------------------------------ deferral context (host)
@@ -169,14 +172,15 @@ static void flush_reduce(DeferCtx& c) {
 static void flush_wgrad(DeferCtx& c) {
   for (size_t i = 0; i < c.wj.size(); i += 14) {
     WBatch b = {};
-    int gx = 1, gy = 1;
+    int total = 0;
     b.njobs = (int)(c.wj.size() - i < 14 ? c.wj.size() - i : 14);
     for (int j = 0; j < b.njobs; ++j) {
       b.job[j] = c.wj[i + j];
-      if (b.job[j].gx > gx) gx = b.job[j].gx;
-      if (b.job[j].gy > gy) gy = b.job[j].gy;
+      b.start[j] = total;
+      total += b.job[j].gx * b.job[j].gy;
     }
-    hipLaunchKernelGGL(wgrad_finish_batched_kernel, dim3(gx, gy, b.njobs), dim3(256), 0, c.s, b);
+    b.start[b.njobs] = total;
+    hipLaunchKernelGGL(wgrad_finish_batched_kernel, dim3(total), dim3(256), 0, c.s, b);
   }
   c.wj.clear();
   c.wused = 0;

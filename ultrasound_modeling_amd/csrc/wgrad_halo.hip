@@ -246,7 +246,8 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   // re-read within a few times the bytes of the operands themselves.  (Sending the deep layers back to the per-tap
   // kernel, or capping at 1x, was measured slower: 7.5 vs 6.9 ms/step.)
   const int64_t in_bytes = (int64_t)gm[0].B * gm[0].H * gm[0].W * (Ma + Nb) * 2, slab_bytes = slab * 4;
-  int splits = (512 + tiles * njobs - 1) / (tiles * njobs);
+  static const int wg_target = getenv("USSEG_WG_TARGET") ? atoi(getenv("USSEG_WG_TARGET")) : 512;
+  int splits = (wg_target + tiles * njobs - 1) / (tiles * njobs);
   int max_splits = (ngroups + 1) / 2;
   const int64_t traffic_cap = 8 * in_bytes / slab_bytes < 4 ? 4 : 8 * in_bytes / slab_bytes;
   if (max_splits > traffic_cap) max_splits = (int)traffic_cap;
