@@ -130,6 +130,16 @@ extern "C" int64_t usseg_splitattn_ws_floats(const UssegSplitAttnDesc* d) {
   return (int64_t)d->B * d->P * (d->Cg + 2 * d->Hd);
 }
 
+// sum / max over up to 128 LDS floats by wave 0 (the serial tid==0 loops were 64-128 dependent LDS round trips each)
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int msk = 32; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int msk = 32; msk >= 1; msk >>= 1) v = fmaxf(v, __shfl_xor(v, msk, 64));
+  return v;
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
   const UssegSplitAttnDesc& d = a.d;
@@ -153,22 +163,18 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
   // dense1 (ResNest.py:182)
   for (int j = tid; j < Hd; j += 128) {
     float v = a.p.b1[p * Hd + j];
+#pragma unroll 8
     for (int c = 0; c < Cg; ++c) v += gin[c] * w1[c * Hd + j];
     h1[j] = v;
   }
   __syncthreads();
-  // norm (LN over Hd, ResNest.py:183 / BN inference, TBI_ResNest.py:190) + act
-  if (tid == 0) {
-    if (d.norm_mode == 0) {
-      float mu = 0.f;
-      for (int j = 0; j < Hd; ++j) mu += h1[j];
-      mu /= (float)Hd;
-      float var = 0.f;
-      for (int j = 0; j < Hd; ++j) var += (h1[j] - mu) * (h1[j] - mu);
-      var /= (float)Hd;
-      red[0] = mu;
-      red[1] = rsqrtf(var + d.eps);
-    }
+  // norm (LN over Hd <= 64, ResNest.py:183 / BN inference, TBI_ResNest.py:190) + act
+  if (tid < 64 && d.norm_mode == 0) {
+    float hv = tid < Hd ? h1[tid] : 0.f;
+    float mu = wave_sum(hv) / (float)Hd;
+    float dv = tid < Hd ? hv - mu : 0.f;
+    float var = wave_sum(dv * dv) / (float)Hd;
+    if (tid == 0) { red[0] = mu; red[1] = rsqrtf(var + d.eps); }
   }
   __syncthreads();
   for (int j = tid; j < Hd; j += 128) {
@@ -189,17 +195,16 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
       for (int c = tid; c < Cg; c += 128) {
         float v = a.p.b2[(p * R + r) * Cg + c];
         const float* w = w2 + (int64_t)r * Hd * Cg;
+#pragma unroll 8
         for (int j = 0; j < Hd; ++j) v += av[j] * w[j * Cg + c];
         z[c] = v;
       }
       __syncthreads();
-      if (tid == 0) {
-        float mx = -INFINITY;
-        for (int c = 0; c < Cg; ++c) mx = fmaxf(mx, z[c]);
-        float sum = 0.f;
-        for (int c = 0; c < Cg; ++c) sum += __expf(z[c] - mx);
-        red[2] = mx;
-        red[3] = 1.f / sum;
+      if (tid < 64) {   // Cg <= 128: two channels per lane
+        float z0 = tid < Cg ? z[tid] : -INFINITY, z1 = tid + 64 < Cg ? z[tid + 64] : -INFINITY;
+        float mx = wave_max(fmaxf(z0, z1));
+        float sum = wave_sum((tid < Cg ? __expf(z0 - mx) : 0.f) + (tid + 64 < Cg ? __expf(z1 - mx) : 0.f));
+        if (tid == 0) { red[2] = mx; red[3] = 1.f / sum; }
       }
       __syncthreads();
       for (int c = tid; c < Cg; c += 128) {
@@ -213,11 +218,11 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
     for (int r = 0; r < R; ++r) {
       const float* sv = a.s + ((int64_t)(b * d.P + p) * R + r) * Cg;
       const float* dsv = a.ds + (int64_t)b * Cy + (p * R + r) * Cg;
-      if (tid == 0) {
-        float dot = 0.f;
-        if (!d.use_sigmoid)
-          for (int c = 0; c < Cg; ++c) dot += dsv[c] * sv[c];
-        red[2] = dot;
+      if (tid < 64) {
+        float t0 = (!d.use_sigmoid && tid < Cg) ? dsv[tid] * sv[tid] : 0.f;
+        float t1 = (!d.use_sigmoid && tid + 64 < Cg) ? dsv[tid + 64] * sv[tid + 64] : 0.f;
+        float dot = wave_sum(t0 + t1);
+        if (tid == 0) red[2] = dot;
       }
       __syncthreads();
       for (int c = tid; c < Cg; c += 128) {
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
     for (int j = tid; j < Hd; j += 128) {
       float v = 0.f;
       for (int r = 0; r < R; ++r)
+#pragma unroll 8
         for (int c = 0; c < Cg; ++c) v += w2[((int64_t)r * Hd + j) * Cg + c] * dz[r * 128 + c];
       da[j] = v;
     }
@@ -252,11 +258,10 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
     }
     __syncthreads();
     if (d.norm_mode == 0) {
-      if (tid == 0) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int j = 0; j < Hd; ++j) { s1 += dh[j]; s2 += dh[j] * xh[j]; }
-        red[2] = s1 / (float)Hd;
-        red[3] = s2 / (float)Hd;
+      if (tid < 64) {
+        float dj = tid < Hd ? dh[tid] : 0.f, xj = tid < Hd ? xh[tid] : 0.f;
+        float s1 = wave_sum(dj), s2 = wave_sum(dj * xj);
+        if (tid == 0) { red[2] = s1 / (float)Hd; red[3] = s2 / (float)Hd; }
       }
       __syncthreads();
       for (int j = tid; j < Hd; j += 128) dh[j] = red[1] * (dh[j] - red[2] - xh[j] * red[3]);
@@ -272,6 +277,7 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
     // d g_sum[b][(p*R+r)*Cg + c] = mult/HW * sum_j w1[c][j] dh[j]
     for (int c = tid; c < Cg; c += 128) {
       float v = 0.f;
+#pragma unroll 8
       for (int j = 0; j < Hd; ++j) v += w1[c * Hd + j] * dh[j];
       v *= gscale;
       for (int r = 0; r < R; ++r) a.dg[(int64_t)b * Cy + (p * R + r) * Cg + c] = v;
