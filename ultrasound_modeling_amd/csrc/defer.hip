@@ -180,7 +180,9 @@ static void flush_wgrad(DeferCtx& c) {
       total += b.job[j].gx * b.job[j].gy;
     }
     b.start[b.njobs] = total;
+    const int slot = usseg_prof_start(2, c.s);     // counted with the weight-gradient kernels it finishes
     hipLaunchKernelGGL(wgrad_finish_batched_kernel, dim3(total), dim3(256), 0, c.s, b);
+    usseg_prof_stop(2, slot, c.s);
   }
   c.wj.clear();
   c.wused = 0;
