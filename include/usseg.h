@@ -301,9 +301,21 @@ typedef struct UssegLossDesc {
   float label_smoothing;
   float clip_eps;       /* 1e-7 */
   float inv_global_batch;
+  int32_t quad_w;       /* 0: logits/dlogits are [M][ldl]; W (full-resolution width): they are in the space-to-depth layout
+                           [B][H/2][W/2][16] that the 2x2-tap form of the stride-2 head produces, pixel (y,x) in slot
+                           4*((y&1)*2+(x&1)) (ldl = lddl = 16, C <= 4).  probs and y_true are always [M][C]. */
 } UssegLossDesc;
 int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, const float* y_true, const float* scale,
                                float* probs, float* loss, void* dlogits, usseg_stream_t stream);
+/* The 3-class head Conv2DTranspose(3x3, stride 2) (Decoder.py:120) in "quad" form: a 2x2-tap stride-1 convolution at the INPUT
+ * resolution whose 16 output channels are (output parity class)*4 + n, run by usseg_conv2d_fwd/dgrad/wgrad as a 3x3 conv with
+ * five all-zero taps.  These helpers move the bias and the gradients between the Keras variables and that form:
+ * bias16[cls*4+n] = bias[n];  dbias[n] += sum_cls d16[cls*4+n];  grad[kh][kw][n][c] += dq[tap][c][cls*4+n] with
+ * tap = stencil index of offset (-(kh>>1), -(kw>>1)), cls = (kh&1)*2 + (kw&1), dq = [9][Cin_phys][16]. */
+int usseg_quad_bias_expand(const float* bias, int32_t C, float* bias16, usseg_stream_t stream);
+int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, usseg_stream_t stream);
+int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, float* grad, usseg_stream_t stream);
+
 /* my_loss_cat scale[hw][c] = 1/(sum_b y[b,hw,c] + 1)/(H*W)  (TBI_ResNest.py:240-241) */
 int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, int32_t C, float* scale, usseg_stream_t stream);
 

@@ -28,3 +28,9 @@ if graph:
     t(lambda: net.capture_graph(x, y), "capture")
     for i in range(5):
         t(lambda: net.train_step(x, y), f"graph step {i}")
+    import statistics
+    ts = []
+    for i in range(30):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); net.train_step(x, y); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(f"graph: min {min(ts):.3f} ms  median {statistics.median(ts):.3f} ms", flush=True)

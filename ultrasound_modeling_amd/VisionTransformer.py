@@ -40,7 +40,7 @@ def repack_all(root: nn.Module):
             elif isinstance(m, cardinal):
                 if m._solo is not None:
                     jobs += m._solo.pack_jobs()
-            elif isinstance(m, (Attention, DecoderBlock)):
+            elif isinstance(m, (Attention, DecoderBlock, DecoderCup)):
                 jobs += m.pack_jobs()
             elif isinstance(m, Conv2D) and m.wp_f is not None:
                 jobs += m.pack_jobs()
@@ -339,12 +339,16 @@ class VisionTransformer(nn.Module):
     def _forward_loss(self, x, y, with_grad: bool):
         hidden, _, features = self.transformer.forward(x)
         logits = self.decoder.forward(hidden, features, return_logits=True)
-        B, H, W, _ = logits.shape
+        B = logits.shape[0]
+        H, W = self.decoder.out_hw
+        qw = self.decoder.quad_w                 # head in quad form: logits / dlogits are [B,H/2,W/2,16]
         probs = torch.empty((B, H, W, self.num_classes), dtype=torch.float32, device=self.device)
-        dlogits = ops.new_act(B, H, W, 8, self.device) if with_grad else None
+        dlogits = None
+        if with_grad:
+            dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device, zero=True) if qw else ops.new_act(B, H, W, 8, self.device)
         ops.fill_f32(self._loss, 0.0)
         ops.softmax_loss(logits, y, probs, self._loss, dlogits, HW=H * W, C_classes=self.num_classes, loss_kind=0,
-                         label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=1.0 / float(self.batch_size))   # :205,:227
+                         label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=1.0 / float(self.batch_size), quad_w=qw)   # :205,:227
         return probs, dlogits
 
     def compute_loss(self, y_true, y_pred):

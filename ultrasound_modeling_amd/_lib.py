@@ -72,7 +72,7 @@ class GemmDesc(C.Structure):
 
 class LossDesc(C.Structure):
     _fields_ = [("M", c_i64), ("HW", c_i32), ("C", c_i32), ("ldl", c_i32), ("lddl", c_i32), ("loss_kind", c_i32),
-                ("label_smoothing", c_f32), ("clip_eps", c_f32), ("inv_global_batch", c_f32)]
+                ("label_smoothing", c_f32), ("clip_eps", c_f32), ("inv_global_batch", c_f32), ("quad_w", c_i32)]
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU, ACT_GELU = 0, 1, 2, 3, 4
@@ -122,6 +122,9 @@ _PROTOS = {
                                           P(SplitAttnGrads), c_vp]),
     "usseg_splitattn_apply_bwd_dy": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "usseg_softmax_loss_fwd_bwd": (C.c_int, [P(LossDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_quad_bias_expand": (C.c_int, [c_vp, c_i32, c_vp, c_vp]),
+    "usseg_quad_bias_fold": (C.c_int, [c_vp, c_i32, c_vp, c_vp]),
+    "usseg_tconv_quad_unpack": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "usseg_loss_cat_scale": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "usseg_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "usseg_sumsq": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),

@@ -412,7 +412,19 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const UssegLossDesc d
   for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < d.M; m += (int64_t)gridDim.x * 256) {
     float z[8], p[8], yt[8];
     float mx = -INFINITY;
-    for (int c = 0; c < C; ++c) { z[c] = logits[m * d.ldl + c]; mx = fmaxf(mx, z[c]); }
+    // quad (space-to-depth) layout of the head's output and its gradient: pixel (y, x) of the full-resolution map lives in
+    // slot 4*((y&1)*2 + (x&1)) of the 16-channel pixel (y/2, x/2) - what the 2x2-tap form of the stride-2 head produces
+    int64_t lbase = m * d.ldl, dbase = m * d.lddl;
+    if (d.quad_w) {
+      const int hw = (int)(m % d.HW);
+      const int64_t b = m / d.HW;
+      const int y = hw / d.quad_w, x = hw - y * d.quad_w;
+      const int64_t q = (b * (d.HW / d.quad_w / 2) + (y >> 1)) * (d.quad_w / 2) + (x >> 1);
+      const int slot = 4 * ((y & 1) * 2 + (x & 1));
+      lbase = q * d.ldl + slot;
+      dbase = q * d.lddl + slot;
+    }
+    for (int c = 0; c < C; ++c) { z[c] = logits[lbase + c]; mx = fmaxf(mx, z[c]); }
     float sum = 0.f;
     for (int c = 0; c < C; ++c) { p[c] = __expf(z[c] - mx); sum += p[c]; }
     float inv = 1.f / sum;
@@ -452,7 +464,13 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const UssegLossDesc d
       float o[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) o[c] = (c < C) ? p[c] * (dLdp[c] - dot) : 0.f;
-      *reinterpret_cast<uint4*>(dlogits + m * d.lddl) = pack8(o);
+      if (d.quad_w) {
+        uint2 v;
+        v.x = pack2bf(o[0], o[1]); v.y = pack2bf(o[2], o[3]);
+        *reinterpret_cast<uint2*>(dlogits + dbase) = v;
+      } else {
+        *reinterpret_cast<uint4*>(dlogits + dbase) = pack8(o);
+      }
     }
   }
   if (y_true && d.loss_kind == 0) {
@@ -468,7 +486,9 @@ extern "C" int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* l
   USSEG_CHECK_ARG(d && logits && probs, "null pointer");
   USSEG_CHECK_ARG(d->C >= 1 && d->C <= 8 && d->ldl >= d->C, "softmax_loss: 1 <= C <= 8");
   USSEG_CHECK_ARG(!y_true || loss, "loss pointer required with y_true");
-  USSEG_CHECK_ARG(!dlogits || (d->lddl == 8), "dlogits stride must be 8");
+  USSEG_CHECK_ARG(d->quad_w == 0 || (d->C <= 4 && d->ldl == 16 && d->quad_w % 2 == 0 && d->HW % (2 * d->quad_w) == 0),
+                  "softmax_loss: quad layout needs C <= 4, ldl == 16, even H and W");
+  USSEG_CHECK_ARG(!dlogits || (d->lddl == (d->quad_w ? 16 : 8)), "dlogits stride must be 8 (16 in the quad layout)");
   USSEG_CHECK_ARG(d->loss_kind == 0 || (d->loss_kind == 1 && scale), "loss_kind 1 needs scale");
   if (d->M <= 0) return USSEG_OK;
   int64_t g = cdiv64(d->M, 256 * 4);

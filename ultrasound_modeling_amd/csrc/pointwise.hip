@@ -618,6 +618,46 @@ extern "C" int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t 
   return usseg_check_launch("pack_weights_batched");
 }
 
+// ---- the stride-2 3x3 head as a 2x2-tap convolution producing its four output parities as 16 channels ("quad" form):
+// out[2i+a, 2j+b, n] = sum over (di,dj) in {0,-1}^2 of x[i+di, j+dj, :] . W[a-2di][b-2dj][n][:]   (terms with a tap index > 2 vanish)
+// The conv kernels run it as an ordinary 3x3 conv with Cout = 16 = (parity class)*4 + n; these three helpers move the
+// bias and the gradients between the Keras variables (kernel [3,3,Cout,Cin], bias [Cout]) and that form.
+__global__ void quad_bias_expand_kernel(const float* bias, int C, float* bias16) {
+  int i = threadIdx.x;
+  if (i < 16) bias16[i] = (i & 3) < C ? bias[i & 3] : 0.f;
+}
+__global__ void quad_bias_fold_kernel(const float* d16, int C, float* dbias) {
+  int n = threadIdx.x;
+  if (n < C) dbias[n] += d16[n] + d16[4 + n] + d16[8 + n] + d16[12 + n];
+}
+// grad[kh][kw][n][c] += dq[tap(kh,kw)][c][class(kh,kw)*4 + n],  dq = [9][Cin_phys][16] (the 3x3-conv weight gradient of the quad form)
+__global__ __launch_bounds__(256) void tconv_quad_unpack_kernel(const float* dq, int Cin_phys, int Cin, int Cout, float* grad) {
+  const int total = 9 * Cout * Cin;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int c = i % Cin, r = i / Cin;
+    int n = r % Cout, kk = r / Cout;
+    int kh = kk / 3, kw = kk - 3 * kh;
+    int t = (1 - (kh >> 1)) * 3 + (1 - (kw >> 1));          // stencil tap of offset (di,dj) = (-(kh>>1), -(kw>>1))
+    int cls = (kh & 1) * 2 + (kw & 1);
+    grad[i] += dq[((int64_t)t * Cin_phys + c) * 16 + cls * 4 + n];
+  }
+}
+extern "C" int usseg_quad_bias_expand(const float* bias, int32_t C, float* bias16, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(bias && bias16 && C >= 1 && C <= 4, "quad_bias_expand: bad args");
+  hipLaunchKernelGGL(quad_bias_expand_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bias, C, bias16);
+  return usseg_check_launch("quad_bias_expand");
+}
+extern "C" int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d16 && dbias && C >= 1 && C <= 4, "quad_bias_fold: bad args");
+  hipLaunchKernelGGL(quad_bias_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d16, C, dbias);
+  return usseg_check_launch("quad_bias_fold");
+}
+extern "C" int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, float* grad, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dq && grad && Cin >= 1 && Cin <= Cin_phys && Cout >= 1 && Cout <= 4, "tconv_quad_unpack: bad args");
+  hipLaunchKernelGGL(tconv_quad_unpack_kernel, dim3((9 * Cout * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, dq, Cin_phys, Cin, Cout, grad);
+  return usseg_check_launch("tconv_quad_unpack");
+}
+
 // ---- dropout mask (tf.nn.dropout(x, rate), TBI_ResNest.py:216): mask[m][c] = keep ? 1/(1-rate) : 0, counter-based hash RNG
 __device__ __forceinline__ uint32_t hash32(uint64_t v) {
   v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;

@@ -536,13 +536,26 @@ def splitattn_bwd(d: SplitAttnDesc, y, dout, params, grads, g, s, ws, dy):
 
 # ------------------------------------------------------------------------------------------------ head softmax + loss
 def softmax_loss(logits, y_true, probs, loss, dlogits, *, HW, C_classes, loss_kind=0, label_smoothing=0.1, clip_eps=1e-7,
-                 inv_global_batch=1.0, scale=None):
-    """logits fp32 [..., ldl]; y_true fp32 [..., C] or None; probs fp32 [..., C]; dlogits bf16 [..., 8] or None."""
+                 inv_global_batch=1.0, scale=None, quad_w=0):
+    """logits fp32 [..., ldl]; y_true fp32 [..., C] or None; probs fp32 [..., C]; dlogits bf16 [..., 8] or None.
+    ``quad_w`` = full-resolution width when logits / dlogits are in the head's space-to-depth layout [B,H/2,W/2,16]."""
     M = probs.numel() // C_classes
     ldl = logits.shape[-1]
-    d = LossDesc(M, HW, C_classes, ldl, 8, loss_kind, label_smoothing, clip_eps, inv_global_batch)
+    d = LossDesc(M, HW, C_classes, ldl, 16 if quad_w else 8, loss_kind, label_smoothing, clip_eps, inv_global_batch, quad_w)
     L.check(L.load().usseg_softmax_loss_fwd_bwd(C.byref(d), logits.data_ptr(), _ptr(y_true), _ptr(scale), probs.data_ptr(), _ptr(loss),
                                                 _ptr(dlogits), _stream()), "softmax_loss")
+
+
+def quad_bias_expand(bias, C_classes, bias16):
+    L.check(L.load().usseg_quad_bias_expand(bias.data_ptr(), C_classes, bias16.data_ptr(), _stream()), "quad_bias_expand")
+
+
+def quad_bias_fold(d16, C_classes, dbias):
+    L.check(L.load().usseg_quad_bias_fold(d16.data_ptr(), C_classes, dbias.data_ptr(), _stream()), "quad_bias_fold")
+
+
+def tconv_quad_unpack(dq, Cin_phys, Cin, Cout, grad):
+    L.check(L.load().usseg_tconv_quad_unpack(dq.data_ptr(), Cin_phys, Cin, Cout, grad.data_ptr(), _stream()), "tconv_quad_unpack")
 
 
 def loss_cat_scale(y_true, scale):
