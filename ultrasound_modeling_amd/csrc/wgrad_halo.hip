@@ -28,7 +28,9 @@ struct WgHaloMulti {
   WgHaloParams job[4];
 };
 
-template <int WVM, int WM, int WN>
+// PF: the next pixel group's operands are loaded into registers while the current group computes (the small tile shapes
+// have the registers for it; without it a group is a serial load -> LDS -> barrier -> MFMA chain of ~4 us).
+template <int WVM, int WM, int WN, bool PF>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P) {
   const WgHaloParams& p = P.job[blockIdx.z];
   constexpr int MAXHP = 288;
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
   const int g_begin = blockIdx.x * p.groups_per_block;
   int g_end = g_begin + p.groups_per_block;
   if (g_end > p.ngroups) g_end = p.ngroups;
-  for (int grp = g_begin; grp < g_end; ++grp) {
+
+  auto patch_fill = [&](int grp, int (*tab)[8]) {
     if (tid < p.NV) {
       int gp = grp * p.NV + tid;
       int valid = gp < p.npatches;
@@ -117,36 +120,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
       int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
       int dd = p.d * p.d;
       int b = v / dd, ab = v - b * dd;
-      s_patch[tid][0] = b; s_patch[tid][1] = ab / p.d; s_patch[tid][2] = ab - (ab / p.d) * p.d;
-      s_patch[tid][3] = ty * p.PH; s_patch[tid][4] = tx * p.PW; s_patch[tid][5] = valid;
+      tab[tid][0] = b; tab[tid][1] = ab / p.d; tab[tid][2] = ab - (ab / p.d) * p.d;
+      tab[tid][3] = ty * p.PH; tab[tid][4] = tx * p.PW; tab[tid][5] = valid;
     }
-    __syncthreads();  // patch table ready; also: previous iteration's LDS reads are done
-#pragma unroll
-    for (int it = 0; it < X_IT; ++it) {
-      int idx = tid + 256 * it;
-      if (x_geo[it] < 0) continue;
-      const int* pt = s_patch[x_geo[it] >> 16];
-      uint4 v = make_uint4(0, 0, 0, 0);
-      int ly = pt[3] + ((x_geo[it] >> 8) & 255) - 1, lx = pt[4] + (x_geo[it] & 255) - 1;
-      if (x_cok && pt[5] && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl) {
-        int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * ly) * p.W + pt[2] + p.d * lx;
-        v = *reinterpret_cast<const uint4*>(p.x + pix * p.ldx + m0 + xq * 8);
-      }
-      *reinterpret_cast<uint4*>(&lds_x[(idx / XCH) * XS + xq * 8]) = v;
+  };
+  auto load_x = [&](int it, int (*tab)[8]) -> uint4 {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (x_geo[it] < 0) return v;
+    const int* pt = tab[x_geo[it] >> 16];
+    int ly = pt[3] + ((x_geo[it] >> 8) & 255) - 1, lx = pt[4] + (x_geo[it] & 255) - 1;
+    if (x_cok && pt[5] && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl) {
+      int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * ly) * p.W + pt[2] + p.d * lx;
+      v = *reinterpret_cast<const uint4*>(p.x + pix * p.ldx + m0 + xq * 8);
     }
-#pragma unroll
-    for (int it = 0; it < Y_IT; ++it) {
-      int idx = tid + 256 * it;
-      if (idx >= 128 * YCH) continue;
-      const int* pt = s_patch[y_geo[it] >> 16];
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (y_cok && pt[5]) {
-        int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * (pt[3] + ((y_geo[it] >> 8) & 255))) * p.W + pt[2] + p.d * (pt[4] + (y_geo[it] & 255));
-        v = *reinterpret_cast<const uint4*>(p.dy + pix * p.lddy + n0 + yq * 8);
-      }
-      *reinterpret_cast<uint4*>(&lds_y[(idx / YCH) * YS + yq * 8]) = v;
+    return v;
+  };
+  auto load_y = [&](int it, int (*tab)[8]) -> uint4 {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (tid + 256 * it >= 128 * YCH) return v;
+    const int* pt = tab[y_geo[it] >> 16];
+    if (y_cok && pt[5]) {
+      int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * (pt[3] + ((y_geo[it] >> 8) & 255))) * p.W + pt[2] + p.d * (pt[4] + (y_geo[it] & 255));
+      v = *reinterpret_cast<const uint4*>(p.dy + pix * p.lddy + n0 + yq * 8);
     }
-    __syncthreads();
+    return v;
+  };
+  auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8_t bfr[WN];
@@ -162,6 +161,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
           for (int j = 0; j < WN; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[t][i][j], 0, 0, 0);
         }
       }
+    }
+  };
+
+  if (!PF) {
+    for (int grp = g_begin; grp < g_end; ++grp) {
+      patch_fill(grp, s_patch);
+      __syncthreads();  // patch table ready; also: previous iteration's LDS reads are done
+#pragma unroll
+      for (int it = 0; it < X_IT; ++it)
+        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + 256 * it) / XCH) * XS + xq * 8]) = load_x(it, s_patch);
+#pragma unroll
+      for (int it = 0; it < Y_IT; ++it)
+        if (tid + 256 * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + 256 * it) / YCH) * YS + yq * 8]) = load_y(it, s_patch);
+      __syncthreads();
+      compute();
+    }
+  } else {
+    __shared__ int s_patch2[8][8];
+    uint4 rx[X_IT], ry[Y_IT];
+    if (g_begin < g_end) {
+      patch_fill(g_begin, s_patch);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < X_IT; ++it) rx[it] = load_x(it, s_patch);
+#pragma unroll
+      for (int it = 0; it < Y_IT; ++it) ry[it] = load_y(it, s_patch);
+    }
+    int par = 0;
+    for (int grp = g_begin; grp < g_end; ++grp, par ^= 1) {
+      int (*nxt)[8] = par ? s_patch : s_patch2;
+#pragma unroll
+      for (int it = 0; it < X_IT; ++it)
+        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + 256 * it) / XCH) * XS + xq * 8]) = rx[it];
+#pragma unroll
+      for (int it = 0; it < Y_IT; ++it)
+        if (tid + 256 * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + 256 * it) / YCH) * YS + yq * 8]) = ry[it];
+      const bool more = grp + 1 < g_end;
+      if (more) patch_fill(grp + 1, nxt);
+      __syncthreads();      // this group's tile and the next group's patch table are visible
+      if (more) {
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) rx[it] = load_x(it, nxt);
+#pragma unroll
+        for (int it = 0; it < Y_IT; ++it) ry[it] = load_y(it, nxt);
+      }
+      compute();
+      __syncthreads();      // everyone is done reading the tile before the next stores
     }
   }
 
@@ -269,10 +315,17 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   }
   const dim3 grid(splits, tiles, njobs);
   const int slot = usseg_prof_start(2, s);
-  if (shape == 1) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1>), grid, dim3(256), 0, s, P);
-  else if (shape == 2) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1>), grid, dim3(256), 0, s, P);
-  else if (shape == 3) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2>), grid, dim3(256), 0, s, P);
-  else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2>), grid, dim3(256), 0, s, P);
+  static const int pf = getenv("USSEG_WGRAD_PF") ? atoi(getenv("USSEG_WGRAD_PF")) : 1;
+  if (shape == 1) {
+    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, true>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, false>), grid, dim3(256), 0, s, P);
+  } else if (shape == 2) {
+    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, true>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, false>), grid, dim3(256), 0, s, P);
+  } else if (shape == 3) {
+    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, true>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, false>), grid, dim3(256), 0, s, P);
+  } else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, false>), grid, dim3(256), 0, s, P);
   if (use_ws)
     for (int j = 0; j < njobs; ++j) usseg_launch_wgrad_finish(P.job[j].ws, splits, slab, gm[j].out, gm[j].map, Ma, Nb, s);
   usseg_prof_stop(2, slot, s);
