@@ -289,13 +289,15 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   // from hundreds of workgroups run at the ~1.3 TB/s atomic rate and cost more than the MFMAs (no-workspace fallback only).
   const int64_t slab = (int64_t)9 * Ma * Nb;
   // traffic guard (rocprofv3 FETCH/WRITE_SIZE showed the partial slabs costing ~2 GB/step): keep the slabs written and
-  // re-read within a few times the bytes of the operands themselves.  (Sending the deep layers back to the per-tap
-  // kernel, or capping at 1x, was measured slower: 7.5 vs 6.9 ms/step.)
+  // re-read within 2x the bytes of the operands themselves (swept 1/2/3/4/8/16 with the multi-job launches and the
+  // register prefetch in place: 2x is the minimum, 4.95 vs 5.05 ms/step at 8x; sending the deep layers back to the
+  // per-tap kernel was slower).
   const int64_t in_bytes = (int64_t)gm[0].B * gm[0].H * gm[0].W * (Ma + Nb) * 2, slab_bytes = slab * 4;
   static const int wg_target = getenv("USSEG_WG_TARGET") ? atoi(getenv("USSEG_WG_TARGET")) : 512;
   int splits = (wg_target + tiles * njobs - 1) / (tiles * njobs);
   int max_splits = (ngroups + 1) / 2;
-  const int64_t traffic_cap = 8 * in_bytes / slab_bytes < 4 ? 4 : 8 * in_bytes / slab_bytes;
+  static const int slab_cap = getenv("USSEG_SLAB_CAP") ? atoi(getenv("USSEG_SLAB_CAP")) : 2;
+  const int64_t traffic_cap = slab_cap * in_bytes / slab_bytes < 4 ? 4 : slab_cap * in_bytes / slab_bytes;
   if (max_splits > traffic_cap) max_splits = (int)traffic_cap;
   if (!ws) max_splits = (ngroups + 15) / 16;
   else if ((int64_t)max_splits * slab * njobs > ws_floats) max_splits = (int)(ws_floats / (slab * njobs));
