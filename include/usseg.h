@@ -70,6 +70,21 @@ int usseg_version(void);
  * y = act(conv(x, Wp) + bias) (+ residual).  bias may be NULL; residual (bf16, stride ldr) may be NULL. */
 int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const void* wp_fwd, const float* bias,
                      const void* residual, int32_t ldr, void* y, usseg_stream_t stream);
+/* Conv2D followed by an inference-mode BatchNormalization and the activation in ONE pass (ResNest.py:17-23; Decoder.py:67-76):
+ * y = act(scale[n] * conv(x, Wp)[n] + shift[n]) with scale = gamma*rsqrt(var+eps), shift = beta - mean*scale + scale*conv_bias
+ * (usseg_bn_fold_batched builds both).  The pre-normalisation tensor is never written; the backward recovers what it needs
+ * from y (usseg_norm_act_bwd mode 2). */
+int usseg_conv2d_fwd_affine(const UssegConvDesc* d, const void* x, const void* wp_fwd, const float* scale, const float* shift,
+                            const void* residual, int32_t ldr, void* y, usseg_stream_t stream);
+typedef struct UssegBnFoldJob {   /* one BatchNormalization layer (device pointers; C logical, Cp physical channels) */
+  const float *gamma, *beta, *mean, *var;
+  const float* bias;               /* bias of the conv in front of it, or NULL */
+  float *scale, *shift;            /* outputs, Cp floats each (zero past C) */
+  int32_t C, Cp;
+  float eps;
+  int32_t reserved;
+} UssegBnFoldJob;
+int usseg_bn_fold_batched(const UssegBnFoldJob* jobs_dev, int32_t njobs, usseg_stream_t stream);
 /* dx = conv_transpose(dy, W) (+ residual): the backward-data of the op above.  wp_dgrad is the operand
  * packed with in/out swapped (K index = tap*Cout + co).  dx has d->Cin channels, stride d->ldx. */
 int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const void* wp_dgrad, const void* residual,
@@ -143,6 +158,7 @@ typedef struct UssegConvJob {
   int32_t ldr;
   int32_t reserved;
   void* y;              /* fwd: y;  dgrad: dx */
+  const float* scale;   /* fwd only, may be NULL: y = act(scale[n]*conv + bias[n]) (folded inference BatchNorm, see _affine) */
 } UssegConvJob;
 int usseg_conv2d_fwd_multi(int32_t njobs, const UssegConvJob* jobs, usseg_stream_t stream);
 int usseg_conv2d_dgrad_multi(int32_t njobs, const UssegConvJob* jobs, usseg_stream_t stream);
@@ -186,10 +202,11 @@ typedef struct UssegNormDesc {
   int32_t C, Cphys;   /* logical channels, physical channels (multiple of 8; pad channels written as 0) */
   int32_t ldx, ldy;   /* channel strides of input and output */
   int32_t G;          /* groups (LN only), C % G == 0 */
-  int32_t mode;       /* 0 LN, 1 affine */
+  int32_t mode;       /* 0 LN, 1 affine, 2 (usseg_norm_act_bwd only) affine whose input x is the ACTIVATED output of usseg_conv2d_fwd_affine */
   float eps;
   int32_t act;
   float alpha;
+  int32_t lddx;       /* usseg_norm_act_bwd: channel stride of dx (0 = ldx) */
 } UssegNormDesc;
 /* mask (may be NULL): bf16 tensor [M][ldm] multiplied into the ACTIVATED output (dropout: 0 or 1/keep; since the mask is
  * non-negative relu(bn(x)*mask) == relu(bn(x))*mask, TBI_ResNest.py:213-218); the backward applies it to dy.

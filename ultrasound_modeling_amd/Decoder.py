@@ -21,6 +21,7 @@ from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 
 
 _FUSED_DGRAD = os.environ.get("USSEG_FUSED_DGRAD", "1") != "0"
+_FOLD_BN = os.environ.get("USSEG_FOLD_BN", "0") != "0"   # built and parity-tested; measured neutral on the step (4.98 vs 4.99 ms), so off by default
 
 
 class DecoderBlock(nn.Module):
@@ -71,7 +72,8 @@ class DecoderBlock(nn.Module):
             span = lambda t: torch.as_strided(t, (oc,), (1,))
             c0 = getattr(self, f"conv{st}_0")
             self._bn[st] = dict(mean=mean, var=var, gamma=span(bns[0].gamma.data), beta=span(bns[0].beta.data),
-                                dgamma=span(bns[0].gamma.grad), dbeta=span(bns[0].beta.grad), dbias=span(c0.bias.grad))
+                                dgamma=span(bns[0].gamma.grad), dbeta=span(bns[0].beta.grad), dbias=span(c0.bias.grad),
+                                bias=span(c0.bias.data), fscale=torch.ones(oc, device=device), fshift=torch.zeros(oc, device=device))
             for a_, b_ in zip(bns[:-1], bns[1:]):
                 assert b_.gamma.data_ptr() == a_.gamma.data_ptr() + 4 * q and b_.beta.data_ptr() == a_.beta.data_ptr() + 4 * q
         # backward-data operand of a stage's four branches, concatenated along K (one implicit GEMM, dx written once)
@@ -80,6 +82,13 @@ class DecoderBlock(nn.Module):
             cin_p = getattr(self, f"conv{st}_0").cin_p
             self._wd_cat[st] = torch.zeros((roundup(cin_p, 16), 28 * q), dtype=BF16, device=device)
         ops.pack_weights_batched(ops.make_pack_table(self.pack_jobs(), device), len(self.pack_jobs()))
+        jobs = self.bn_fold_jobs()
+        ops.bn_fold_batched(ops.make_bn_fold_table(jobs, device), len(jobs))
+
+    def bn_fold_jobs(self):
+        """One folded inference BatchNorm per stage (its four branch BNs are adjacent vectors): scale/shift for the conv epilogues."""
+        return [ops.bn_fold_job(b["gamma"], b["beta"], b["mean"], b["var"], b["bias"], b["fscale"], b["fshift"], self.out_channels, KERAS_BN_EPS)
+                for b in (self._bn["1"], self._bn["2"])]
 
     def pack_jobs(self):
         """Pack jobs of the concatenated backward-data operands (the per-conv operands are packed by the Conv2D layers)."""
@@ -101,20 +110,30 @@ class DecoderBlock(nn.Module):
                                 d["mean"], d["var"])
 
     def _bn_bwd(self, st, raw, dy, dx):
+        """``raw``: the pre-norm conv outputs, or (folded) the ACTIVATED outputs - mode 2 recovers what it needs from them."""
         d = self._bn[st]
-        return ops.norm_act_bwd(raw, dy, self.out_channels, d["gamma"], d["beta"], dx, d["dgamma"], d["dbeta"], 1, 1, KERAS_BN_EPS,
-                                ACT_LRELU, KERAS_LRELU_ALPHA, d["mean"], d["var"], dbias=d["dbias"])
+        return ops.norm_act_bwd(raw, dy, self.out_channels, d["gamma"], d["beta"], dx, d["dgamma"], d["dbeta"], 2 if self._fold else 1, 1,
+                                KERAS_BN_EPS, ACT_LRELU, KERAS_LRELU_ALPHA, d["mean"], d["var"], dbias=d["dbias"])
 
     def _branches_fwd(self, st, x, raw):
-        """The four parallel convs of a stage: the 1x1, then the three dilated 3x3 convs as ONE multi-job launch."""
+        """The four parallel convs of a stage: the 1x1, then the three dilated 3x3 convs as ONE multi-job launch.
+        Folded: inference-mode BN + LeakyReLU ride in the conv epilogues and ``raw`` receives the activated output."""
         q = self.out_channels // 4
         convs = [getattr(self, f"conv{st}_{j}") for j in range(4)]
-        convs[0].forward(x, out=raw[..., :q])
+        b = self._bn[st]
+        sl = lambda t, j: t[j * q:(j + 1) * q]
+        if self._fold:
+            convs[0].forward(x, out=raw[..., :q], act=ACT_LRELU, alpha=KERAS_LRELU_ALPHA, scale=sl(b["fscale"], 0), shift=sl(b["fshift"], 0))
+        else:
+            convs[0].forward(x, out=raw[..., :q])
         jobs = []
         for j in (1, 2, 3):
             c = convs[j]
             c._x = x
-            jobs.append((x, c.wp_f, c.bias.data, c.k, c.dil, raw[..., j * q:(j + 1) * q], ACT_NONE, 0.0))
+            if self._fold:
+                jobs.append((x, c.wp_f, sl(b["fshift"], j), c.k, c.dil, raw[..., j * q:(j + 1) * q], ACT_LRELU, KERAS_LRELU_ALPHA, sl(b["fscale"], j)))
+            else:
+                jobs.append((x, c.wp_f, c.bias.data, c.k, c.dil, raw[..., j * q:(j + 1) * q], ACT_NONE, 0.0))
         ops.conv2d_fwd_multi(jobs)
 
     def _branches_bwd(self, st, draw, dx):
@@ -144,12 +163,19 @@ class DecoderBlock(nn.Module):
         self.up.forward(x, out=cat[..., :oc])                                         # :63
         if has_skip:
             ops.copy_channels(skip, cat[..., oc:])                                    # :66
+        self._fold = _FOLD_BN and not any(getattr(self, f"bn{st}_{j}").training_mode for st in ("1", "2") for j in range(4))
+        out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, oc, dev)
+        if self._fold:   # :67-76, :79-88 with BN + LeakyReLU in the conv epilogues: no pre-norm tensors, no norm launches
+            act1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
+            self._branches_fwd("1", cat, act1)
+            self._branches_fwd("2", act1, out)
+            self._has_skip, self._raw = has_skip, (act1, out)
+            return out
         raw1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
         self._branches_fwd("1", cat, raw1)                                            # :67-74 convs write their channel slice
         act1 = self._bn_fwd("1", raw1, ops.new_act(B, 2 * H, 2 * W, oc, dev))        # :68-76 four BNs + LeakyReLU, one launch
         raw2 = ops.new_act(B, 2 * H, 2 * W, oc, dev)
         self._branches_fwd("2", act1, raw2)                                           # :79-86
-        out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, oc, dev)
         self._bn_fwd("2", raw2, out)                                                  # :80-88
         self._has_skip, self._raw = has_skip, (raw1, raw2)
         return out

@@ -45,9 +45,15 @@ def repack_all(root: nn.Module):
             elif isinstance(m, Conv2D) and m.wp_f is not None:
                 jobs += m.pack_jobs()
         dev = next(root.parameters()).device
-        table = (ops.make_pack_table(jobs, dev), len(jobs))
+        folds = []
+        for m in root.modules():
+            if isinstance(m, (ResNest, DecoderBlock)):
+                folds += m.bn_fold_jobs()
+        table = (ops.make_pack_table(jobs, dev), len(jobs), ops.make_bn_fold_table(folds, dev) if folds else None, len(folds))
         object.__setattr__(root, "_pack_table", table)
-    ops.pack_weights_batched(*table)
+    ops.pack_weights_batched(table[0], table[1])
+    if table[3]:
+        ops.bn_fold_batched(table[2], table[3])     # folded inference BatchNorm constants of the conv epilogues
 
 
 class Embeddings(nn.Module):

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
 
 class ConvJob(C.Structure):
     _fields_ = [("desc", ConvDesc), ("x", c_vp), ("wp", c_vp), ("bias", c_vp), ("residual", c_vp), ("ldr", c_i32),
-                ("reserved", c_i32), ("y", c_vp)]
+                ("reserved", c_i32), ("y", c_vp), ("scale", c_vp)]
 
 
 class WgradBlock(C.Structure):
@@ -48,7 +48,7 @@ class WgradJob(C.Structure):
 
 class NormDesc(C.Structure):
     _fields_ = [("M", c_i64), ("C", c_i32), ("Cphys", c_i32), ("ldx", c_i32), ("ldy", c_i32), ("G", c_i32),
-                ("mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32)]
+                ("mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32), ("lddx", c_i32)]
 
 
 class SplitAttnDesc(C.Structure):
@@ -84,6 +84,8 @@ _PROTOS = {
     "usseg_last_error": (C.c_char_p, []),
     "usseg_version": (C.c_int, []),
     "usseg_conv2d_fwd": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_conv2d_fwd_affine": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_bn_fold_batched": (C.c_int, [c_vp, c_i32, c_vp]),
     "usseg_conv2d_dgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_conv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "usseg_conv2d_wgrad_mapped": (C.c_int, [P(ConvDesc), c_vp, c_vp, P(WgradDst), c_vp, c_i64, c_vp]),

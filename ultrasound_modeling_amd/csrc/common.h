@@ -80,6 +80,10 @@ static inline int wg_map_fill(WgMap& m, const UssegWgradDst* d) {
   return 1;
 }
 
+// per-output-channel multiplier applied before the bias in the conv epilogues (folded inference BatchNorm): set by the
+// *_affine / multi entry points for the duration of one call, read by the launchers (slot = job index)
+extern thread_local const float* usseg_epi_scale[4];
+
 void usseg_set_error(const char* fmt, ...);
 #define USSEG_CHECK_ARG(cond, ...)                 \
   do {                                             \

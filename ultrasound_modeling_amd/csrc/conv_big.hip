@@ -19,6 +19,7 @@ struct BigJob {
   const bf16_t* w;
   void* y;
   const float* bias;
+  const float* scale;   // optional per-channel multiplier applied before the bias (folded inference BatchNorm)
   const bf16_t* res;
   int32_t H, W, d, Hl, Wl, PH, PW, NV;
   int32_t tiles_x, tiles_per_v, npatches;
@@ -187,6 +188,10 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
+      if (p.scale) {
+        float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+      }
       if (p.bias) {
         float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -337,6 +342,7 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
     if (!big_fill_job(P.job[j], g[j].x, g[j].w, g[j].y, g[j].bias, g[j].res, g[j].B, g[j].H, g[j].W, g[j].d, g[j].Cin, g[j].ldx, g[j].Nout,
                       g[j].ldy, g[j].ldr, g[j].Nw, g[j].Kw, g[j].act, g[j].alpha, g[j].out_f32, g[j].accumulate, g[j].flip, best_px))
       return 0;
+  for (int j = 0; j < njobs; ++j) P.job[j].scale = g[j].flip ? nullptr : usseg_epi_scale[j];
   big_launch(P, njobs, best_nt, best_px, s);
   return 1;
 }

@@ -21,6 +21,7 @@ struct HaloParams {
   const bf16_t* w;
   void* y;
   const float* bias;
+  const float* scale;   // optional per-channel multiplier applied before the bias (folded inference BatchNorm)
   const bf16_t* res;
   int32_t B, H, W, d;
   int32_t Hl, Wl;        // lattice size = H/d, W/d
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloMulti P) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
+      if (p.scale) {
+        float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+      }
       if (p.bias) {
         float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -356,6 +361,10 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
+        if (p.scale) {
+          float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+          v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+        }
         if (p.bias) {
           float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
           v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -471,6 +480,7 @@ int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const 
   if (disabled) return 0;
   HaloMulti P;
   if (!halo_fill(P.job[0], x, w, y, bias, res, B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act, alpha, out_f32, accumulate, flip)) return 0;
+  P.job[0].scale = flip ? nullptr : usseg_epi_scale[0];
   return halo_launch(P, 1, s);
 }
 
@@ -488,6 +498,7 @@ int usseg_try_launch_conv_halo_multi(int njobs, const UssegConvJob* jobs, int fl
                   : halo_fill(P.job[j], (const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, q.bias, (const bf16_t*)q.residual, d.B, d.H, d.W,
                               d.dilation, d.Cin, d.ldx, d.Cout, d.ldy, q.ldr, roundup(d.Cout, 16), 9 * d.Cin, d.act, d.alpha, out_f32, acc, 0);
     if (!ok) return 0;
+    P.job[j].scale = flip ? nullptr : usseg_epi_scale[j];
   }
   return halo_launch(P, njobs, s);
 }

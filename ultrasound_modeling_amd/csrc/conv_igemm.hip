@@ -18,6 +18,7 @@ struct IgemmParams {
   const bf16_t* w;
   void* y;
   const float* bias;
+  const float* scale;   // optional per-channel multiplier applied before the bias (folded inference BatchNorm)
   const bf16_t* res;
   int32_t B, Hg, Wg;
   int64_t M;
@@ -188,6 +189,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
+      if (p.scale) {
+        float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+      }
       if (p.bias) {
         float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -271,6 +276,7 @@ extern "C" int usseg_conv2d_fwd(const UssegConvDesc* d, const void* x, const voi
     return usseg_check_launch("conv_halo");
   IgemmParams p = {};
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)wp; p.y = y; p.bias = bias; p.res = (const bf16_t*)residual; p.ldr = ldr;
+  p.scale = usseg_epi_scale[0];
   p.B = d->B; p.Hg = d->H; p.Wg = d->W; p.M = (int64_t)d->B * d->H * d->W;
   p.Hi = d->H; p.Wi = d->W; p.ldx = d->ldx; p.isy = p.isx = 1;
   p.Ho = d->H; p.Wo = d->W; p.ldy = d->ldy; p.osy = p.osx = 1; p.oay = p.oax = 0;
@@ -338,17 +344,31 @@ static int conv_multi(int32_t njobs, const UssegConvJob* jobs, int flip, usseg_s
     if (flip) USSEG_CHECK_ARG(!(jobs[j].desc.flags & USSEG_OUT_F32) && jobs[j].desc.Cout % 8 == 0, "dgrad needs bf16 dy with Cout % 8 == 0");
     all3 = all3 && jobs[j].desc.ksize == 3;
   }
+  struct ScaleGuard {   // the per-job epilogue multipliers are visible to the launchers only during this call
+    ~ScaleGuard() { for (int j = 0; j < 4; ++j) usseg_epi_scale[j] = nullptr; }
+  } guard;
   if (njobs > 1 && all3) {
+    for (int j = 0; j < njobs; ++j) usseg_epi_scale[j] = flip ? nullptr : jobs[j].scale;
     if (usseg_try_launch_conv_big_multi(njobs, jobs, flip, (hipStream_t)stream)) return usseg_check_launch("conv_big_multi");
     if (usseg_try_launch_conv_halo_multi(njobs, jobs, flip, (hipStream_t)stream)) return usseg_check_launch("conv_halo_multi");
   }
   for (int j = 0; j < njobs; ++j) {
     const UssegConvJob& q = jobs[j];
+    for (int k = 0; k < 4; ++k) usseg_epi_scale[k] = nullptr;
+    usseg_epi_scale[0] = flip ? nullptr : q.scale;
     int rc = flip ? usseg_conv2d_dgrad(&q.desc, q.x, q.wp, q.residual, q.ldr, q.y, stream)
                   : usseg_conv2d_fwd(&q.desc, q.x, q.wp, q.bias, q.residual, q.ldr, q.y, stream);
     if (rc) return rc;
   }
   return USSEG_OK;
+}
+extern "C" int usseg_conv2d_fwd_affine(const UssegConvDesc* d, const void* x, const void* wp, const float* scale, const float* shift,
+                                       const void* residual, int32_t ldr, void* y, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(scale && shift && ((((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0, "conv2d_fwd_affine: scale/shift must be non-null, 16-byte aligned");
+  usseg_epi_scale[0] = scale;
+  int rc = usseg_conv2d_fwd(d, x, wp, shift, residual, ldr, y, stream);
+  usseg_epi_scale[0] = nullptr;
+  return rc;
 }
 extern "C" int usseg_conv2d_fwd_multi(int32_t njobs, const UssegConvJob* jobs, usseg_stream_t stream) {
   return conv_multi(njobs, jobs, 0, stream);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
     *reinterpret_cast<float4*>(gv + 4) = *reinterpret_cast<const float4*>(p.gamma + cl + 4);
     *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(p.beta + cl);
     *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(p.beta + cl + 4);
-    if (MODE == 1) {
+    if (MODE >= 1) {
       *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(p.mean + cl);
       *reinterpret_cast<float4*>(mv + 4) = *reinterpret_cast<const float4*>(p.mean + cl + 4);
       *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(p.var + cl);
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
       ga[j] = ok ? gv[j] : 0.f;
       be[j] = ok ? bv[j] : 0.f;
       mu_c[j] = (MODE == 1 && ok) ? mv[j] : 0.f;
-      rs_c[j] = (MODE == 1 && ok) ? rsqrtf(vv[j] + p.eps) : 0.f;
+      if (MODE == 2) mu_c[j] = (ok && fabsf(gv[j]) > 1e-20f) ? 1.f / gv[j] : 0.f;   // mode 2 keeps 1/gamma here (the mean is not needed)
+      rs_c[j] = (MODE >= 1 && ok) ? rsqrtf(vv[j] + p.eps) : 0.f;
       if (NG > 1) {
         int gj = g0 + (r0 + j) / p.Cg;   // Cg >= 3 in every model, so a chunk spans at most 4 groups; general anyway
 #pragma unroll
@@ -174,9 +175,20 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
         rstd_j[j] = r;
         xh[j] = d[j] * r;
       }
-    } else {
+    } else if (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) xh[j] = (xv[j] - mu_c[j]) * rs_c[j];
+    } else {
+      // MODE 2 (backward only): x is the ACTIVATED output y of a conv whose epilogue applied the folded affine + activation
+      // (usseg_conv2d_fwd_affine); the pre-activation and the normalised value are recovered from it (gamma != 0)
+      const float inv_alpha = p.alpha != 0.f ? 1.f / p.alpha : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float y = xv[j], pre = y;
+        if (p.act == USSEG_ACT_LRELU) pre = y >= 0.f ? y : y * inv_alpha;
+        else if (p.act == USSEG_ACT_ELU) pre = y > 0.f ? y : log1pf(y * inv_alpha);
+        xh[j] = (pre - be[j]) * mu_c[j];
+      }
     }
 
     if (!BWD) {
@@ -257,7 +269,8 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
 
 template <bool BWD>
 static void norm_launch(const NormParams& p, unsigned grid, hipStream_t s) {
-  if (p.mode == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 1, 1>), dim3(grid), dim3(256), 0, s, p);
+  if (p.mode == 2) hipLaunchKernelGGL((norm_act_kernel<true, 2, 1>), dim3(grid), dim3(256), 0, s, p);
+  else if (p.mode == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 1, 1>), dim3(grid), dim3(256), 0, s, p);
   else if (p.G == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 1>), dim3(grid), dim3(256), 0, s, p);
   else if (p.G <= 3) hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 3>), dim3(grid), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 4>), dim3(grid), dim3(256), 0, s, p);
@@ -267,7 +280,7 @@ static int norm_common(const UssegNormDesc* d, NormParams& p) {
   USSEG_CHECK_ARG(d, "null descriptor");
   USSEG_CHECK_ARG(d->C > 0 && d->Cphys % 8 == 0 && d->Cphys >= d->C && d->Cphys <= 512, "norm: C/Cphys out of range (Cphys <= 512, multiple of 8)");
   USSEG_CHECK_ARG(d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->Cphys && d->ldy >= d->Cphys, "norm: bad strides");
-  USSEG_CHECK_ARG(d->mode == 0 || d->mode == 1, "norm: mode must be 0 (LN) or 1 (affine)");
+  USSEG_CHECK_ARG(d->mode == 0 || d->mode == 1 || d->mode == 2, "norm: mode must be 0 (LN), 1 (affine) or 2 (affine backward from the activated output)");
   int G = d->mode == 0 ? d->G : 1;
   USSEG_CHECK_ARG(G >= 1 && G <= 4 && d->C % G == 0, "norm: 1 <= G <= 4 and C % G == 0");
   p.M = d->M; p.C = d->C; p.Cphys = d->Cphys; p.G = G; p.Cg = d->mode == 0 ? d->C / G : d->C;
@@ -285,6 +298,7 @@ extern "C" int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const f
   USSEG_CHECK_ARG(x && y && gamma && beta && (d->mode == 0 || (mean && var)), "norm fwd: null pointer");
   USSEG_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0,
                   "norm: gamma/beta/mean/var must be 16-byte aligned (and readable up to Cphys floats)");
+  USSEG_CHECK_ARG(d->mode != 2, "norm fwd: mode 2 is a backward-only mode");
   p.x = (const bf16_t*)x; p.y = (bf16_t*)y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
   p.mask = (const bf16_t*)mask; p.ldm = ldm;
   p.ldx = d->ldx; p.ldy = d->ldy;
@@ -301,12 +315,14 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   int rc = norm_common(d, p);
   if (rc) return rc;
   USSEG_CHECK_ARG(x && dy && dx && gamma && beta && dgamma && dbeta && ws && (d->mode == 0 || (mean && var)), "norm bwd: null pointer");
+  USSEG_CHECK_ARG(d->mode != 2 || !mask, "norm bwd mode 2 does not take a dropout mask");
   USSEG_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0,
                   "norm: gamma/beta/mean/var must be 16-byte aligned (and readable up to Cphys floats)");
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
   p.mask = (const bf16_t*)mask; p.ldm = ldm;
   p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias; p.ws = ws;
-  p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->ldx;
+  p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->lddx > 0 ? d->lddx : d->ldx;
+  USSEG_CHECK_ARG(p.lddx % 8 == 0 && p.lddx >= d->Cphys, "norm bwd: bad dx stride");
   if (p.M <= 0) return USSEG_OK;
   int ppb = 4 * (64 / p.LPP);
   // small tensors are latency bound (each loop trip is a dependent load -> store): spread them over many workgroups
@@ -656,6 +672,25 @@ extern "C" int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_
   USSEG_CHECK_ARG(dq && grad && Cin >= 1 && Cin <= Cin_phys && Cout >= 1 && Cout <= 4, "tconv_quad_unpack: bad args");
   hipLaunchKernelGGL(tconv_quad_unpack_kernel, dim3((9 * Cout * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, dq, Cin_phys, Cin, Cout, grad);
   return usseg_check_launch("tconv_quad_unpack");
+}
+
+// ---- folded inference BatchNorm: scale = gamma*rsqrt(var+eps), shift = beta - mean*scale + scale*conv_bias, all layers in ONE launch
+__global__ __launch_bounds__(256) void bn_fold_batched_kernel(const UssegBnFoldJob* jobs) {
+  const UssegBnFoldJob j = jobs[blockIdx.x];
+  for (int c = threadIdx.x; c < j.Cp; c += 256) {
+    float sc = 0.f, sh = 0.f;
+    if (c < j.C) {
+      sc = j.gamma[c] * rsqrtf(j.var[c] + j.eps);
+      sh = j.beta[c] - j.mean[c] * sc + (j.bias ? sc * j.bias[c] : 0.f);
+    }
+    j.scale[c] = sc;
+    j.shift[c] = sh;
+  }
+}
+extern "C" int usseg_bn_fold_batched(const UssegBnFoldJob* jobs_dev, int32_t njobs, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(jobs_dev && njobs > 0 && njobs < 65536, "bn_fold_batched: bad args");
+  hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  return usseg_check_launch("bn_fold_batched");
 }
 
 // ---- dropout mask (tf.nn.dropout(x, rate), TBI_ResNest.py:216): mask[m][c] = keep ? 1/(1-rate) : 0, counter-based hash RNG

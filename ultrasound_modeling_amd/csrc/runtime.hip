@@ -3,6 +3,7 @@
 #include "common.h"
 
 static thread_local char g_err[512] = "";
+thread_local const float* usseg_epi_scale[4] = {nullptr, nullptr, nullptr, nullptr};
 
 void usseg_set_error(const char* fmt, ...) {
   va_list ap;

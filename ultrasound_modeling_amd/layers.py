@@ -140,13 +140,16 @@ class Conv2D(nn.Module):
         jobs = self.pack_jobs()
         ops.pack_weights_batched(ops.make_pack_table(jobs, self.wp_f.device), len(jobs))
 
-    def forward(self, x, out=None, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False, use_bias=True):
+    def forward(self, x, out=None, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False, use_bias=True, scale=None, shift=None):
+        """``scale`` / ``shift``: a folded inference BatchNormalization (y = act(scale*conv + shift); ``shift`` holds the bias)."""
         B, H, W, C, _ = ops.geom(x)
         assert C == self.cin_p, f"expected {self.cin_p} physical input channels, got {C}"
         if out is None:
             out = (torch.empty((B, H, W, roundup(self.cout, 4)), dtype=torch.float32, device=x.device)
                    if out_f32 else ops.new_act(B, H, W, self.cout_p, x.device))
         self._x = x
+        if scale is not None:
+            return ops.conv2d_fwd(x, self.wp_f, shift, self.k, self.dil, out, act, alpha, residual, out_f32, scale=scale)
         return ops.conv2d_fwd(x, self.wp_f, self.bias.data if use_bias else None, self.k, self.dil, out, act, alpha, residual, out_f32)
 
     def wgrad_job(self, dy):
@@ -271,6 +274,19 @@ class BatchNormalization(LayerNormalization):
         cp = roundup(channels, 8)
         self.register_buffer("moving_mean_p", torch.zeros(cp))
         self.register_buffer("moving_variance_p", torch.ones(cp))
+        # inference mode folded into the producing conv's epilogue: y = act(fold_scale*conv + fold_shift) (ops.bn_fold_job)
+        self.register_buffer("fold_scale", torch.ones(cp))
+        self.register_buffer("fold_shift", torch.zeros(cp))
+
+    def fold_job(self, conv_bias):
+        return ops.bn_fold_job(self.gamma.data, self.beta.data, self.moving_mean_p, self.moving_variance_p, conv_bias,
+                               self.fold_scale, self.fold_shift, self.C, self.eps)
+
+    def backward_folded(self, y, dy, act, alpha, dx=None, dbias=None):
+        """Backward of conv-epilogue-folded BN + activation from the ACTIVATED output y (the pre-norm tensor was never stored)."""
+        dx = dx if dx is not None else torch.empty_like(y)
+        return ops.norm_act_bwd(y, dy, self.C, self.gamma.data, self.beta.data, dx, self.gamma.grad, self.beta.grad, 2, 1, self.eps,
+                                act, alpha, self.moving_mean_p, self.moving_variance_p, dbias)
 
     @property
     def moving_mean(self):

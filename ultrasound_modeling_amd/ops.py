@@ -182,13 +182,18 @@ def _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation=1, act=ACT_NONE, al
 
 
 # ------------------------------------------------------------------------------------------------ conv
-def conv2d_fwd(x, wp, bias, ksize, dilation, out, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False):
+def conv2d_fwd(x, wp, bias, ksize, dilation, out, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False, scale=None):
+    """``scale`` (fp32 per output channel): y = act(scale*conv + bias) - the folded inference BatchNorm (bias = its shift)."""
     B, H, W, Cin, ldx = geom(x)
     Bo, Ho, Wo, Cout, ldy = geom(out)
     assert (Bo, Ho, Wo) == (B, H, W)
     assert x.dtype == BF16 and out.dtype == (torch.float32 if out_f32 else BF16)
     d = _conv_desc(B, H, W, Cin, Cout, ldx, ldy, ksize, dilation, act, alpha, OUT_F32 if out_f32 else 0)
     ldr = geom(residual)[4] if residual is not None else 0
+    if scale is not None:
+        L.check(L.load().usseg_conv2d_fwd_affine(C.byref(d), x.data_ptr(), wp.data_ptr(), scale.data_ptr(), bias.data_ptr(), _ptr(residual),
+                                                 ldr, out.data_ptr(), _stream()), "conv2d_fwd_affine")
+        return out
     L.check(L.load().usseg_conv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), _ptr(bias), _ptr(residual), ldr,
                                       out.data_ptr(), _stream()), "conv2d_fwd")
     return out
@@ -207,7 +212,9 @@ def conv2d_dgrad(dy, wp_d, ksize, dilation, dx, residual=None, accumulate=False)
 def conv2d_fwd_multi(jobs):
     """jobs: list of (x, wp, bias, ksize, dilation, out, act, alpha) of INDEPENDENT convs -> one launch where possible."""
     arr = (L.ConvJob * len(jobs))()
-    for j, (x, wp, bias, ksize, dilation, out, act, alpha) in enumerate(jobs):
+    for j, job in enumerate(jobs):
+        x, wp, bias, ksize, dilation, out, act, alpha = job[:8]
+        arr[j].scale = _ptr(job[8]) if len(job) > 8 else None      # optional folded-BatchNorm multiplier (bias = its shift)
         B, H, W, Cin, ldx = geom(x)
         Bo, Ho, Wo, Cout, ldy = geom(out)
         assert (Bo, Ho, Wo) == (B, H, W) and x.dtype == BF16 and out.dtype == BF16
@@ -349,6 +356,26 @@ def make_pack_table(jobs, device) -> torch.Tensor:
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
 
 
+BN_FOLD_JOB_DTYPE = [("gamma", "<u8"), ("beta", "<u8"), ("mean", "<u8"), ("var", "<u8"), ("bias", "<u8"), ("scale", "<u8"), ("shift", "<u8"),
+                     ("C", "<i4"), ("Cp", "<i4"), ("eps", "<f4"), ("reserved", "<i4")]
+
+
+def bn_fold_job(gamma, beta, mean, var, bias, scale, shift, C_logical, eps):
+    """Descriptor of one folded inference BatchNorm: scale = gamma*rsqrt(var+eps), shift = beta - mean*scale + scale*bias."""
+    return (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(), bias.data_ptr() if bias is not None else 0,
+            scale.data_ptr(), shift.data_ptr(), C_logical, scale.numel(), eps, 0)
+
+
+def make_bn_fold_table(jobs, device) -> torch.Tensor:
+    import numpy as np
+    arr = np.array(jobs, dtype=BN_FOLD_JOB_DTYPE)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+
+
+def bn_fold_batched(table: torch.Tensor, njobs: int):
+    L.check(L.load().usseg_bn_fold_batched(table.data_ptr(), njobs, _stream()), "bn_fold_batched")
+
+
 def pack_weights_batched(table: torch.Tensor, njobs: int):
     L.check(L.load().usseg_pack_weights_batched(table.data_ptr(), njobs, _stream()), "pack_weights_batched")
 
@@ -376,8 +403,7 @@ def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, ep
                  var=None, dbias=None, mask=None):
     B, H, W, Cphys, ldx = geom(x)
     lddy = geom(dy)[4]
-    assert geom(dx)[4] == ldx, "dx must have the stride of x"
-    d = NormDesc(B * H * W, C_logical, Cphys, ldx, lddy, G, mode, eps, act, alpha)
+    d = NormDesc(B * H * W, C_logical, Cphys, ldx, lddy, G, mode, eps, act, alpha, geom(dx)[4])
     ldm = geom(mask)[4] if mask is not None else 0
     L.check(L.load().usseg_norm_act_bwd(C.byref(d), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean),
                                         _ptr(var), _ptr(mask), ldm, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias),
