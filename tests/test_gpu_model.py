@@ -155,3 +155,41 @@ def test_native_256x80x10_configuration():
     errs = sorted(rel(grads[k], grads_r[k]) for k in grads_r)
     print(f"native 256x80x10: probs rel {e_p:.3e} loss rel {e_l:.2e} grad median {errs[len(errs) // 2]:.3e} p90 {errs[int(len(errs) * .9)]:.3e}")
     assert e_p < 2e-2 and e_l < 5e-3 and errs[len(errs) // 2] < 3e-2 and errs[int(len(errs) * 0.9)] < 1e-1
+
+
+def test_folded_batchnorm_matches_unfused():
+    """usseg_conv2d_fwd_affine + norm backward mode 2 (inference BatchNorm folded into the conv epilogues, off by default)
+    against the default conv -> norm path: same loss, probabilities and gradients to bf16 depth."""
+    import ultrasound_modeling_amd.Decoder as D
+    import ultrasound_modeling_amd.ResNest as R
+    from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 64, 1).clamp_(-1, 1)
+    y = torch.softmax(torch.randn(2, 64, 64, 3), -1)
+    out = []
+    for fold in (False, True):
+        D._FOLD_BN = R._FOLD_BN = fold
+        torch.manual_seed(7)
+        net = VisionTransformer(batch_size=2, img_size=(64, 64), in_channels=1)
+        with torch.no_grad():
+            for m in net.modules():     # non-trivial BN statistics and affine parameters
+                if hasattr(m, "moving_mean_p"):
+                    g = torch.Generator().manual_seed(m.C)
+                    m.moving_mean_p[:m.C] = 0.2 * torch.randn(m.C, generator=g).to(m.moving_mean_p.device)
+                    m.moving_variance_p[:m.C] = (0.5 + torch.rand(m.C, generator=g)).to(m.moving_mean_p.device)
+                    m.gamma.data[:] = (0.7 + 0.6 * torch.rand(m.C, generator=g)).to(m.gamma.device)
+                    m.beta.data[:] = (0.1 * torch.randn(m.C, generator=g)).to(m.gamma.device)
+        net.repack()
+        net.flat.zero_grad()
+        probs, dl = net._forward_loss(net._prep_x(x), net._prep_y(y), True)
+        from ultrasound_modeling_amd import ops
+        with ops.overlap_region():
+            dh, df = net.decoder.backward(dl)
+            net.transformer.backward(dh, df)
+        torch.cuda.synchronize()
+        out.append((net._loss.item(), probs.clone(), net.flat.grad.clone()))
+    D._FOLD_BN = R._FOLD_BN = False
+    (l0, p0, g0), (l1, p1, g1) = out
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    assert abs(l1 - l0) < 5e-3 * abs(l0) and rel(p1, p0) < 2e-2
+    assert rel(g1, g0) < 6e-2

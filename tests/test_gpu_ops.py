@@ -397,3 +397,116 @@ def test_batchnorm_training_mode(gen):
     dx = bn.backward(to_dev_padded(dy))
     assert rel(dx, bf(xr.grad)) < 5e-3
     assert rel(bn.gamma.grad, gr.grad) < 2e-3 and rel(bn.beta.grad, br.grad) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ decoder-stage entry points
+@pytest.mark.parametrize("B,H,W,Cin,q", [(2, 16, 16, 40, 8), (1, 32, 32, 128, 16), (2, 16, 16, 72, 24)])
+def test_decoder_stage_multi_job_and_fused_dgrad(gen, B, H, W, Cin, q):
+    """The DecoderBlock stage (Decoder.py:67-75): 1x1 + three dilated 3x3 convs on one input.
+    usseg_conv2d_fwd_multi == the convs one by one; usseg_conv2d_dgrad_branches == the sum of their backward-data passes;
+    usseg_conv2d_wgrad_multi == the weight gradients one by one; all against the fp64 oracle."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    dil, ks = (1, 2, 4, 8), (1, 3, 3, 3)
+    convs, ws, bs = [], [], []
+    holder = torch.nn.ModuleList()
+    for j in range(4):
+        c = Conv2D(Cin, q, ks[j], dil[j])
+        w = rnd(gen, ks[j], ks[j], Cin, q, scale=1.0 / math.sqrt(ks[j] * ks[j] * Cin))
+        b = rnd(gen, q, scale=0.5)
+        c.kernel.data.copy_(w); c.bias.data.copy_(b)
+        convs.append(c); ws.append(w); bs.append(b); holder.append(c)
+    finalize(holder)
+    x = rnd(gen, B, H, W, Cin)
+    xd = to_dev_padded(x)
+    cin_p = xd.shape[-1]
+    refs = [O.conv2d_same(x, ws[j], bs[j], dil[j]) for j in range(4)]
+    out = torch.zeros(B, H, W, 4 * q, dtype=torch.bfloat16, device=DEV)
+    for c in convs:
+        c._x = xd
+    convs[0].forward(xd, out=out[..., :q])
+    ops.conv2d_fwd_multi([(xd, c.wp_f, c.bias.data, c.k, c.dil, out[..., j * q:(j + 1) * q], ops.ACT_NONE, 0.0)
+                          for j, c in enumerate(convs) if j > 0])
+    torch.cuda.synchronize()
+    for j in range(4):
+        assert rel(out[..., j * q:(j + 1) * q], bf(refs[j])) < REL_BF16, j
+    # backward
+    dy = rnd(gen, B, H, W, 4 * q)
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    sum((O.conv2d_same(xr, wr[j], bs[j], dil[j]) * dy[..., j * q:(j + 1) * q]).sum() for j in range(4)).backward()
+    dyd = to_dev_padded(dy)
+    wcat = torch.zeros((ops.roundup(cin_p, 16), 28 * q), dtype=torch.bfloat16, device=DEV)
+    jobs, base = [], 0
+    for c in convs:
+        T = c.k * c.k
+        sT, sI, sO = c._strides_tio()
+        jobs.append(ops.pack_job(c.kernel.data, sT, sI, sO, T, c.cin, c.cout, wcat, 28 * q, q, 0, base))
+        base += T * q
+    ops.pack_weights_batched(ops.make_pack_table(jobs, DEV), len(jobs))
+    dx = torch.full((B, H, W, cin_p), 5.0, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d_dgrad_branches(dyd, wcat, [c.k for c in convs], [c.dil for c in convs], [j * q for j in range(4)], q, dx)
+    torch.cuda.synchronize()
+    assert rel(dx[..., :Cin], bf(xr.grad)) < 2 * REL_BF16
+    if cin_p > Cin:
+        assert dx[..., Cin:].abs().max().item() == 0
+    ops.conv2d_wgrad_multi([convs[j].wgrad_job(dyd[..., j * q:(j + 1) * q]) for j in (1, 2, 3)])
+    torch.cuda.synchronize()
+    for j in (1, 2, 3):
+        assert rel(convs[j].kernel.grad, wr[j].grad) < REL_F32, j
+
+
+def test_deferred_finishing_matches_immediate(gen):
+    """usseg_defer_begin/_end: the queued, batched finishing reductions give the same gradients as the immediate ones."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D, LayerNormalization
+    B, H, W, Cin, Cout = 2, 16, 16, 24, 40
+    holder = torch.nn.ModuleList([Conv2D(Cin, Cout, 3), LayerNormalization(Cout), Conv2D(Cout, 21, 1)])
+    conv, ln, conv2 = holder
+    finalize(holder)
+    x = to_dev_padded(rnd(gen, B, H, W, Cin))
+    dy = to_dev_padded(rnd(gen, B, H, W, 21))
+
+    def run(deferred):
+        for p in holder.parameters():
+            p.grad.zero_()
+        r = conv.forward(x)
+        a = ln.forward(r, ops.ACT_LRELU, 0.3)
+        conv2.forward(a)
+        ctx = ops.overlap_region() if deferred else __import__("contextlib").nullcontext()
+        with ctx:
+            d = conv2.backward(dy)
+            d = ln.backward(d, dbias=conv.bias.grad)
+            conv.backward(d, need_dx=False, skip_bias=True)
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in holder.parameters()]
+
+    g0, g1 = run(False), run(True)
+    for a, b in zip(g0, g1):
+        assert rel(b, a) < 1e-5
+
+
+def test_head_quad_form_matches_transposed_conv(gen):
+    """The 3-class head Conv2DTranspose(3x3, s2) (Decoder.py:120) run as a 2x2-tap conv with 16 parity channels: forward
+    logits, softmax/loss in the quad layout and all three gradients against the plain transposed-conv path."""
+    from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
+    import ultrasound_modeling_amd.Decoder as D
+    torch.manual_seed(5)
+    x = torch.randn(2, 64, 64, 1).clamp_(-1, 1)
+    y = torch.softmax(torch.randn(2, 64, 64, 3), -1)
+    res = []
+    for quad in ("1", "0"):
+        import os
+        os.environ["USSEG_QUAD_HEAD"] = quad
+        torch.manual_seed(11)
+        net = VisionTransformer(batch_size=2, img_size=(64, 64), in_channels=1)
+        assert net.decoder.quad_head == (quad == "1")
+        loss, probs = net.train_step(x, y)
+        torch.cuda.synchronize()
+        res.append((loss.item(), probs.clone(), net.decoder.head.kernel.data.clone(), net.decoder.head.bias.data.clone(),
+                    net.flat.flat.clone()))
+    os.environ.pop("USSEG_QUAD_HEAD")
+    (l1, p1, k1, b1, f1), (l0, p0, k0, b0, f0) = res
+    assert abs(l1 - l0) < 2e-3 * abs(l0) and rel(p1, p0) < 5e-3
+    # one Adam step from identical weights: the updated head variables (sign-like Adam step) and the whole model must agree
+    assert rel(k1, k0) < 2e-2 and rel(b1, b0) < 2e-2 and rel(f1, f0) < 2e-2
