@@ -143,6 +143,7 @@ class _SlabA:
         scratch = _Workspace.get(dev, T * self.Up * self.Vp)
         ops.fill_f32(scratch, 0.0)
         ops.conv2d_wgrad(u, dv, self.k, 1, scratch)
+        ops.defer_flush()                       # 12 (path, radix) blocks > the 4 of a mapped destination: scratch is read right away
         sT = self.cv11 * self.cvkk
         for gi, (c1, _, c2, _) in enumerate(self.br):
             ops.unpack_wgrad(scratch, self.Up, self.Vp, T, self.cvkk, self.cv11, gi * self.cvkk, gi * self.cv11, c2.kernel.grad, sT, 1, self.cvkk)
@@ -152,6 +153,7 @@ class _SlabA:
         scratch = _Workspace.get(dev, self.cin_p * self.Up)
         ops.fill_f32(scratch, 0.0)
         ops.conv2d_wgrad(x, du_raw, 1, 1, scratch)
+        ops.defer_flush()
         for gi, (c1, _, c2, _) in enumerate(self.br):
             ops.unpack_wgrad(scratch, self.cin_p, self.Up, 1, self.cv11, self.cin, gi * self.cv11, 0, c1.kernel.grad, 0, 1, self.cv11)
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
@@ -446,7 +448,8 @@ class ResNest:
         ops.softmax_loss(logits, y, probs, self._loss_map, dlogits, HW=H * W, C_classes=self.num_class, loss_kind=1,
                          scale=self._scale)                                                    # :125, :234-248
         if train:
-            net.backward(dlogits)                                                              # :43 (gradient of the SUM of the map)
+            with ops.overlap_region():          # deferred / batched finishing reductions of the norm backward and bias sums
+                net.backward(dlogits)                                                          # :43 (gradient of the SUM of the map)
             if self.grad_sync is not None:
                 self.grad_sync(self.flat.grad)
             self.optimizer.apply()                                                             # :46

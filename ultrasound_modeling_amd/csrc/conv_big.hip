@@ -310,6 +310,7 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
   static const int px_env = getenv("USSEG_BIG_PX") ? atoi(getenv("USSEG_BIG_PX")) : 0;
   static const int nt_env = getenv("USSEG_BIG_NT") ? atoi(getenv("USSEG_BIG_NT")) : 0;
   static const int min_wg = getenv("USSEG_BIG_MIN_WG") ? atoi(getenv("USSEG_BIG_MIN_WG")) : 128;
+  static const int wg_min = getenv("USSEG_BIG_WG_TILE") ? atoi(getenv("USSEG_BIG_WG_TILE")) : 512;
   if (!mode) return 0;
   int nt_max = 1;
   for (int j = 0; j < njobs; ++j) nt_max = nt_for(g[j].Nout) > nt_max ? nt_for(g[j].Nout) : nt_max;
@@ -334,7 +335,7 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
         break;
       }
       best_px = PX; best_nt = nt; best_wg = wg;      // narrower tiles only add workgroups: keep the last one tried
-      if (wg >= 512 || nt_env) break;
+      if (wg >= wg_min || nt_env) break;
     }
   }
   if (!best_px || (best_wg < min_wg && !(px_env || nt_env))) return 0;
