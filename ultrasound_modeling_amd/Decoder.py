@@ -260,7 +260,7 @@ class DecoderCup(nn.Module):
         B, H, W, _, _ = ops.geom(x)
         ops.quad_bias_expand(self.head.bias.data, self.num_classes, self._bias16)
         logits = torch.empty((B, H, W, 16), dtype=torch.float32, device=x.device)
-        self._head_x = x
+        self._head_x = self.head._x = x
         return ops.conv2d_fwd(x, self._wq_f, self._bias16, 3, 1, logits, out_f32=True)
 
     def _head_backward(self, dl4):
