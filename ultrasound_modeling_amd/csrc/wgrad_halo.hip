@@ -30,20 +30,24 @@ struct WgHaloMulti {
 
 // PF: the next pixel group's operands are loaded into registers while the current group computes (the small tile shapes
 // have the registers for it; without it a group is a serial load -> LDS -> barrier -> MFMA chain of ~4 us).
-template <int WVM, int WM, int WN, bool PF>
-__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P) {
+// NTG: tap groups.  NTG = 2 runs 8 waves: waves 0-3 accumulate taps 0-4, waves 4-7 taps 5-8 of the SAME LDS tiles, which
+// halves the accumulator registers per wave (144 -> 80 for the 64x64 tile) and makes room for the prefetch registers.
+template <int WVM, int WM, int WN, bool PF, int NTG>
+__global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel(const WgHaloMulti P) {
+  constexpr int NTHR = 256 * NTG, TPG = NTG == 1 ? 9 : 5;   // threads, taps per group
   const WgHaloParams& p = P.job[blockIdx.z];
   constexpr int MAXHP = 288;
   constexpr int WVN = 4 / WVM;
   constexpr int BMc = 16 * WM * WVM, BNc = 16 * WN * WVN;      // channels per workgroup tile
   constexpr int XS = BMc + 8, YS = BNc + 8;        // LDS row strides (elements): +16 B pad
   constexpr int XCH = BMc / 8, YCH = BNc / 8;      // 16-byte chunks per pixel row
-  constexpr int X_IT = (MAXHP * XCH + 255) / 256, Y_IT = (128 * YCH + 255) / 256;
+  constexpr int X_IT = (MAXHP * XCH + NTHR - 1) / NTHR, Y_IT = (128 * YCH + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) bf16_t lds_x[MAXHP * XS];
   __shared__ __attribute__((aligned(16))) bf16_t lds_y[128 * YS];
   __shared__ int s_patch[8][8];  // per patch: b, la, lb, ly0, lx0, valid
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, tg = tid >> 8;   // tile wave, tap group
+  const int t0 = tg * TPG;
   const int mt = blockIdx.y / p.ntiles_n, nt = blockIdx.y - mt * p.ntiles_n;
   const int m0 = mt * BMc, n0 = nt * BNc;
   const int HW2 = p.PW + 2, HPP = (p.PH + 2) * HW2, NHP = p.NV * HPP;
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
   int x_geo[X_IT];  // (patch << 16) | (halo row << 8) | halo col, or -1
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
-    int idx = tid + 256 * it;
+    int idx = tid + NTHR * it;
     int hp = idx / XCH;
     x_geo[it] = -1;
     if (hp < NHP) {
@@ -65,14 +69,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
   int y_geo[Y_IT];  // (patch << 16) | (row << 8) | col
 #pragma unroll
   for (int it = 0; it < Y_IT; ++it) {
-    int idx = tid + 256 * it;
-    int pk = idx / YCH;  // 0..127
+    int idx = tid + NTHR * it;
+    int pk = (idx / YCH) & 127;  // 0..127 (threads past the tile are masked at the load)
     int s = pk >> 4, pl = pk & 15;
     int pi = s / spp, sl = s - pi * spp;
     int r = pl / p.PW, c = pl - r * p.PW;
     y_geo[it] = (pi << 16) | ((sl * rps + r) << 8) | c;
   }
-  const int xq = tid % XCH, yq = tid % YCH;  // 256 % XCH == 0 and 256 % YCH == 0, so the chunk column is fixed
+  const int xq = tid % XCH, yq = tid % YCH;  // NTHR % XCH == 0 and NTHR % YCH == 0, so the chunk column is fixed
   const bool x_cok = (m0 + xq * 8) < p.Ma, y_cok = (n0 + yq * 8) < p.Nb;
 
   // ---- fragment addressing (fixed): 16-lane group g covers K rows (pixels) 8g..8g+7 of each 32-pixel step
@@ -91,9 +95,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
       yb[ks][h] = pk * YS + wn * 16 * WN + 4 * tp;
     }
 
-  f32x4_t acc[9][WM][WN];
+  f32x4_t acc[TPG][WM][WN];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TPG; ++t)
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
   };
   auto load_y = [&](int it, int (*tab)[8]) -> uint4 {
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (tid + 256 * it >= 128 * YCH) return v;
+    if (tid + NTHR * it >= 128 * YCH) return v;
     const int* pt = tab[y_geo[it] >> 16];
     if (y_cok && pt[5]) {
       int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * (pt[3] + ((y_geo[it] >> 8) & 255))) * p.W + pt[2] + p.d * (pt[4] + (y_geo[it] & 255));
@@ -152,13 +156,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
 #pragma unroll
       for (int j = 0; j < WN; ++j) bfr[j] = tr8(lds_y, yb[ks][0] + 16 * j, yb[ks][1] + 16 * j);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int tt = 0; tt < TPG; ++tt) {
+        const int t = t0 + tt;
+        if (NTG > 1 && t >= 9) break;        // the second tap group has four taps
         const int toff = ((t / 3) * HW2 + (t % 3)) * XS;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
           bf16x8_t af = tr8(lds_x, xb[ks][0] + toff + 16 * i, xb[ks][1] + toff + 16 * i);
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[t][i][j], 0, 0, 0);
+          for (int j = 0; j < WN; ++j) acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[tt][i][j], 0, 0, 0);
         }
       }
     }
@@ -170,10 +176,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
       __syncthreads();  // patch table ready; also: previous iteration's LDS reads are done
 #pragma unroll
       for (int it = 0; it < X_IT; ++it)
-        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + 256 * it) / XCH) * XS + xq * 8]) = load_x(it, s_patch);
+        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = load_x(it, s_patch);
 #pragma unroll
       for (int it = 0; it < Y_IT; ++it)
-        if (tid + 256 * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + 256 * it) / YCH) * YS + yq * 8]) = load_y(it, s_patch);
+        if (tid + NTHR * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = load_y(it, s_patch);
       __syncthreads();
       compute();
     }
@@ -193,10 +199,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
       int (*nxt)[8] = par ? s_patch : s_patch2;
 #pragma unroll
       for (int it = 0; it < X_IT; ++it)
-        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + 256 * it) / XCH) * XS + xq * 8]) = rx[it];
+        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = rx[it];
 #pragma unroll
       for (int it = 0; it < Y_IT; ++it)
-        if (tid + 256 * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + 256 * it) / YCH) * YS + yq * 8]) = ry[it];
+        if (tid + NTHR * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = ry[it];
       const bool more = grp + 1 < g_end;
       if (more) patch_fill(grp + 1, nxt);
       __syncthreads();      // this group's tile and the next group's patch table are visible
@@ -215,11 +221,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
   // [9][Ma][Nb] slab with plain stores (summed by wgrad_finish_kernel); without one it falls back to atomics.
   float* dst = p.ws ? p.ws + (int64_t)blockIdx.x * 9 * p.Ma * p.Nb : p.out;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int tt = 0; tt < TPG; ++tt)
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
+        const int t = t0 + tt;
+        if (NTG > 1 && t >= 9) continue;
         int n = n0 + wn * 16 * WN + j * 16 + li;
         if (n >= p.Nb) continue;
 #pragma unroll
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgHaloMulti P)
           int m = m0 + wm * 16 * WM + i * 16 + g * 4 + r;
           if (m < p.Ma) {
             float* q = dst + ((int64_t)t * p.Ma + m) * p.Nb + n;
-            if (p.ws) *q = acc[t][i][j][r];
-            else atomicAdd(q, acc[t][i][j][r]);
+            if (p.ws) *q = acc[tt][i][j][r];
+            else atomicAdd(q, acc[tt][i][j][r]);
           }
         }
       }
@@ -319,15 +327,19 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   const int slot = usseg_prof_start(2, s);
   static const int pf = getenv("USSEG_WGRAD_PF") ? atoi(getenv("USSEG_WGRAD_PF")) : 1;
   if (shape == 1) {
-    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, true>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, false>), grid, dim3(256), 0, s, P);
+    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, true, 1>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, false, 1>), grid, dim3(256), 0, s, P);
   } else if (shape == 2) {
-    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, true>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, false>), grid, dim3(256), 0, s, P);
+    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, true, 1>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, false, 1>), grid, dim3(256), 0, s, P);
   } else if (shape == 3) {
-    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, true>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, false>), grid, dim3(256), 0, s, P);
-  } else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, false>), grid, dim3(256), 0, s, P);
+    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, true, 1>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, false, 1>), grid, dim3(256), 0, s, P);
+  } else {
+    static const int tg8 = getenv("USSEG_WGRAD_8W") ? atoi(getenv("USSEG_WGRAD_8W")) : 1;
+    if (tg8) hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, true, 2>), grid, dim3(512), 0, s, P);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, false, 1>), grid, dim3(256), 0, s, P);
+  }
   if (use_ws)
     for (int j = 0; j < njobs; ++j) usseg_launch_wgrad_finish(P.job[j].ws, splits, slab, gm[j].out, gm[j].map, Ma, Nb, s);
   usseg_prof_stop(2, slot, s);
