@@ -336,6 +336,31 @@ int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int3
 /* my_loss_cat scale[hw][c] = 1/(sum_b y[b,hw,c] + 1)/(H*W)  (TBI_ResNest.py:240-241) */
 int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, int32_t C, float* scale, usseg_stream_t stream);
 
+/* ---- host input pipeline on the device -----------------------------------------------------
+ * label2vec (Dataset_2.py:6-20): label [M] fp32 -> soft class maps [M][num_classes] (3: c2 = clip(l-1,0,1) where l >= 1.05,
+ * c1 = (l > 0.95) ? 1-c2 : 0, c0 = l <= 0.95; 2: (1-l, l)). */
+int usseg_label2vec(const float* label, int64_t M, int32_t num_classes, float* out, usseg_stream_t stream);
+/* dataAug (DataAugs.py:82-102) AS EXECUTED for a batch, one fused pass: imageReduc (zeroes the image where the label is 0,
+ * DataAugs.py:76-78), up to 2 clip boxes (:27-38), shift (:6-24, last row/column stay zero) and noisy (:41-51, unit Gaussian
+ * / 5000: from `noise` [B,H,W,C] if given, else a counter-based generator seeded per sample), then label2vec and the cast
+ * to the model's input.  The draws are made on the host in the reference's order and passed per sample. */
+typedef struct UssegAugSample {
+  int32_t do_reduc, nclip;
+  int32_t clip[2][4];        /* r, c, ra, ca per box */
+  int32_t do_shift, shift_r, shift_c, shift_dir;
+  int32_t do_noise, reserved;
+  uint64_t seed;
+} UssegAugSample;
+typedef struct UssegAugDesc {
+  int32_t B, H, W, C;        /* x: [B,H,W,C] fp32 or fp64, y: [B,H,W] fp32 */
+  int32_t Cphys;             /* channels of the bf16 output (multiple of 8, zero padded) */
+  int32_t num_classes;       /* for y_vec */
+} UssegAugDesc;
+/* outputs (any may be NULL except one of the x outputs): x_out_bf16 [B,H,W,Cphys], x_out_f32 [B,H,W,C], y_out [B,H,W],
+ * y_vec [B,H,W,num_classes] */
+int usseg_augment(const UssegAugDesc* d, const UssegAugSample* samples_dev, const void* x, int32_t x_is_f64, const float* y,
+                  const float* noise, void* x_out_bf16, float* x_out_f32, float* y_out, float* y_vec, usseg_stream_t stream);
+
 /* ---- bias gradient: db[c] += sum_pixels dy[m][c] --------------------------------------------- */
 int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, float* ws, usseg_stream_t stream);
 

@@ -46,6 +46,15 @@ class WgradJob(C.Structure):
     _fields_ = [("desc", ConvDesc), ("x", c_vp), ("dy", c_vp), ("dw", c_vp), ("dst", P_WgradDst)]
 
 
+class AugSample(C.Structure):
+    _fields_ = [("do_reduc", c_i32), ("nclip", c_i32), ("clip", (c_i32 * 4) * 2), ("do_shift", c_i32), ("shift_r", c_i32),
+                ("shift_c", c_i32), ("shift_dir", c_i32), ("do_noise", c_i32), ("reserved", c_i32), ("seed", C.c_uint64)]
+
+
+class AugDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("H", c_i32), ("W", c_i32), ("C", c_i32), ("Cphys", c_i32), ("num_classes", c_i32)]
+
+
 class NormDesc(C.Structure):
     _fields_ = [("M", c_i64), ("C", c_i32), ("Cphys", c_i32), ("ldx", c_i32), ("ldy", c_i32), ("G", c_i32),
                 ("mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32), ("lddx", c_i32)]
@@ -127,6 +136,8 @@ _PROTOS = {
     "usseg_quad_bias_expand": (C.c_int, [c_vp, c_i32, c_vp, c_vp]),
     "usseg_quad_bias_fold": (C.c_int, [c_vp, c_i32, c_vp, c_vp]),
     "usseg_tconv_quad_unpack": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_label2vec": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "usseg_augment": (C.c_int, [P(AugDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_loss_cat_scale": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "usseg_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "usseg_sumsq": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),

@@ -536,7 +536,12 @@ __global__ __launch_bounds__(256) void cast_input_kernel(const T* src, int64_t M
     int c0 = (int)(i - m * CH) * 8;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? (float)src[m * C + c0 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      v[j] = (c0 + j < C) ? (float)src[m * C + c0 + j] : 0.f;
+      // fp64 input: the float32 value (Keras' layer autocast) must exist before the bf16 rounding - without this fence the
+      // compiler fuses double -> float -> bf16 into one rounding, which differs on exact float ties (seen 4 in 600k)
+      asm volatile("" : "+v"(v[j]));
+    }
     *reinterpret_cast<uint4*>(dst + m * Cphys + c0) = pack8(v);
   }
 }
