@@ -233,16 +233,17 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   int64_t gx = cdiv64(p.M, 128);
   USSEG_CHECK_ARG(gx < (1ll << 31), "igemm: too many pixel tiles");
   const unsigned gz = p.cls_mode ? 4 : (p.nb2 > 0 ? (unsigned)p.nbatch : 1);
+  // channel tile: the widest that covers Nout, narrowed while the launch has fewer workgroups than CUs (the 16x16 stages
+  // are 32 pixel tiles: a 128-channel tile leaves 3/4 of the chip idle - the b0.up backward-data ran 63 us on 64 workgroups)
+  static const int wg_min = getenv("USSEG_IGEMM_WG_MIN") ? atoi(getenv("USSEG_IGEMM_WG_MIN")) : 256;
+  int nt = p.Nout <= 16 ? 1 : (p.Nout <= 32 ? 2 : (p.Nout <= 64 ? 4 : 8));
+  while (nt > 2 && gx * ((p.Nout + 16 * nt - 1) / (16 * nt)) * gz < wg_min) nt >>= 1;
+  const unsigned gy = (unsigned)((p.Nout + 16 * nt - 1) / (16 * nt));
   const int slot = usseg_prof_start(1, s);
-  if (p.Nout <= 16) {
-    hipLaunchKernelGGL(igemm_kernel<1>, dim3((unsigned)gx, 1, gz), block, 0, s, p);
-  } else if (p.Nout <= 32) {
-    hipLaunchKernelGGL(igemm_kernel<2>, dim3((unsigned)gx, 1, gz), block, 0, s, p);
-  } else if (p.Nout <= 64) {
-    hipLaunchKernelGGL(igemm_kernel<4>, dim3((unsigned)gx, 1, gz), block, 0, s, p);
-  } else {
-    hipLaunchKernelGGL(igemm_kernel<8>, dim3((unsigned)gx, (unsigned)((p.Nout + 127) / 128), gz), block, 0, s, p);
-  }
+  if (nt == 1) hipLaunchKernelGGL(igemm_kernel<1>, dim3((unsigned)gx, gy, gz), block, 0, s, p);
+  else if (nt == 2) hipLaunchKernelGGL(igemm_kernel<2>, dim3((unsigned)gx, gy, gz), block, 0, s, p);
+  else if (nt == 4) hipLaunchKernelGGL(igemm_kernel<4>, dim3((unsigned)gx, gy, gz), block, 0, s, p);
+  else hipLaunchKernelGGL(igemm_kernel<8>, dim3((unsigned)gx, gy, gz), block, 0, s, p);
   usseg_prof_stop(1, slot, s);
   return usseg_check_launch("igemm");
 }
