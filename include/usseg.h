@@ -215,6 +215,10 @@ int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const float* gamma
                        const float* mean, const float* var, const void* mask, int32_t ldm, void* y, usseg_stream_t stream);
 /* tf.nn.dropout mask (TBI_ResNest.py:216): mask = keep ? 1/(1-rate) : 0 from a counter-based hash of (seed, index). */
 int usseg_dropout_mask(void* mask, int64_t M, int32_t C, int32_t ld, uint64_t seed, float rate, usseg_stream_t stream);
+/* Same, with a device-resident step counter mixed into the seed (the optimiser's step variable): a captured HIP graph of the
+ * training step then draws a fresh mask at every replay. */
+int usseg_dropout_mask_step(void* mask, int64_t M, int32_t C, int32_t ld, uint64_t seed, const int32_t* step_dev, float rate,
+                            usseg_stream_t stream);
 /* dx, and dgamma/dbeta accumulated.  x is the SAME pre-normalisation input as in fwd. */
 int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma, const float* beta,
                        const float* mean, const float* var, const void* mask, int32_t ldm, void* dx, float* dgamma,

@@ -15,3 +15,11 @@ for i in range(5):
     torch.cuda.synchronize()
     print(f"step {i}: {(time.perf_counter() - t0) * 1e3:.2f} ms  loss {lm.sum().item():.4f}", flush=True)
 print(f"images/s {B / (time.perf_counter() - t0):.1f}")
+if len(sys.argv) > 3 and sys.argv[3] == "graph":
+    net.capture_graph(x, y)
+    ts = []
+    for i in range(20):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        lm, acc, _ = net.step(x, y, train=True)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f"graph: min {min(ts) * 1e3:.2f} ms  loss {lm.sum().item():.4f}  images/s {B / min(ts):.1f}")

@@ -290,7 +290,7 @@ class _ResModel(nn.Module):
             return None if m is None else m
         mask = torch.empty_like(like)
         self.dropout_seed += 1
-        return ops.dropout_mask(mask, self.dropout_seed * 7919 + i, 0.5)             # tf.nn.dropout(out, 0.5), :216
+        return ops.dropout_mask(mask, self.dropout_seed * 7919 + i, 0.5, getattr(self, "step_dev", None))   # tf.nn.dropout(out, 0.5), :216
 
     def forward(self, x, return_logits=False):
         if x.dtype != BF16:
@@ -398,6 +398,8 @@ class ResNest:
         self._loss_map = torch.zeros(height * width, dtype=torch.float32, device=self.device)
         self._scale = torch.zeros(height * width * num_class, dtype=torch.float32, device=self.device)
         self.grad_sync = None
+        self._graph = None
+        self.resModel.step_dev = self.optimizer.step_dev      # dropout masks follow the device step counter (graph replays)
 
     # parameters in / out under the Keras layer names ------------------------------------------------------------------
     def load_params(self, params: dict):
@@ -432,10 +434,70 @@ class ResNest:
     def my_loss_cat(self, y_true, y_pred):
         raise NotImplementedError("fused with the head softmax (usseg_softmax_loss_fwd_bwd, loss_kind=1); use step()")
 
+    # ---- HIP-graph replay of the training step (as VisionTransformer.capture_graph): one graph, or two around the all-reduce
+    def _grad_body(self, x, y):
+        net = self.resModel
+        self.flat.zero_grad()
+        logits = net.forward(x, return_logits=True)
+        B, H, W, _ = logits.shape
+        probs = torch.empty((B, H, W, self.num_class), dtype=torch.float32, device=self.device)
+        dlogits = ops.new_act(B, H, W, 8, self.device)
+        ops.loss_cat_scale(y, self._scale)
+        ops.fill_f32(self._loss_map, 0.0)
+        ops.softmax_loss(logits, y, probs, self._loss_map, dlogits, HW=H * W, C_classes=self.num_class, loss_kind=1, scale=self._scale)
+        with ops.overlap_region():
+            net.backward(dlogits)
+        return probs
+
+    def _update_body(self):
+        self.optimizer.apply()
+        self.resModel.repack()
+
+    def capture_graph(self, x, y, warmup: int = 2):
+        x = torch.as_tensor(x).to(self.device).contiguous()
+        y = torch.as_tensor(y).to(device=self.device, dtype=torch.float32).contiguous()
+        self._gx, self._gy = x.clone(), y.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._grad_body(self._gx, self._gy)
+                self._update_body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        if self.grad_sync is None:
+            with torch.cuda.graph(g1):
+                self._gprobs = self._grad_body(self._gx, self._gy)
+                self._update_body()
+            self._graph = (g1, None)
+        else:
+            with torch.cuda.graph(g1):
+                self._gprobs = self._grad_body(self._gx, self._gy)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._update_body()
+            self._graph = (g1, g2)
+
+    def _graph_step(self, x, y):
+        self._gx.copy_(x)
+        self._gy.copy_(y)
+        g1, g2 = self._graph
+        g1.replay()
+        if g2 is not None:
+            self.grad_sync(self.flat.grad)
+            g2.replay()
+        H, W = self.height, self.width
+        probs = self._gprobs
+        accuracy = (probs.argmax(dim=-1) == self._gy.argmax(dim=-1)).float().mean()
+        return self._loss_map.clone().reshape(H, W), accuracy, probs
+
     def step(self, x, y, train=False):
         """TBI_ResNest.py:35-55."""
         x = torch.as_tensor(x).to(self.device).contiguous()
         y = torch.as_tensor(y).to(device=self.device, dtype=torch.float32).contiguous()
+        if train and self._graph is not None:
+            return self._graph_step(x, y)
         net = self.resModel
         if train:
             self.flat.zero_grad()

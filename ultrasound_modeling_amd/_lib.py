@@ -112,6 +112,7 @@ _PROTOS = {
                                      c_f32, c_i32, c_vp]),
     "usseg_norm_act_fwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_dropout_mask": (C.c_int, [c_vp, c_i64, c_i32, c_i32, C.c_uint64, c_f32, c_vp]),
+    "usseg_dropout_mask_step": (C.c_int, [c_vp, c_i64, c_i32, c_i32, C.c_uint64, c_vp, c_f32, c_vp]),
     "usseg_norm_act_bwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_reduce_ws_floats": (c_i64, []),
     "usseg_channel_stats": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),

@@ -703,7 +703,11 @@ __device__ __forceinline__ uint32_t hash32(uint64_t v) {
   v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
   return (uint32_t)v;
 }
-__global__ __launch_bounds__(256) void dropout_mask_kernel(bf16_t* mask, int64_t M, int CH, int ld, uint64_t seed, float rate) {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(bf16_t* mask, int64_t M, int CH, int ld, uint64_t seed, float rate,
+                                                           const int32_t* step_dev) {
+  // step_dev (optional): a device-resident step counter mixed into the seed, so that a captured HIP graph draws a fresh mask
+  // at every replay (the host-side seed of a captured launch is frozen)
+  if (step_dev) seed += (uint64_t)(uint32_t)(*step_dev) * 0x2545F4914F6CDD1DULL;
   const int64_t total = M * CH;
   const float keep_scale = 1.f / (1.f - rate);
   const uint32_t thr = (uint32_t)(rate * 4294967296.0);
@@ -720,8 +724,16 @@ extern "C" int usseg_dropout_mask(void* mask, int64_t M, int32_t C, int32_t ld, 
   USSEG_CHECK_ARG(mask && C % 8 == 0 && ld % 8 == 0 && rate >= 0.f && rate < 1.f, "dropout_mask: bad args");
   if (M <= 0) return USSEG_OK;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(M * (C / 8), 256 * 2, 4096)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)mask, M,
-                     C / 8, ld, seed, rate);
+                     C / 8, ld, seed, rate, (const int32_t*)nullptr);
   return usseg_check_launch("dropout_mask");
+}
+extern "C" int usseg_dropout_mask_step(void* mask, int64_t M, int32_t C, int32_t ld, uint64_t seed, const int32_t* step_dev, float rate,
+                                       usseg_stream_t stream) {
+  USSEG_CHECK_ARG(mask && step_dev && C % 8 == 0 && ld % 8 == 0 && rate >= 0.f && rate < 1.f, "dropout_mask_step: bad args");
+  if (M <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(M * (C / 8), 256 * 2, 4096)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)mask, M,
+                     C / 8, ld, seed, rate, step_dev);
+  return usseg_check_launch("dropout_mask_step");
 }
 
 // ---- BatchNormalization TRAINING mode (Keras: batch mean / biased variance, moving statistics updated with momentum) -------

@@ -411,8 +411,12 @@ def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, ep
     return dx
 
 
-def dropout_mask(mask, seed: int, rate: float):
+def dropout_mask(mask, seed: int, rate: float, step_dev=None):
+    """``step_dev``: int32 device counter mixed into the seed (fresh masks when the launch is replayed from a HIP graph)."""
     B, H, W, Cc, ld = geom(mask)
+    if step_dev is not None:
+        L.check(L.load().usseg_dropout_mask_step(mask.data_ptr(), B * H * W, Cc, ld, seed, step_dev.data_ptr(), rate, _stream()), "dropout_mask_step")
+        return mask
     L.check(L.load().usseg_dropout_mask(mask.data_ptr(), B * H * W, Cc, ld, seed, rate, _stream()), "dropout_mask")
     return mask
 
