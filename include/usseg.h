@@ -191,6 +191,16 @@ int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t njobs, usse
 int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t Ncols, int32_t T, int32_t Nn, int32_t Kk,
                        int32_t n_off, int32_t k_off, float* dst, int64_t sT, int64_t sN, int64_t sK,
                        float scale, int32_t accumulate, usseg_stream_t stream);
+/* Several unpacks in one launch (device-resident job table, static pointers): the per-branch blocks of a grouped gradient. */
+typedef struct UssegUnpackJob {
+  const float* scratch;
+  float* dst;
+  int64_t sT, sN, sK;
+  int32_t Mrows, Ncols, T, Nn, Kk, n_off, k_off, accumulate;
+  float scale;
+  int32_t reserved;
+} UssegUnpackJob;
+int usseg_unpack_wgrad_batched(const UssegUnpackJob* jobs_dev, int32_t njobs, int32_t max_elems, usseg_stream_t stream);
 
 /* ---- normalisation + activation (bf16 rows of C channels, G groups of Cg = C/G) ---------------
  * mode 0: LayerNormalization(axis=-1, eps) per pixel and per group (ResNest.py:86,125,132,164; Decoder.py:112)

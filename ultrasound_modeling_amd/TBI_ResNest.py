@@ -131,6 +131,22 @@ class _SlabA:
         self._saved = (x, u_raw, u, v_raw, y, g, s, ws)
         return out
 
+    def _unpack_tables(self, dev):
+        """Private scratch gradients of the two grouped convs + the device job tables that scatter their diagonal blocks."""
+        key = self.br[0][0].kernel.grad.data_ptr()
+        if getattr(self, "_unp_key", None) != key:
+            T = self.k * self.k
+            s1 = torch.zeros(self.cin_p * self.Up, dtype=torch.float32, device=dev)
+            s2 = torch.zeros(T * self.Up * self.Vp, dtype=torch.float32, device=dev)
+            sT = self.cv11 * self.cvkk
+            j1 = [ops.unpack_job(s1, self.cin_p, self.Up, 1, self.cv11, self.cin, gi * self.cv11, 0, c1.kernel.grad, 0, 1, self.cv11)
+                  for gi, (c1, _, c2, _) in enumerate(self.br)]
+            j2 = [ops.unpack_job(s2, self.Up, self.Vp, T, self.cvkk, self.cv11, gi * self.cvkk, gi * self.cv11, c2.kernel.grad, sT, 1, self.cvkk)
+                  for gi, (c1, _, c2, _) in enumerate(self.br)]
+            self._unp = (s1, s2, ops.make_unpack_table(j1, dev), ops.make_unpack_table(j2, dev))
+            self._unp_key = key
+        return self._unp
+
     def backward(self, dout, dx_residual=None):
         x, u_raw, u, v_raw, y, g, s, ws = self._saved
         B, H, W, _, _ = ops.geom(x)
@@ -140,22 +156,18 @@ class _SlabA:
         dy = ops.splitattn_bwd(d, y, dout, self.mlp_p, self.mlp_g, g, s, ws, torch.empty_like(y))
         dv = ops.norm_act_bwd(v_raw, dy, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, 1, 1, e, ACT_ELU, 1.0,
                               self.m2, self.v2, dbias=self.db2)
-        scratch = _Workspace.get(dev, T * self.Up * self.Vp)
-        ops.fill_f32(scratch, 0.0)
-        ops.conv2d_wgrad(u, dv, self.k, 1, scratch)
+        s1, s2, tab1, tab2 = self._unpack_tables(dev)
+        ops.fill_f32(s2, 0.0)
+        ops.conv2d_wgrad(u, dv, self.k, 1, s2)
         ops.defer_flush()                       # 12 (path, radix) blocks > the 4 of a mapped destination: scratch is read right away
-        sT = self.cv11 * self.cvkk
-        for gi, (c1, _, c2, _) in enumerate(self.br):
-            ops.unpack_wgrad(scratch, self.Up, self.Vp, T, self.cvkk, self.cv11, gi * self.cvkk, gi * self.cv11, c2.kernel.grad, sT, 1, self.cvkk)
+        ops.unpack_wgrad_batched(tab2)          # all diagonal blocks of the slab in one launch
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, 1, torch.empty_like(u))
         du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, 1, 1, e, ACT_ELU, 1.0,
                                   self.m1, self.v1, dbias=self.db1)
-        scratch = _Workspace.get(dev, self.cin_p * self.Up)
-        ops.fill_f32(scratch, 0.0)
-        ops.conv2d_wgrad(x, du_raw, 1, 1, scratch)
+        ops.fill_f32(s1, 0.0)
+        ops.conv2d_wgrad(x, du_raw, 1, 1, s1)
         ops.defer_flush()
-        for gi, (c1, _, c2, _) in enumerate(self.br):
-            ops.unpack_wgrad(scratch, self.cin_p, self.Up, 1, self.cv11, self.cin, gi * self.cv11, 0, c1.kernel.grad, 0, 1, self.cv11)
+        ops.unpack_wgrad_batched(tab1)
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
 
 
@@ -366,12 +378,8 @@ class _ResModel(nn.Module):
     def _tconv_backward(layer, dy):
         # Conv2DTranspose.backward computes the bias gradient itself; here it came from the BN backward (dbias)
         x = layer._x
-        T = layer.k * layer.k
-        scratch = _Workspace.get(dy.device, T * layer.cin_p * layer.cout_p)
-        ops.fill_f32(scratch, 0.0)
-        ops.tconv2d_wgrad(x, dy, layer.k, scratch)
-        sT, sI, sO = layer._strides_tio()
-        ops.unpack_wgrad(scratch, layer.cin_p, layer.cout_p, T, layer.cout, layer.cin, 0, 0, layer.kernel.grad, sT, sO, sI)
+        with ops.side_stream(x, dy):           # straight into the Keras [k,k,Cout,Cin] variable, slabs instead of atomics
+            ops.tconv2d_wgrad_mapped(x, dy, layer.k, layer._wgrad_map())
         B, H, W, _, _ = ops.geom(x)
         return ops.tconv2d_dgrad(dy, layer.wp_d, layer.k, ops.new_act(B, H, W, layer.cin_p, dy.device))
 

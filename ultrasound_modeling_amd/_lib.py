@@ -110,6 +110,7 @@ _PROTOS = {
     "usseg_pack_weights_batched": (C.c_int, [c_vp, c_i32, c_vp]),
     "usseg_unpack_wgrad": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_i64,
                                      c_f32, c_i32, c_vp]),
+    "usseg_unpack_wgrad_batched": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),
     "usseg_norm_act_fwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "usseg_dropout_mask": (C.c_int, [c_vp, c_i64, c_i32, c_i32, C.c_uint64, c_f32, c_vp]),
     "usseg_dropout_mask_step": (C.c_int, [c_vp, c_i64, c_i32, c_i32, C.c_uint64, c_vp, c_f32, c_vp]),

@@ -617,6 +617,28 @@ extern "C" int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t N
   return usseg_check_launch("unpack_wgrad");
 }
 
+// several unpacks (the per-branch diagonal blocks of a grouped weight gradient) in ONE launch: blockIdx.y = job
+__global__ __launch_bounds__(256) void unpack_wgrad_batched_kernel(const UssegUnpackJob* jobs) {
+  const UssegUnpackJob j = jobs[blockIdx.y];
+  const int total = j.T * j.Nn * j.Kk;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int n = i % j.Nn;
+    int r = i / j.Nn;
+    int k = r % j.Kk;
+    int t = r / j.Kk;
+    float v = j.scale * j.scratch[((int64_t)t * j.Mrows + j.k_off + k) * j.Ncols + j.n_off + n];
+    float* d = j.dst + t * j.sT + n * j.sN + k * j.sK;
+    *d = j.accumulate ? *d + v : v;
+  }
+}
+extern "C" int usseg_unpack_wgrad_batched(const UssegUnpackJob* jobs_dev, int32_t njobs, int32_t max_elems, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(jobs_dev && njobs > 0 && njobs < 65536 && max_elems > 0, "unpack_wgrad_batched: bad args");
+  int gx = (max_elems + 255) / 256;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(unpack_wgrad_batched_kernel, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  return usseg_check_launch("unpack_wgrad_batched");
+}
+
 // ---- all operand packs of a model in ONE launch: blockIdx.y = job ---------------------------------------------
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const UssegPackJob* jobs) {
   const UssegPackJob j = jobs[blockIdx.y];

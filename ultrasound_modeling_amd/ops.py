@@ -385,6 +385,25 @@ def unpack_wgrad(scratch, Mrows, Ncols, T, Nn, Kk, n_off, k_off, dst, sT, sN, sK
                                         scale, 1 if accumulate else 0, _stream()), "unpack_wgrad")
 
 
+UNPACK_JOB_DTYPE = [("scratch", "<u8"), ("dst", "<u8"), ("sT", "<i8"), ("sN", "<i8"), ("sK", "<i8"), ("Mrows", "<i4"), ("Ncols", "<i4"), ("T", "<i4"),
+                    ("Nn", "<i4"), ("Kk", "<i4"), ("n_off", "<i4"), ("k_off", "<i4"), ("accumulate", "<i4"), ("scale", "<f4"), ("reserved", "<i4")]
+
+
+def unpack_job(scratch, Mrows, Ncols, T, Nn, Kk, n_off, k_off, dst, sT, sN, sK, scale=1.0, accumulate=True):
+    return (scratch.data_ptr(), dst.data_ptr(), sT, sN, sK, Mrows, Ncols, T, Nn, Kk, n_off, k_off, 1 if accumulate else 0, scale, 0)
+
+
+def make_unpack_table(jobs, device):
+    import numpy as np
+    arr = np.array(jobs, dtype=UNPACK_JOB_DTYPE)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(jobs), int(max(j[7] * j[8] * j[9] for j in jobs))
+
+
+def unpack_wgrad_batched(table):
+    t, n, mx = table
+    L.check(L.load().usseg_unpack_wgrad_batched(t.data_ptr(), n, mx, _stream()), "unpack_wgrad_batched")
+
+
 # ------------------------------------------------------------------------------------------------ norm / act / pool
 def _norm_desc(x, C_logical, out_ld, G, mode, eps, act, alpha) -> NormDesc:
     B, H, W, Cphys, ldx = geom(x)
