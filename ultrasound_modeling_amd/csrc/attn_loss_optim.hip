@@ -22,9 +22,12 @@ __global__ __launch_bounds__(256) void sa_reduce_kernel(const bf16_t* y, const b
   for (int j = 0; j < 8; ++j) s[j] = 0.f;
   // output-channel index of each of this lane's y channels (only needed for R > 1)
   int co[8];
+  float cok[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int cy = chunk * 8 + j;
+    cok[j] = cy < Cy ? 1.f : 0.f;
+    cy = min(cy, Cy - 1);   // clamped: the loads below are unconditional (a load under a per-element condition serialises)
     int pr = cy / Cg;  // = p*R + r
     co[j] = (pr / R) * Cg + (cy - pr * Cg);
   }
@@ -43,9 +46,11 @@ __global__ __launch_bounds__(256) void sa_reduce_kernel(const bf16_t* y, const b
 #pragma unroll
           for (int j = 0; j < 8; ++j) s[j] += v[j] * d[j];
         } else {
+          float dv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (chunk * 8 + j < Cy) s[j] += v[j] * bf2f(db[m * lddo + co[j]]);
+          for (int j = 0; j < 8; ++j) dv[j] = bf2f(db[m * lddo + co[j]]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[j] += cok[j] * v[j] * dv[j];
         }
       } else {
 #pragma unroll
@@ -333,18 +338,25 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const bf16_t* in, const f
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Co) ? mult * v[j] * sv[j] : 0.f;
       } else {
+        // R <= 4 distinct branches: all R*8 (value, weight) pairs are loaded unconditionally at clamped indices first
+        float xv[4][8], wv[4][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          int c = c0 + j;
-          float acc = 0.f;
-          if (c < Co) {
-            int p = c / Cg, cc = c - p * Cg;
-            for (int r = 0; r < R; ++r) {
-              int cy = (p * R + r) * Cg + cc;
-              acc += bf2f(in[pix * ldi + cy]) * s[(int64_t)b * Cy + cy];
-            }
+          const int c = min(c0 + j, Co - 1);
+          const int p = c / Cg, cc = c - p * Cg;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int cy = (p * R + min(r, R - 1)) * Cg + cc;
+            xv[r][j] = bf2f(in[pix * ldi + cy]);
+            wv[r][j] = s[(int64_t)b * Cy + cy];
           }
-          o[j] = mult * acc;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float acc = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc += r < R ? xv[r][j] * wv[r][j] : 0.f;
+          o[j] = (c0 + j < Co) ? mult * acc : 0.f;
         }
       }
     } else {
@@ -361,17 +373,18 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const bf16_t* in, const f
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Cy) ? mult * v[j] * sv[j] + dv[j] : 0.f;
       } else {
+        float dv[8], sv[8], gv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          int cy = c0 + j;
-          float v = 0.f;
-          if (cy < Cy) {
-            int pr = cy / Cg;
-            int co = (pr / R) * Cg + (cy - pr * Cg);
-            v = mult * bf2f(in[pix * ldi + co]) * s[(int64_t)b * Cy + cy] + dg[(int64_t)b * Cy + cy];
-          }
-          o[j] = v;
+          const int cy = min(c0 + j, Cy - 1);
+          const int pr = cy / Cg;
+          const int co = (pr / R) * Cg + (cy - pr * Cg);
+          dv[j] = bf2f(in[pix * ldi + co]);
+          sv[j] = s[(int64_t)b * Cy + cy];
+          gv[j] = dg[(int64_t)b * Cy + cy];
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Cy) ? mult * dv[j] * sv[j] + gv[j] : 0.f;
       }
     }
     *reinterpret_cast<uint4*>(out + pix * ldo + c0) = pack8(o);
