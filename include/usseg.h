@@ -338,14 +338,15 @@ typedef struct UssegLossDesc {
 } UssegLossDesc;
 int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, const float* y_true, const float* scale,
                                float* probs, float* loss, void* dlogits, usseg_stream_t stream);
-/* The 3-class head Conv2DTranspose(3x3, stride 2) (Decoder.py:120) in "quad" form: a 2x2-tap stride-1 convolution at the INPUT
- * resolution whose 16 output channels are (output parity class)*4 + n, run by usseg_conv2d_fwd/dgrad/wgrad as a 3x3 conv with
- * five all-zero taps.  These helpers move the bias and the gradients between the Keras variables and that form:
- * bias16[cls*4+n] = bias[n];  dbias[n] += sum_cls d16[cls*4+n];  grad[kh][kw][n][c] += dq[tap][c][cls*4+n] with
- * tap = stencil index of offset (-(kh>>1), -(kw>>1)), cls = (kh&1)*2 + (kw&1), dq = [9][Cin_phys][16]. */
+/* The <= 4-class head Conv2DTranspose(k x k, stride 2, 'same') (Decoder.py:120 k=3; TBI_ResNest.py:124 k=4) in "quad" form: a
+ * stride-1 convolution at the INPUT resolution whose 16 output channels are (output parity class)*4 + n, run by
+ * usseg_conv2d_fwd/dgrad/wgrad as a 3x3 conv (each parity uses <= 2x2 of the stencil taps, the rest are zero).  With
+ * pad = (k==4): kernel tap kh feeds output parity a = (kh+pad)&1 from source offset di = (a+pad-kh)/2.  These helpers move
+ * the bias and the gradients between the Keras variables and that form: bias16[cls*4+n] = bias[n];
+ * dbias[n] += sum_cls d16[cls*4+n];  grad[kh][kw][n][c] += dq[(di+1)*3+(dj+1)][c][(a*2+b)*4+n], dq = [9][Cin_phys][16]. */
 int usseg_quad_bias_expand(const float* bias, int32_t C, float* bias16, usseg_stream_t stream);
 int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, usseg_stream_t stream);
-int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, float* grad, usseg_stream_t stream);
+int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t ksize, float* grad, usseg_stream_t stream);
 
 /* my_loss_cat scale[hw][c] = 1/(sum_b y[b,hw,c] + 1)/(H*W)  (TBI_ResNest.py:240-241) */
 int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, int32_t C, float* scale, usseg_stream_t stream);

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import ops
 from .layers import (KERAS_BN_EPS, KERAS_LRELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, LayerNormalization,
-                     LeakyReLU)
+                     LeakyReLU, QuadHead)
 from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 
 
@@ -225,57 +225,20 @@ class DecoderCup(nn.Module):
         # <= 4 classes: the head runs in "quad" form - a 2x2-tap conv at the input resolution whose 16 channels are the four
         # output parities (one HBM-bound launch each way instead of a 4-class gather GEMM and a 9-tap per-tap weight gradient)
         self.quad_head = num_classes <= 4 and os.environ.get("USSEG_QUAD_HEAD", "1") != "0"
-        if self.quad_head:
-            self.head.on_finalize = lambda device: None
+        self._quad = QuadHead(self.head) if self.quad_head else None
 
     def on_finalize(self, device):
-        if not self.quad_head:
-            return
-        cin_p = self.head.cin_p
-        self._wq_f = torch.zeros((16, 9 * cin_p), dtype=BF16, device=device)
-        self._wq_d = torch.zeros((roundup(cin_p, 16), 9 * 16), dtype=BF16, device=device)
-        self._bias16 = torch.zeros(16, dtype=torch.float32, device=device)
-        self._d16 = torch.zeros(16, dtype=torch.float32, device=device)
-        self._dq = torch.zeros(9 * cin_p * 16, dtype=torch.float32, device=device)
-        jobs = self.pack_jobs()
-        ops.pack_weights_batched(ops.make_pack_table(jobs, device), len(jobs))
+        if self._quad is not None:
+            self._quad.on_finalize(device)
 
     def pack_jobs(self):
-        """Quad-form operands of the head from its Keras kernel [3,3,Cout,Cin]: tap (kh,kw) -> stencil offset (-(kh>>1), -(kw>>1)),
-        output rows (kh&1)*2 + (kw&1) (the parity class) * 4 + n."""
-        if not self.quad_head:
-            return []
-        h = self.head
-        jobs = []
-        for kh in range(3):
-            for kw in range(3):
-                src = h.kernel.data[kh, kw]                       # [Cout][Cin] view
-                t = (1 - (kh >> 1)) * 3 + (1 - (kw >> 1))
-                cls = (kh & 1) * 2 + (kw & 1)
-                jobs.append(ops.pack_job(src, 0, h.cin, 1, 1, h.cout, h.cin, self._wq_f, 9 * h.cin_p, h.cin_p, cls * 4, t * h.cin_p))
-                jobs.append(ops.pack_job(src, 0, 1, h.cin, 1, h.cin, h.cout, self._wq_d, 9 * 16, 16, 0, t * 16 + cls * 4))
-        return jobs
+        return self._quad.pack_jobs() if self._quad is not None else []
 
     def _head_forward(self, x):
-        B, H, W, _, _ = ops.geom(x)
-        ops.quad_bias_expand(self.head.bias.data, self.num_classes, self._bias16)
-        logits = torch.empty((B, H, W, 16), dtype=torch.float32, device=x.device)
-        self._head_x = self.head._x = x
-        return ops.conv2d_fwd(x, self._wq_f, self._bias16, 3, 1, logits, out_f32=True)
+        return self._quad.forward(x)
 
     def _head_backward(self, dl4):
-        """dl4: bf16 [B,h,w,16] gradient of the quad-form logits -> dx [B,h,w,cin]."""
-        h, x = self.head, self._head_x
-        with ops.side_stream(x, dl4):
-            ops.fill_f32(self._dq, 0.0)
-            ops.fill_f32(self._d16, 0.0)
-            ops.conv2d_wgrad(x, dl4, 3, 1, self._dq)
-            ops.colsum(dl4, self._d16, 16)
-            ops.defer_flush()                                      # _dq / _d16 are read right away
-            ops.tconv_quad_unpack(self._dq, h.cin_p, h.cin, h.cout, h.kernel.grad)
-            ops.quad_bias_fold(self._d16, h.cout, h.bias.grad)
-        B, H, W, _, _ = ops.geom(x)
-        return ops.conv2d_dgrad(dl4, self._wq_d, 3, 1, ops.new_act(B, H, W, h.cin_p, x.device))
+        return self._quad.backward(dl4)
 
     def forward(self, hidden_states, features: Optional[List[torch.Tensor]] = None, return_logits=False):
         assert features is not None, "this implementation is built for the skip-connected configuration the drivers use"

@@ -15,6 +15,7 @@ Arch B; stages whose branch channels exceed 512 (kpaths*radix*cvkk = 768) are pr
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -22,7 +23,7 @@ import torch.nn as nn
 
 from . import ops
 from .flat import AdamClip, FlatParams
-from .layers import (KERAS_BN_EPS, KERAS_ELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, _Workspace)
+from .layers import (KERAS_BN_EPS, KERAS_ELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, QuadHead, _Workspace)
 from .ops import ACT_ELU, ACT_NONE, ACT_RELU, BF16, roundup
 
 
@@ -258,6 +259,7 @@ class _ResModel(nn.Module):
             add(name + "_bn", BatchNormalization(oc))                                # :213
             cin = oc + sk
         add("f_tran", Conv2DTranspose(cin, num_class, 4, **G))                       # :124
+        self._quad = QuadHead(self.f_tran) if (num_class <= 4 and os.environ.get("USSEG_QUAD_HEAD", "1") != "0") else None
         self._stages = None
         self.dropout_seed = 0
         self.injected_masks = None      # tests inject {0,1} keep masks to make the always-on dropout deterministic
@@ -279,12 +281,16 @@ class _ResModel(nn.Module):
         for st in self._build():
             for sl in st.slabs:
                 sl.on_finalize(device)
+        if self._quad is not None:
+            self._quad.on_finalize(device)
 
     def pack_jobs(self):
         jobs = [j for st in self._build() for sl in st.slabs for j in sl.pack_jobs()]
         for m in self.modules():
             if isinstance(m, Conv2D) and m.wp_f is not None:
                 jobs += m.pack_jobs()
+        if self._quad is not None:
+            jobs += self._quad.pack_jobs()
         return jobs
 
     def repack(self):
@@ -333,17 +339,23 @@ class _ResModel(nn.Module):
             ops.copy_channels(skip, cat[..., oc:])                                     # tf.concat (:110-122)
             self._cats.append(cat); self._masks.append(mask); self._upraw.append(raw)
             u = cat
-        logits = g("f_tran").forward(u, out_f32=True)                                  # :124
+        B, H, W = u.shape[0], 2 * u.shape[1], 2 * u.shape[2]
+        self.out_hw = (H, W)
+        # :124; logits fp32 [B,H,W,4] or, in quad form, [B,H/2,W/2,16] (ops.softmax_loss indexes it through quad_w)
+        logits = self._quad.forward(u) if self._quad is not None else g("f_tran").forward(u, out_f32=True)
         if return_logits:
             return logits
-        B, H, W, _ = logits.shape
         probs = torch.empty((B, H, W, self.num_class), dtype=torch.float32, device=logits.device)
-        ops.softmax_loss(logits, None, probs, None, None, HW=H * W, C_classes=self.num_class)    # :125
+        ops.softmax_loss(logits, None, probs, None, None, HW=H * W, C_classes=self.num_class, quad_w=self.quad_w)    # :125
         return probs
+
+    @property
+    def quad_w(self):
+        return self.out_hw[1] if self._quad is not None else 0
 
     def backward(self, dlogits):
         g = lambda n: getattr(self, n)
-        d = g("f_tran").backward(dlogits)
+        d = self._quad.backward(dlogits) if self._quad is not None else g("f_tran").backward(dlogits)
         dpool = [None] * 6                    # gradients w.r.t. pool1..pool6 outputs coming from the decoder skips
         for i in reversed(range(5)):
             name, oc, drop = self.UPS[i]
@@ -447,12 +459,12 @@ class ResNest:
         net = self.resModel
         self.flat.zero_grad()
         logits = net.forward(x, return_logits=True)
-        B, H, W, _ = logits.shape
+        B, (H, W), qw = logits.shape[0], net.out_hw, net.quad_w
         probs = torch.empty((B, H, W, self.num_class), dtype=torch.float32, device=self.device)
-        dlogits = ops.new_act(B, H, W, 8, self.device)
+        dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device, zero=True) if qw else ops.new_act(B, H, W, 8, self.device)
         ops.loss_cat_scale(y, self._scale)
         ops.fill_f32(self._loss_map, 0.0)
-        ops.softmax_loss(logits, y, probs, self._loss_map, dlogits, HW=H * W, C_classes=self.num_class, loss_kind=1, scale=self._scale)
+        ops.softmax_loss(logits, y, probs, self._loss_map, dlogits, HW=H * W, C_classes=self.num_class, loss_kind=1, scale=self._scale, quad_w=qw)
         with ops.overlap_region():
             net.backward(dlogits)
         return probs
@@ -510,13 +522,15 @@ class ResNest:
         if train:
             self.flat.zero_grad()
         logits = net.forward(x, return_logits=True)                                            # :40
-        B, H, W, _ = logits.shape
+        B, (H, W), qw = logits.shape[0], net.out_hw, net.quad_w
         probs = torch.empty((B, H, W, self.num_class), dtype=torch.float32, device=self.device)
-        dlogits = ops.new_act(B, H, W, 8, self.device) if train else None
+        dlogits = None
+        if train:
+            dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device, zero=True) if qw else ops.new_act(B, H, W, 8, self.device)
         ops.loss_cat_scale(y, self._scale)                                                     # :240-241
         ops.fill_f32(self._loss_map, 0.0)
         ops.softmax_loss(logits, y, probs, self._loss_map, dlogits, HW=H * W, C_classes=self.num_class, loss_kind=1,
-                         scale=self._scale)                                                    # :125, :234-248
+                         scale=self._scale, quad_w=qw)                                         # :125, :234-248
         if train:
             with ops.overlap_region():          # deferred / batched finishing reductions of the norm backward and bias sums
                 net.backward(dlogits)                                                          # :43 (gradient of the SUM of the map)

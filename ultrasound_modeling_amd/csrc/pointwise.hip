@@ -674,15 +674,17 @@ __global__ void quad_bias_fold_kernel(const float* d16, int C, float* dbias) {
   if (n < C) dbias[n] += d16[n] + d16[4 + n] + d16[8 + n] + d16[12 + n];
 }
 // grad[kh][kw][n][c] += dq[tap(kh,kw)][c][class(kh,kw)*4 + n],  dq = [9][Cin_phys][16] (the 3x3-conv weight gradient of the quad form)
-__global__ __launch_bounds__(256) void tconv_quad_unpack_kernel(const float* dq, int Cin_phys, int Cin, int Cout, float* grad) {
-  const int total = 9 * Cout * Cin;
+__global__ __launch_bounds__(256) void tconv_quad_unpack_kernel(const float* dq, int Cin_phys, int Cin, int Cout, float* grad, int k) {
+  const int total = k * k * Cout * Cin, pad = k == 4 ? 1 : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     int c = i % Cin, r = i / Cin;
     int n = r % Cout, kk = r / Cout;
-    int kh = kk / 3, kw = kk - 3 * kh;
-    int t = (1 - (kh >> 1)) * 3 + (1 - (kw >> 1));          // stencil tap of offset (di,dj) = (-(kh>>1), -(kw>>1))
-    int cls = (kh & 1) * 2 + (kw & 1);
-    grad[i] += dq[((int64_t)t * Cin_phys + c) * 16 + cls * 4 + n];
+    int kh = kk / k, kw = kk - k * kh;
+    // output parity a = (kh+pad)&1 and source offset di = (a+pad-kh)/2 of kernel tap kh (k=3: pad 0; k=4: pad 1)
+    int a = (kh + pad) & 1, b = (kw + pad) & 1;
+    int di = (a + pad - kh) / 2, dj = (b + pad - kw) / 2;
+    int t = (di + 1) * 3 + (dj + 1);
+    grad[i] += dq[((int64_t)t * Cin_phys + c) * 16 + (a * 2 + b) * 4 + n];
   }
 }
 extern "C" int usseg_quad_bias_expand(const float* bias, int32_t C, float* bias16, usseg_stream_t stream) {
@@ -695,9 +697,11 @@ extern "C" int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, u
   hipLaunchKernelGGL(quad_bias_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d16, C, dbias);
   return usseg_check_launch("quad_bias_fold");
 }
-extern "C" int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, float* grad, usseg_stream_t stream) {
-  USSEG_CHECK_ARG(dq && grad && Cin >= 1 && Cin <= Cin_phys && Cout >= 1 && Cout <= 4, "tconv_quad_unpack: bad args");
-  hipLaunchKernelGGL(tconv_quad_unpack_kernel, dim3((9 * Cout * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, dq, Cin_phys, Cin, Cout, grad);
+extern "C" int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t ksize, float* grad,
+                                       usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dq && grad && Cin >= 1 && Cin <= Cin_phys && Cout >= 1 && Cout <= 4 && (ksize == 3 || ksize == 4), "tconv_quad_unpack: bad args");
+  hipLaunchKernelGGL(tconv_quad_unpack_kernel, dim3((ksize * ksize * Cout * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, dq, Cin_phys, Cin,
+                     Cout, grad, ksize);
   return usseg_check_launch("tconv_quad_unpack");
 }
 

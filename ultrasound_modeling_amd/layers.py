@@ -228,6 +228,67 @@ class Conv2DTranspose(Conv2D):
         return ops.tconv2d_dgrad(dy, self.wp_d, self.k, dx, dx_residual, accumulate_dx)
 
 
+class QuadHead:
+    """A <= 4-class stride-2 Conv2DTranspose head (Decoder.py:120, k=3; TBI_ResNest.py:124, k=4) run in "quad" form: a
+    stride-1 conv at the input resolution whose 16 channels are the four output parities (one HBM-bound launch each way
+    instead of a 4-class gather GEMM and a per-tap weight gradient).  Logits / their gradient live in the space-to-depth
+    layout [B,h,w,16] that ``ops.softmax_loss(..., quad_w=W)`` indexes."""
+
+    def __init__(self, head: "Conv2DTranspose"):
+        assert head.cout <= 4 and head.k in (3, 4)
+        self.head = head
+        head.on_finalize = lambda device: None      # packed here instead
+
+    def on_finalize(self, device):
+        cin_p = self.head.cin_p
+        self.wq_f = torch.zeros((16, 9 * cin_p), dtype=BF16, device=device)
+        self.wq_d = torch.zeros((roundup(cin_p, 16), 9 * 16), dtype=BF16, device=device)
+        self.bias16 = torch.zeros(16, dtype=torch.float32, device=device)
+        self.d16 = torch.zeros(16, dtype=torch.float32, device=device)
+        self.dq = torch.zeros(9 * cin_p * 16, dtype=torch.float32, device=device)
+        jobs = self.pack_jobs()
+        ops.pack_weights_batched(ops.make_pack_table(jobs, device), len(jobs))
+
+    def pack_jobs(self):
+        """Quad operands from the Keras kernel [k,k,Cout,Cin]: tap kh feeds output parity a = (kh+pad)&1 from source offset
+        di = (a+pad-kh)/2 (pad = 1 for k=4); rows = parity class*4 + n, stencil tap = (di+1)*3 + (dj+1)."""
+        h, k = self.head, self.head.k
+        pad = 1 if k == 4 else 0
+        jobs = []
+        for kh in range(k):
+            for kw in range(k):
+                src = h.kernel.data[kh, kw]                       # [Cout][Cin] view
+                a, b = (kh + pad) & 1, (kw + pad) & 1
+                t = ((a + pad - kh) // 2 + 1) * 3 + ((b + pad - kw) // 2 + 1)
+                cls = a * 2 + b
+                jobs.append(ops.pack_job(src, 0, h.cin, 1, 1, h.cout, h.cin, self.wq_f, 9 * h.cin_p, h.cin_p, cls * 4, t * h.cin_p))
+                jobs.append(ops.pack_job(src, 0, 1, h.cin, 1, h.cin, h.cout, self.wq_d, 9 * 16, 16, 0, t * 16 + cls * 4))
+        return jobs
+
+    def forward(self, x):
+        B, H, W, _, _ = ops.geom(x)
+        ops.quad_bias_expand(self.head.bias.data, self.head.cout, self.bias16)
+        logits = torch.empty((B, H, W, 16), dtype=torch.float32, device=x.device)
+        self._x = self.head._x = x
+        return ops.conv2d_fwd(x, self.wq_f, self.bias16, 3, 1, logits, out_f32=True)
+
+    def backward(self, dl4, need_dx=True):
+        """dl4: bf16 [B,h,w,16] gradient of the quad-form logits -> dx [B,h,w,cin]."""
+        h, x = self.head, self._x
+        with ops.side_stream(x, dl4):
+            ops.fill_f32(self.dq, 0.0)
+            ops.fill_f32(self.d16, 0.0)
+            ops.conv2d_wgrad(x, dl4, 3, 1, self.dq)
+            ops.colsum(dl4, self.d16, 16)
+            ops.defer_flush()                                      # dq / d16 are read right away
+            ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, h.k, h.kernel.grad)
+            ops.quad_bias_fold(self.d16, h.cout, h.bias.grad)
+        if not need_dx:
+            return None
+        B, H, W, _, _ = ops.geom(x)
+        return ops.conv2d_dgrad(dl4, self.wq_d, 3, 1, ops.new_act(B, H, W, h.cin_p, x.device))
+
+
 # ------------------------------------------------------------------------------------------------ normalisation
 class LayerNormalization(nn.Module):
     """tf.keras.layers.LayerNormalization(axis=-1, epsilon=1e-3): per pixel over channels; optional fused activation."""

@@ -603,8 +603,8 @@ def quad_bias_fold(d16, C_classes, dbias):
     L.check(L.load().usseg_quad_bias_fold(d16.data_ptr(), C_classes, dbias.data_ptr(), _stream()), "quad_bias_fold")
 
 
-def tconv_quad_unpack(dq, Cin_phys, Cin, Cout, grad):
-    L.check(L.load().usseg_tconv_quad_unpack(dq.data_ptr(), Cin_phys, Cin, Cout, grad.data_ptr(), _stream()), "tconv_quad_unpack")
+def tconv_quad_unpack(dq, Cin_phys, Cin, Cout, ksize, grad):
+    L.check(L.load().usseg_tconv_quad_unpack(dq.data_ptr(), Cin_phys, Cin, Cout, ksize, grad.data_ptr(), _stream()), "tconv_quad_unpack")
 
 
 def loss_cat_scale(y_true, scale):
