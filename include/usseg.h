@@ -343,10 +343,23 @@ int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, cons
  * usseg_conv2d_fwd/dgrad/wgrad as a 3x3 conv (each parity uses <= 2x2 of the stencil taps, the rest are zero).  With
  * pad = (k==4): kernel tap kh feeds output parity a = (kh+pad)&1 from source offset di = (a+pad-kh)/2.  These helpers move
  * the bias and the gradients between the Keras variables and that form: bias16[cls*4+n] = bias[n];
- * dbias[n] += sum_cls d16[cls*4+n];  grad[kh][kw][n][c] += dq[(di+1)*3+(dj+1)][c][(a*2+b)*4+n], dq = [9][Cin_phys][16]. */
-int usseg_quad_bias_expand(const float* bias, int32_t C, float* bias16, usseg_stream_t stream);
+ * dbias[n] += sum_cls d16[cls*4+n] (head, Np = 4);  grad[kh][kw][n][c] += dq[(di+1)*3+(dj+1)][c][(a*2+b)*Np+n], dq = [9][Cin_phys][4*Np]. */
+int usseg_quad_bias_expand(const float* bias, int32_t C, int32_t Np, float* out /* [4*Np] */, usseg_stream_t stream);
 int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, usseg_stream_t stream);
-int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t ksize, float* grad, usseg_stream_t stream);
+int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t Np, int32_t ksize, float* grad,
+                            usseg_stream_t stream);
+/* General quad-form transposed conv (any channel count; Np = physical output channels per parity class, the 16 of the head = 4*4):
+ * y4 / dy4 are [B,H,W,4*Np] space-to-depth tensors of the [B,2H,2W,Np] output (usseg_space_to_depth2 converts either way);
+ * the descriptor is that of the 3x3 stride-1 conv (ksize 3, Cout = 4*Np).  Each parity class only uses <= 2x2 of the nine stencil
+ * taps: the conv kernels skip the others per channel class (tap masks), so no multiply is wasted on the structural zeros.
+ * Replaces tf.keras.layers.Conv2DTranspose(k=4, strides 2) of TBI_ResNest.py:124,210 (and k=3 of Decoder.py:120). */
+int usseg_space_to_depth2(const void* full, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ld_full, void* quad, int32_t Np,
+                          int32_t ld_quad, int32_t to_quad, usseg_stream_t stream);
+int usseg_tconv_quad_fwd(const UssegConvDesc* d, int32_t ksize, int32_t Np, const void* x, const void* wq_f, const float* bias_q, void* y4,
+                         usseg_stream_t stream);
+int usseg_tconv_quad_dgrad(const UssegConvDesc* d, int32_t ksize, int32_t Np, const void* dy4, const void* wq_d, void* dx, usseg_stream_t stream);
+int usseg_tconv_quad_wgrad(const UssegConvDesc* d, int32_t ksize, int32_t Np, const void* x, const void* dy4, float* dq, float* ws,
+                           int64_t ws_floats, usseg_stream_t stream);
 
 /* my_loss_cat scale[hw][c] = 1/(sum_b y[b,hw,c] + 1)/(H*W)  (TBI_ResNest.py:240-241) */
 int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, int32_t C, float* scale, usseg_stream_t stream);

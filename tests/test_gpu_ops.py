@@ -510,3 +510,32 @@ def test_head_quad_form_matches_transposed_conv(gen):
     assert abs(l1 - l0) < 2e-3 * abs(l0) and rel(p1, p0) < 5e-3
     # one Adam step from identical weights: the updated head variables (sign-like Adam step) and the whole model must agree
     assert rel(k1, k0) < 2e-2 and rel(b1, b0) < 2e-2 and rel(f1, f0) < 2e-2
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 8, 8, 72, 64, 4), (1, 16, 16, 40, 32, 3), (2, 4, 4, 128, 128, 4), (1, 8, 16, 64, 24, 3)])
+def test_quad_form_transposed_conv(gen, B, H, W, Cin, Cout, k):
+    """Conv2DTranspose(k, strides 2, 'same') as tap-masked 3x3 convs on space-to-depth tensors (layers.QuadTConv,
+    usseg_tconv_quad_fwd/dgrad/wgrad + usseg_space_to_depth2): forward, backward-data and weight gradient against the oracle."""
+    from ultrasound_modeling_amd.layers import Conv2DTranspose, QuadTConv
+    layer = Conv2DTranspose(Cin, Cout, k)
+    w = rnd(gen, k, k, Cout, Cin, scale=1.0 / math.sqrt(k * k * Cin))
+    b = rnd(gen, Cout, scale=0.5)
+    layer.kernel.data.copy_(w); layer.bias.data.copy_(b)
+    q = QuadTConv(layer)
+    holder = torch.nn.ModuleList([layer])
+    finalize(holder)
+    q.on_finalize(torch.device(DEV))
+    x = rnd(gen, B, H, W, Cin)
+    xd = to_dev_padded(x)
+    ref = O.conv2d_transpose_s2_same(x, w, b)
+    y = q.forward(xd)
+    torch.cuda.synchronize()
+    assert rel(y[..., :Cout], bf(ref)) < REL_BF16
+    dy = rnd(gen, B, 2 * H, 2 * W, Cout)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (O.conv2d_transpose_s2_same(xr, wr, b) * dy).sum().backward()
+    dx = q.backward(to_dev_padded(dy))
+    torch.cuda.synchronize()
+    assert rel(dx[..., :Cin], bf(xr.grad)) < 2 * REL_BF16
+    assert rel(layer.kernel.grad, wr.grad) < REL_F32
+    assert rel(layer.bias.grad, dy.sum(dim=(0, 1, 2))) < REL_F32

@@ -16,11 +16,12 @@ import torch.nn as nn
 
 from . import ops
 from .layers import (KERAS_BN_EPS, KERAS_LRELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, LayerNormalization,
-                     LeakyReLU, QuadHead)
+                     LeakyReLU, QuadHead, QuadTConv)
 from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 
 
 _FUSED_DGRAD = os.environ.get("USSEG_FUSED_DGRAD", "1") != "0"
+_QUAD_UP = os.environ.get("USSEG_QUAD_UP", "0") != "0"
 _FOLD_BN = os.environ.get("USSEG_FOLD_BN", "0") != "0"   # built and parity-tested; measured neutral on the step (4.98 vs 4.99 ms), so off by default
 
 
@@ -47,6 +48,7 @@ class DecoderBlock(nn.Module):
         for j in range(4):                                                            # :51-54
             setattr(self, f"bn2_{j}", BatchNormalization(oc // 4))
         self.up = Conv2DTranspose(self.in_channels, oc, 3)                            # :57
+        self._qup = QuadTConv(self.up) if _QUAD_UP else None
 
     # ---- the four parallel branches of a stage share one BatchNormalization launch: their gamma / beta / conv-bias
     # variables are laid out back to back in the flat buffer and their moving statistics share one device buffer
@@ -81,6 +83,8 @@ class DecoderBlock(nn.Module):
         for st in ("1", "2"):
             cin_p = getattr(self, f"conv{st}_0").cin_p
             self._wd_cat[st] = torch.zeros((roundup(cin_p, 16), 28 * q), dtype=BF16, device=device)
+        if self._qup is not None:
+            self._qup.on_finalize(device)
         ops.pack_weights_batched(ops.make_pack_table(self.pack_jobs(), device), len(self.pack_jobs()))
         jobs = self.bn_fold_jobs()
         ops.bn_fold_batched(ops.make_bn_fold_table(jobs, device), len(jobs))
@@ -102,6 +106,8 @@ class DecoderBlock(nn.Module):
                 sT, sI, sO = c._strides_tio()
                 jobs.append(ops.pack_job(c.kernel.data, sT, sI, sO, T, c.cin, c.cout, self._wd_cat[st], 28 * q, q, 0, base))
                 base += T * q
+        if self._qup is not None:
+            jobs += self._qup.pack_jobs()
         return jobs
 
     def _bn_fwd(self, st, raw, out):
@@ -160,7 +166,10 @@ class DecoderBlock(nn.Module):
         c1 = oc + (self.skip_channels if has_skip else 0)
         assert has_skip or self.skip_channels == 0, "block was built for a skip connection"
         cat = ops.new_act(B, 2 * H, 2 * W, c1, dev)
-        self.up.forward(x, out=cat[..., :oc])                                         # :63
+        if self._qup is not None:
+            self._qup.forward(x, out=cat[..., :oc])
+        else:
+            self.up.forward(x, out=cat[..., :oc])                                     # :63
         if has_skip:
             ops.copy_channels(skip, cat[..., oc:])                                    # :66
         self._fold = _FOLD_BN and not any(getattr(self, f"bn{st}_{j}").training_mode for st in ("1", "2") for j in range(4))
@@ -193,7 +202,7 @@ class DecoderBlock(nn.Module):
         c1 = oc + (self.skip_channels if self._has_skip else 0)
         dcat = ops.new_act(B, H2, W2, c1, dev)
         self._branches_bwd("1", draw1, dcat)
-        dx = self.up.backward(dcat[..., :oc])
+        dx = self._qup.backward(dcat[..., :oc]) if self._qup is not None else self.up.backward(dcat[..., :oc])
         dskip = dcat[..., oc:] if self._has_skip else None
         return dx, dskip
 

@@ -23,7 +23,8 @@ import torch.nn as nn
 
 from . import ops
 from .flat import AdamClip, FlatParams
-from .layers import (KERAS_BN_EPS, KERAS_ELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, QuadHead, _Workspace)
+from .layers import (KERAS_BN_EPS, KERAS_ELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, QuadHead, QuadTConv,
+                     _Workspace)
 from .ops import ACT_ELU, ACT_NONE, ACT_RELU, BF16, roundup
 
 
@@ -260,6 +261,12 @@ class _ResModel(nn.Module):
             cin = oc + sk
         add("f_tran", Conv2DTranspose(cin, num_class, 4, **G))                       # :124
         self._quad = QuadHead(self.f_tran) if (num_class <= 4 and os.environ.get("USSEG_QUAD_HEAD", "1") != "0") else None
+        # the five 4x4 stride-2 up-convolutions (:210) as tap-masked convs on space-to-depth tensors
+        self._qt = {}
+        if os.environ.get("USSEG_QUAD_TCONV", "0") != "0":      # built and parity-tested; with 768-1024 input channels both paths are MFMA-heavy and the quad form measured 5 % slower (11.6 vs 11.0 ms), so off by default
+            for name, oc, drop in self.UPS:
+                object.__setattr__(self, "_qt_" + name, QuadTConv(getattr(self, name + "_t_conv")))
+                self._qt[name] = getattr(self, "_qt_" + name)
         self._stages = None
         self.dropout_seed = 0
         self.injected_masks = None      # tests inject {0,1} keep masks to make the always-on dropout deterministic
@@ -283,6 +290,8 @@ class _ResModel(nn.Module):
                 sl.on_finalize(device)
         if self._quad is not None:
             self._quad.on_finalize(device)
+        for q in self._qt.values():
+            q.on_finalize(device)
 
     def pack_jobs(self):
         jobs = [j for st in self._build() for sl in st.slabs for j in sl.pack_jobs()]
@@ -291,6 +300,8 @@ class _ResModel(nn.Module):
                 jobs += m.pack_jobs()
         if self._quad is not None:
             jobs += self._quad.pack_jobs()
+        for q in self._qt.values():
+            jobs += q.pack_jobs()
         return jobs
 
     def repack(self):
@@ -330,7 +341,7 @@ class _ResModel(nn.Module):
         for i, (name, oc, drop) in enumerate(self.UPS):                                # :109-122
             skip = pooled[4 - i]
             B, H, W, _, _ = ops.geom(u)
-            raw = g(name + "_t_conv").forward(u)                                       # :210
+            raw = self._qt[name].forward(u) if name in self._qt else g(name + "_t_conv").forward(u)   # :210
             cat = ops.new_act(B, 2 * H, 2 * W, oc + skip.shape[3], u.device)
             mask = self._mask(i, raw) if drop else None
             bn = g(name + "_bn")
@@ -365,7 +376,7 @@ class _ResModel(nn.Module):
             draw = ops.norm_act_bwd(raw, d[..., :oc], oc, bn.gamma.data, bn.beta.data, torch.empty_like(raw), bn.gamma.grad, bn.beta.grad,
                                     1, 1, KERAS_BN_EPS, ACT_RELU, 0.0, bn.moving_mean_p, bn.moving_variance_p,
                                     dbias=g(name + "_t_conv").bias.grad, mask=self._masks[i])
-            d = self._tconv_backward(g(name + "_t_conv"), draw)
+            d = self._qt[name].backward(draw, bias_grad=False) if name in self._qt else self._tconv_backward(g(name + "_t_conv"), draw)
         # d = gradient w.r.t. pool6 (the input of upsample_0); pool5..pool1 also feed the decoder concats (dpool)
         stages = self._build()
         for i in reversed(range(5)):

@@ -84,6 +84,14 @@ static inline int wg_map_fill(WgMap& m, const UssegWgradDst* d) {
 // *_affine / multi entry points for the duration of one call, read by the launchers (slot = job index)
 extern thread_local const float* usseg_epi_scale[4];
 
+// per-channel-class tap masks of the quad-form transposed conv (set by the usseg_tconv_quad_* entry points for one call):
+// output channels (fwd, wgrad) or input channels (dgrad) [cls*group_ch, (cls+1)*group_ch) only use the stencil taps in mask[cls]
+struct UssegTapMask {
+  int32_t group_ch;      // 0 = no masking
+  uint16_t mask[4];
+};
+extern thread_local UssegTapMask usseg_tap_mask;
+
 void usseg_set_error(const char* fmt, ...);
 #define USSEG_CHECK_ARG(cond, ...)                 \
   do {                                             \

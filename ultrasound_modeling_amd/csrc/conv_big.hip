@@ -28,6 +28,8 @@ struct BigJob {
   int32_t out_f32, accumulate, flip;
   int32_t gx, gy, npa, nstages;   // this job's grid extent; A pieces (16 halo pixels each) per stage; LDS stages (1 or 2)
   uint32_t x_bytes, w_bytes;   // buffer extents for the range-checked DMA
+  int32_t mask_ch;             // quad-form transposed conv: channels per parity class (0 = every tap for every channel)
+  uint16_t tapmask[4];         // stencil taps class c uses (fwd: class of the output-channel tile; dgrad: class of the K chunk)
 };
 struct BigParams {
   BigJob job[4];
@@ -155,8 +157,10 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
     if (dbuf && ck + 1 < p.nchunks) issue(ck + 1, (ck + 1) & 1);
     const char* abuf = lds + (dbuf ? (ck & 1) * stage_bytes : 0);
     const char* wbuf = abuf + a_bytes + w_lane;
+    const uint32_t tmask = p.mask_ch ? p.tapmask[(p.flip ? ck * 32 : n0) / p.mask_ch] : 0x1ffu;   // wave-uniform
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+      if (!((tmask >> t) & 1u)) continue;     // this class's weights are identically zero at tap t
       const int toff = (t / 3) * HW2 + (t % 3);
       bf16x8_t xf[NS], wf[NT];
 #pragma unroll
@@ -344,6 +348,13 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
                       g[j].ldy, g[j].ldr, g[j].Nw, g[j].Kw, g[j].act, g[j].alpha, g[j].out_f32, g[j].accumulate, g[j].flip, best_px))
       return 0;
   for (int j = 0; j < njobs; ++j) P.job[j].scale = g[j].flip ? nullptr : usseg_epi_scale[j];
+  if (usseg_tap_mask.group_ch) {
+    // the tile (fwd: 16*nt output channels; dgrad: one 32-channel K chunk) must lie inside one class
+    const int unit = g[0].flip ? 32 : 16 * best_nt;
+    if (njobs != 1 || usseg_tap_mask.group_ch % unit) return 0;
+    P.job[0].mask_ch = usseg_tap_mask.group_ch;
+    for (int c = 0; c < 4; ++c) P.job[0].tapmask[c] = usseg_tap_mask.mask[c];
+  }
   big_launch(P, njobs, best_nt, best_px, s);
   return 1;
 }

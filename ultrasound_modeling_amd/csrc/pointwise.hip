@@ -665,16 +665,15 @@ extern "C" int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t 
 // out[2i+a, 2j+b, n] = sum over (di,dj) in {0,-1}^2 of x[i+di, j+dj, :] . W[a-2di][b-2dj][n][:]   (terms with a tap index > 2 vanish)
 // The conv kernels run it as an ordinary 3x3 conv with Cout = 16 = (parity class)*4 + n; these three helpers move the
 // bias and the gradients between the Keras variables (kernel [3,3,Cout,Cin], bias [Cout]) and that form.
-__global__ void quad_bias_expand_kernel(const float* bias, int C, float* bias16) {
-  int i = threadIdx.x;
-  if (i < 16) bias16[i] = (i & 3) < C ? bias[i & 3] : 0.f;
+__global__ void quad_bias_expand_kernel(const float* bias, int C, int Np, float* out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 4 * Np; i += gridDim.x * blockDim.x) out[i] = (i % Np) < C ? bias[i % Np] : 0.f;
 }
 __global__ void quad_bias_fold_kernel(const float* d16, int C, float* dbias) {
   int n = threadIdx.x;
   if (n < C) dbias[n] += d16[n] + d16[4 + n] + d16[8 + n] + d16[12 + n];
 }
 // grad[kh][kw][n][c] += dq[tap(kh,kw)][c][class(kh,kw)*4 + n],  dq = [9][Cin_phys][16] (the 3x3-conv weight gradient of the quad form)
-__global__ __launch_bounds__(256) void tconv_quad_unpack_kernel(const float* dq, int Cin_phys, int Cin, int Cout, float* grad, int k) {
+__global__ __launch_bounds__(256) void tconv_quad_unpack_kernel(const float* dq, int Cin_phys, int Cin, int Cout, float* grad, int k, int Np) {
   const int total = k * k * Cout * Cin, pad = k == 4 ? 1 : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     int c = i % Cin, r = i / Cin;
@@ -684,12 +683,12 @@ __global__ __launch_bounds__(256) void tconv_quad_unpack_kernel(const float* dq,
     int a = (kh + pad) & 1, b = (kw + pad) & 1;
     int di = (a + pad - kh) / 2, dj = (b + pad - kw) / 2;
     int t = (di + 1) * 3 + (dj + 1);
-    grad[i] += dq[((int64_t)t * Cin_phys + c) * 16 + (a * 2 + b) * 4 + n];
+    grad[i] += dq[((int64_t)t * Cin_phys + c) * (4 * Np) + (a * 2 + b) * Np + n];
   }
 }
-extern "C" int usseg_quad_bias_expand(const float* bias, int32_t C, float* bias16, usseg_stream_t stream) {
-  USSEG_CHECK_ARG(bias && bias16 && C >= 1 && C <= 4, "quad_bias_expand: bad args");
-  hipLaunchKernelGGL(quad_bias_expand_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bias, C, bias16);
+extern "C" int usseg_quad_bias_expand(const float* bias, int32_t C, int32_t Np, float* out, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(bias && out && C >= 1 && Np >= C && Np % 4 == 0, "quad_bias_expand: bad args");
+  hipLaunchKernelGGL(quad_bias_expand_kernel, dim3((4 * Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, bias, C, Np, out);
   return usseg_check_launch("quad_bias_expand");
 }
 extern "C" int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, usseg_stream_t stream) {
@@ -697,11 +696,12 @@ extern "C" int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, u
   hipLaunchKernelGGL(quad_bias_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d16, C, dbias);
   return usseg_check_launch("quad_bias_fold");
 }
-extern "C" int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t ksize, float* grad,
+extern "C" int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t Np, int32_t ksize, float* grad,
                                        usseg_stream_t stream) {
-  USSEG_CHECK_ARG(dq && grad && Cin >= 1 && Cin <= Cin_phys && Cout >= 1 && Cout <= 4 && (ksize == 3 || ksize == 4), "tconv_quad_unpack: bad args");
-  hipLaunchKernelGGL(tconv_quad_unpack_kernel, dim3((ksize * ksize * Cout * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, dq, Cin_phys, Cin,
-                     Cout, grad, ksize);
+  USSEG_CHECK_ARG(dq && grad && Cin >= 1 && Cin <= Cin_phys && Cout >= 1 && Cout <= Np && (ksize == 3 || ksize == 4), "tconv_quad_unpack: bad args");
+  int g = (ksize * ksize * Cout * Cin + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(tconv_quad_unpack_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dq, Cin_phys, Cin, Cout, grad, ksize, Np);
   return usseg_check_launch("tconv_quad_unpack");
 }
 
@@ -722,6 +722,80 @@ extern "C" int usseg_bn_fold_batched(const UssegBnFoldJob* jobs_dev, int32_t njo
   USSEG_CHECK_ARG(jobs_dev && njobs > 0 && njobs < 65536, "bn_fold_batched: bad args");
   hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return usseg_check_launch("bn_fold_batched");
+}
+
+// space-to-depth / depth-to-space (2x2): full[b, 2i+a, 2j+b', n] <-> quad[b, i, j, (2a+b')*Np + n], 16 bytes per thread
+template <bool TO_QUAD>
+__global__ __launch_bounds__(256) void s2d_kernel(const bf16_t* src, int B, int H, int W, int CH, int ld_full, int Np, bf16_t* dst, int ld_quad) {
+  const int64_t total = (int64_t)B * 4 * H * W * CH;           // (b, y, x of the full-resolution map, 8-channel chunk)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)(i % CH) * 8;
+    int64_t r = i / CH;
+    const int x = (int)(r % (2 * W)); r /= 2 * W;
+    const int y = (int)(r % (2 * H));
+    const int b = (int)(r / (2 * H));
+    const int64_t full = (((int64_t)b * 2 * H + y) * 2 * W + x) * ld_full + c0;
+    const int64_t quad = (((int64_t)b * H + (y >> 1)) * W + (x >> 1)) * ld_quad + ((y & 1) * 2 + (x & 1)) * Np + c0;
+    if (TO_QUAD) *reinterpret_cast<uint4*>(dst + quad) = *reinterpret_cast<const uint4*>(src + full);
+    else *reinterpret_cast<uint4*>(dst + full) = *reinterpret_cast<const uint4*>(src + quad);
+  }
+}
+extern "C" int usseg_space_to_depth2(const void* full, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ld_full, void* quad, int32_t Np,
+                                     int32_t ld_quad, int32_t to_quad, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(full && quad && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && Np >= C && Np % 8 == 0 && ld_full % 8 == 0 && ld_full >= C &&
+                      ld_quad % 8 == 0 && ld_quad >= 4 * Np, "space_to_depth2: bad args");
+  const int64_t total = (int64_t)B * 4 * H * W * (C / 8);
+  dim3 grid(grid_for(total, 256 * 4, 4096));
+  if (to_quad)
+    hipLaunchKernelGGL(s2d_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)full, B, H, W, C / 8, ld_full, Np, (bf16_t*)quad, ld_quad);
+  else
+    hipLaunchKernelGGL(s2d_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)quad, B, H, W, C / 8, ld_full, Np, (bf16_t*)full, ld_quad);
+  return usseg_check_launch("space_to_depth2");
+}
+
+// Quad-form transposed conv (stride 2, 'same', k = 3 or 4) as tap-masked 3x3 convs on space-to-depth tensors: sets the per-class
+// stencil masks for one call of the conv entry point (kernels that do not honour the mask still compute the right result: the
+// masked taps carry zero weights / unused gradient entries).
+static void quad_masks(int k, bool reversed) {
+  const int pad = k == 4 ? 1 : 0;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      unsigned m = 0;
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw)
+          if (((kh + pad) & 1) == a && ((kw + pad) & 1) == b) {
+            int t = ((a + pad - kh) / 2 + 1) * 3 + ((b + pad - kw) / 2 + 1);
+            m |= 1u << (reversed ? 8 - t : t);
+          }
+      usseg_tap_mask.mask[a * 2 + b] = (uint16_t)m;
+    }
+}
+struct TapMaskGuard {
+  ~TapMaskGuard() { usseg_tap_mask.group_ch = 0; }
+};
+extern "C" int usseg_tconv_quad_fwd(const UssegConvDesc* d, int32_t ksize, int32_t Np, const void* x, const void* wq_f, const float* bias_q,
+                                    void* y4, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && (ksize == 3 || ksize == 4) && Np > 0 && d->Cout == 4 * Np && d->ksize == 3 && d->dilation == 1, "tconv_quad_fwd: bad args");
+  TapMaskGuard guard;
+  quad_masks(ksize, false);
+  usseg_tap_mask.group_ch = Np;
+  return usseg_conv2d_fwd(d, x, wq_f, bias_q, nullptr, 0, y4, stream);
+}
+extern "C" int usseg_tconv_quad_dgrad(const UssegConvDesc* d, int32_t ksize, int32_t Np, const void* dy4, const void* wq_d, void* dx,
+                                      usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && (ksize == 3 || ksize == 4) && Np > 0 && d->Cout == 4 * Np && d->ksize == 3 && d->dilation == 1, "tconv_quad_dgrad: bad args");
+  TapMaskGuard guard;
+  quad_masks(ksize, true);      // the backward-data loop uses weight tap 8 - t at loop tap t
+  usseg_tap_mask.group_ch = Np;
+  return usseg_conv2d_dgrad(d, dy4, wq_d, nullptr, 0, dx, stream);
+}
+extern "C" int usseg_tconv_quad_wgrad(const UssegConvDesc* d, int32_t ksize, int32_t Np, const void* x, const void* dy4, float* dq, float* ws,
+                                      int64_t ws_floats, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && (ksize == 3 || ksize == 4) && Np > 0 && d->Cout == 4 * Np && d->ksize == 3 && d->dilation == 1, "tconv_quad_wgrad: bad args");
+  TapMaskGuard guard;
+  quad_masks(ksize, false);
+  usseg_tap_mask.group_ch = Np;
+  return usseg_conv2d_wgrad(d, x, dy4, dq, ws, ws_floats, stream);
 }
 
 // ---- dropout mask (tf.nn.dropout(x, rate), TBI_ResNest.py:216): mask[m][c] = keep ? 1/(1-rate) : 0, counter-based hash RNG

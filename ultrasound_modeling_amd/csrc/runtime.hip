@@ -4,6 +4,7 @@
 
 static thread_local char g_err[512] = "";
 thread_local const float* usseg_epi_scale[4] = {nullptr, nullptr, nullptr, nullptr};
+thread_local UssegTapMask usseg_tap_mask = {0, {0x1ff, 0x1ff, 0x1ff, 0x1ff}};
 
 void usseg_set_error(const char* fmt, ...) {
   va_list ap;

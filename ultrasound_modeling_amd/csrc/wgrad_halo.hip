@@ -18,6 +18,8 @@ struct WgHaloParams {
   int32_t B, H, W, d, Hl, Wl, PH, PW, NV;
   int32_t tiles_x, tiles_per_v, npatches, ngroups, groups_per_block;
   int32_t ldx, lddy, Ma, Nb, ntiles_n;
+  int32_t mask_ch;        // quad-form transposed conv: output channels per parity class (0 = all taps)
+  uint16_t tapmask[4];
 };
 
 // WVM = waves along the input-channel axis (2 or 4; the other 4/WVM waves split the output channels),
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     }
     return v;
   };
+  const uint32_t tmask = p.mask_ch ? p.tapmask[n0 / p.mask_ch] : 0x1ffu;   // workgroup-uniform
   auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       for (int tt = 0; tt < TPG; ++tt) {
         const int t = t0 + tt;
         if (NTG > 1 && t >= 9) break;        // the second tap group has four taps
+        if (!((tmask >> t) & 1u)) continue;  // masked taps keep a zero accumulator (their slab entries are written as zeros)
         const int toff = ((t / 3) * HW2 + (t % 3)) * XS;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
@@ -322,6 +326,11 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     P.job[j].ntiles_n = ntn;
     P.job[j].groups_per_block = gpb;
     P.job[j].ws = use_ws ? ws + (int64_t)j * splits * slab : nullptr;
+  }
+  if (usseg_tap_mask.group_ch) {
+    if (njobs != 1 || usseg_tap_mask.group_ch % bn) return 0;      // an output-channel tile must lie inside one class
+    P.job[0].mask_ch = usseg_tap_mask.group_ch;
+    for (int c = 0; c < 4; ++c) P.job[0].tapmask[c] = usseg_tap_mask.mask[c];
   }
   const dim3 grid(splits, tiles, njobs);
   const int slot = usseg_prof_start(2, s);

@@ -281,12 +281,76 @@ class QuadHead:
             ops.conv2d_wgrad(x, dl4, 3, 1, self.dq)
             ops.colsum(dl4, self.d16, 16)
             ops.defer_flush()                                      # dq / d16 are read right away
-            ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, h.k, h.kernel.grad)
+            ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, 4, h.k, h.kernel.grad)
             ops.quad_bias_fold(self.d16, h.cout, h.bias.grad)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)
         return ops.conv2d_dgrad(dl4, self.wq_d, 3, 1, ops.new_act(B, H, W, h.cin_p, x.device))
+
+
+class QuadTConv:
+    """Any stride-2 'same' Conv2DTranspose (k = 3 or 4) as tap-masked 3x3 stride-1 convs on space-to-depth tensors: the four
+    output parities become 4*Np channels at the INPUT resolution, each parity class uses only its <= 2x2 stencil taps (the
+    conv kernels skip the rest), so the work is exactly that of the transposed conv while forward / backward-data run on the
+    LDS-DMA conv kernel and the weight gradient on the halo-tile kernel (instead of the 4-class gather GEMM and the per-tap
+    weight gradient that re-reads both operands once per tap: 16x for k=4)."""
+
+    def __init__(self, layer: "Conv2DTranspose"):
+        assert layer.k in (3, 4)
+        self.layer, self.Np = layer, layer.cout_p
+        layer.on_finalize = lambda device: None      # packed here instead
+
+    def on_finalize(self, device):
+        h, Np = self.layer, self.Np
+        self.wq_f = torch.zeros((roundup(4 * Np, 16), 9 * h.cin_p), dtype=BF16, device=device)
+        self.wq_d = torch.zeros((roundup(h.cin_p, 16), 9 * 4 * Np), dtype=BF16, device=device)
+        self.bias_q = torch.zeros(4 * Np, dtype=torch.float32, device=device)
+        self.dq = torch.zeros(9 * h.cin_p * 4 * Np, dtype=torch.float32, device=device)
+        jobs = self.pack_jobs()
+        ops.pack_weights_batched(ops.make_pack_table(jobs, device), len(jobs))
+
+    def pack_jobs(self):
+        h, k, Np = self.layer, self.layer.k, self.Np
+        pad = 1 if k == 4 else 0
+        jobs = []
+        for kh in range(k):
+            for kw in range(k):
+                src = h.kernel.data[kh, kw]                       # [Cout][Cin] view
+                a, b = (kh + pad) & 1, (kw + pad) & 1
+                t = ((a + pad - kh) // 2 + 1) * 3 + ((b + pad - kw) // 2 + 1)
+                cls = a * 2 + b
+                jobs.append(ops.pack_job(src, 0, h.cin, 1, 1, h.cout, h.cin, self.wq_f, 9 * h.cin_p, h.cin_p, cls * Np, t * h.cin_p))
+                jobs.append(ops.pack_job(src, 0, 1, h.cin, 1, h.cin, h.cout, self.wq_d, 9 * 4 * Np, 4 * Np, 0, t * 4 * Np + cls * Np))
+        return jobs
+
+    def forward(self, x, out=None):
+        """x [B,H,W,cin] -> raw tconv output [B,2H,2W,cout_p] (bias added), optionally written into the slice ``out``."""
+        B, H, W, _, _ = ops.geom(x)
+        h = self.layer
+        ops.quad_bias_expand(h.bias.data, h.cout, self.bias_q)
+        y4 = ops.tconv_quad_fwd(x, self.wq_f, self.bias_q, h.k, self.Np, ops.new_act(B, H, W, 4 * self.Np, x.device))
+        out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, h.cout_p, x.device)
+        ops.space_to_depth2(out, y4, self.Np, to_quad=False)
+        self._x = h._x = x
+        return out
+
+    def backward(self, dy, need_dx=True, bias_grad=True):
+        """dy [B,2H,2W,cout_p] (slice views allowed) -> dx; accumulates kernel (and bias) gradients."""
+        h, x = self.layer, self._x
+        B, H, W, _, _ = ops.geom(x)
+        dy4 = ops.new_act(B, H, W, 4 * self.Np, x.device)
+        ops.space_to_depth2(dy, dy4, self.Np, to_quad=True)
+        with ops.side_stream(x, dy4, dy):
+            ops.fill_f32(self.dq, 0.0)
+            ops.tconv_quad_wgrad(x, dy4, h.k, self.Np, self.dq)
+            ops.defer_flush()                                      # dq is read right away
+            ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, self.Np, h.k, h.kernel.grad)
+            if bias_grad:
+                ops.colsum(dy, h.bias.grad, h.cout)
+        if not need_dx:
+            return None
+        return ops.tconv_quad_dgrad(dy4, self.wq_d, h.k, self.Np, ops.new_act(B, H, W, h.cin_p, x.device))
 
 
 # ------------------------------------------------------------------------------------------------ normalisation

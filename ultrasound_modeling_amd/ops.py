@@ -595,16 +595,48 @@ def softmax_loss(logits, y_true, probs, loss, dlogits, *, HW, C_classes, loss_ki
                                                 _ptr(dlogits), _stream()), "softmax_loss")
 
 
-def quad_bias_expand(bias, C_classes, bias16):
-    L.check(L.load().usseg_quad_bias_expand(bias.data_ptr(), C_classes, bias16.data_ptr(), _stream()), "quad_bias_expand")
+def quad_bias_expand(bias, C_logical, out):
+    L.check(L.load().usseg_quad_bias_expand(bias.data_ptr(), C_logical, out.numel() // 4, out.data_ptr(), _stream()), "quad_bias_expand")
+
+
+def space_to_depth2(full, quad, Np, to_quad=True):
+    """full [B,2H,2W,C] (channel-slice views allowed) <-> quad [B,H,W,4*Np]: quad[b,i,j,(2a+b')*Np+n] = full[b,2i+a,2j+b',n]."""
+    B, H2, W2, Cc, ldf = geom(full)
+    _, H, W, _, ldq = geom(quad)
+    assert (H2, W2) == (2 * H, 2 * W)
+    L.check(L.load().usseg_space_to_depth2(full.data_ptr(), B, H, W, Cc, ldf, quad.data_ptr(), Np, ldq, 1 if to_quad else 0, _stream()),
+            "space_to_depth2")
+
+
+def tconv_quad_fwd(x, wq_f, bias_q, ksize, Np, y4):
+    B, H, W, Cin, ldx = geom(x)
+    d = _conv_desc(B, H, W, Cin, 4 * Np, ldx, geom(y4)[4], 3, 1)
+    L.check(L.load().usseg_tconv_quad_fwd(C.byref(d), ksize, Np, x.data_ptr(), wq_f.data_ptr(), _ptr(bias_q), y4.data_ptr(), _stream()), "tconv_quad_fwd")
+    return y4
+
+
+def tconv_quad_dgrad(dy4, wq_d, ksize, Np, dx):
+    B, H, W, _, ldy = geom(dy4)
+    _, _, _, Cin, ldx = geom(dx)
+    d = _conv_desc(B, H, W, Cin, 4 * Np, ldx, ldy, 3, 1)
+    L.check(L.load().usseg_tconv_quad_dgrad(C.byref(d), ksize, Np, dy4.data_ptr(), wq_d.data_ptr(), dx.data_ptr(), _stream()), "tconv_quad_dgrad")
+    return dx
+
+
+def tconv_quad_wgrad(x, dy4, ksize, Np, dq):
+    B, H, W, Cin, ldx = geom(x)
+    d = _conv_desc(B, H, W, Cin, 4 * Np, ldx, geom(dy4)[4], 3, 1)
+    ws = wgrad_ws(x.device)
+    L.check(L.load().usseg_tconv_quad_wgrad(C.byref(d), ksize, Np, x.data_ptr(), dy4.data_ptr(), dq.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _stream()), "tconv_quad_wgrad")
 
 
 def quad_bias_fold(d16, C_classes, dbias):
     L.check(L.load().usseg_quad_bias_fold(d16.data_ptr(), C_classes, dbias.data_ptr(), _stream()), "quad_bias_fold")
 
 
-def tconv_quad_unpack(dq, Cin_phys, Cin, Cout, ksize, grad):
-    L.check(L.load().usseg_tconv_quad_unpack(dq.data_ptr(), Cin_phys, Cin, Cout, ksize, grad.data_ptr(), _stream()), "tconv_quad_unpack")
+def tconv_quad_unpack(dq, Cin_phys, Cin, Cout, Np, ksize, grad):
+    L.check(L.load().usseg_tconv_quad_unpack(dq.data_ptr(), Cin_phys, Cin, Cout, Np, ksize, grad.data_ptr(), _stream()), "tconv_quad_unpack")
 
 
 def loss_cat_scale(y_true, scale):
