@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
 static int big_fill_job(BigJob& p, const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W,
                         int d, int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
                         int accumulate, int flip, int PX) {
-  if (d < 1 || H % d || W % d || Cin <= 32) return 0;
+  static const int min_cin = getenv("USSEG_BIG_MIN_CIN") ? atoi(getenv("USSEG_BIG_MIN_CIN")) : 33;
+  if (d < 1 || H % d || W % d || Cin < min_cin) return 0;
   const int Hl = H / d, Wl = W / d;
   int PW;
   if (Wl % 16 == 0) PW = 16;
