@@ -300,6 +300,7 @@ typedef struct UssegSplitAttnParams {
 typedef struct UssegSplitAttnGrads {
   float *w1, *b1, *gamma, *beta, *w2, *b2;
 } UssegSplitAttnGrads;
+/* g[b][c] = sum_hw y[b,hw,c] (g is OVERWRITTEN: no pre-zeroing needed) */
 int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, float* g, float* ws, usseg_stream_t stream);
 /* ws: fp32 workspace of usseg_splitattn_ws_floats(d) floats holding the saved MLP intermediates */
 int64_t usseg_splitattn_ws_floats(const UssegSplitAttnDesc* d);
@@ -307,7 +308,7 @@ int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float* g, const U
                             float* ws, usseg_stream_t stream);
 int usseg_splitattn_apply_fwd(const UssegSplitAttnDesc* d, const void* y, const float* s, void* out,
                               usseg_stream_t stream);
-/* backward: (1) ds[b][p][r][c] = sum_hw mult*y*dout (zeroed by caller) (2) MLP backward -> dg, param grads
+/* backward: (1) ds[b][p][r][c] = sum_hw mult*y*dout (ds is OVERWRITTEN) (2) MLP backward -> dg, param grads
  * (3) dy = mult*s*dout + dg*mult/HW */
 int usseg_splitattn_apply_bwd_reduce(const UssegSplitAttnDesc* d, const void* y, const void* dout, int32_t lddo,
                                      float* ds, float* ws, usseg_stream_t stream);

@@ -99,7 +99,7 @@ extern "C" int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, f
   if (gx > gmax) gx = gmax;
   hipLaunchKernelGGL(sa_reduce_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)nullptr, d->HW, Cy,
                      d->ldy, 0, d->R, d->Cg, LPP, ws);
-  usseg_launch_reduce_finish(ws, d->B, gx, 1, roundup(Cy, 8), Cy, 1.0f, g, nullptr, nullptr, (hipStream_t)stream);
+  usseg_launch_reduce_finish(ws, d->B, gx, 1, roundup(Cy, 8), Cy, 1.0f, g, nullptr, nullptr, (hipStream_t)stream, 1);   // g is OVERWRITTEN
   return usseg_check_launch("splitattn_gap");
 }
 
@@ -118,7 +118,7 @@ extern "C" int usseg_splitattn_apply_bwd_reduce(const UssegSplitAttnDesc* d, con
   if (gx > gmax) gx = gmax;
   hipLaunchKernelGGL(sa_reduce_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)dout, d->HW, Cy,
                      d->ldy, lddo, d->R, d->Cg, LPP, ws);
-  usseg_launch_reduce_finish(ws, d->B, gx, 1, roundup(Cy, 8), Cy, d->mult, ds, nullptr, nullptr, (hipStream_t)stream);
+  usseg_launch_reduce_finish(ws, d->B, gx, 1, roundup(Cy, 8), Cy, d->mult, ds, nullptr, nullptr, (hipStream_t)stream, 1);   // ds is OVERWRITTEN
   return usseg_check_launch("splitattn_apply_bwd_reduce");
 }
 

@@ -108,7 +108,7 @@ void usseg_prof_stop(int kind, int slot, hipStream_t s);
 #define USSEG_REDUCE_MAX_BLOCKS 1024
 // adds the per-workgroup partial rows written by a reduction kernel to up to three destinations (defer.hip)
 void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0, float* d1, float* d2,
-                                hipStream_t s);
+                                hipStream_t s, int overwrite = 0);
 
 // 3x3 conv with an LDS halo tile (conv_halo.hip): returns 1 if it took the launch, 0 if the geometry does not fit
 int usseg_try_launch_conv_halo(const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W, int d,

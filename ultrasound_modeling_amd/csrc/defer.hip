@@ -16,7 +16,7 @@ struct RJob {
   float *d0, *d1, *d2;
   int32_t groups, nb, K, Cp, C, nblocks;
   float scale;
-  int32_t pad;
+  int32_t overwrite;   // 1: dst = scale*sum (no pre-zeroed destination needed), 0: dst += scale*sum
 };
 struct RBatch {
   int32_t njobs, pad;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void reduce_finish_body(const RJob& q, int bx, int nb
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += s_part[r][o];
       float* dst = k == 0 ? q.d0 : (k == 1 ? q.d1 : q.d2);
-      if (dst) dst[g * q.C + c] += q.scale * t;
+      if (dst) dst[g * q.C + c] = q.overwrite ? q.scale * t : dst[g * q.C + c] + q.scale * t;
     }
     __syncthreads();
   }
@@ -199,9 +199,9 @@ float* usseg_defer_reduce_ws(hipStream_t s, float* caller_ws, int64_t need) {
 }
 
 void usseg_launch_reduce_finish(const float* ws, int groups, int nb, int K, int Cp, int C, float scale, float* d0, float* d1, float* d2,
-                                hipStream_t s) {
+                                hipStream_t s, int overwrite) {
   RJob q = {};
-  q.ws = ws; q.d0 = d0; q.d1 = d1; q.d2 = d2; q.groups = groups; q.nb = nb; q.K = K; q.Cp = Cp; q.C = C; q.scale = scale;
+  q.ws = ws; q.d0 = d0; q.d1 = d1; q.d2 = d2; q.groups = groups; q.nb = nb; q.K = K; q.Cp = Cp; q.C = C; q.scale = scale; q.overwrite = overwrite;
   int total = groups * K * C;
   int grid = (total + 15) / 16;
   if (grid > 1024) grid = 1024;

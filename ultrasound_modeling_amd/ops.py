@@ -553,7 +553,7 @@ def splitattn_fwd(d: SplitAttnDesc, y, params, out):
     """params = (w1,b1,gamma,beta,mean,var,w2,b2) fp32 tensors laid out per path.  Returns (out, g, s, ws)."""
     dev = y.device
     Cy = d.P * d.R * d.Cg
-    g = torch.zeros((d.B, Cy), dtype=torch.float32, device=dev)
+    g = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)      # overwritten by usseg_splitattn_gap
     s = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
     ws = torch.empty(d.B * d.P * (d.Cg + 2 * d.Hd), dtype=torch.float32, device=dev)
     lib = L.load()
@@ -568,7 +568,7 @@ def splitattn_bwd(d: SplitAttnDesc, y, dout, params, grads, g, s, ws, dy):
     """grads = (dw1,db1,dgamma,dbeta,dw2,db2) accumulated with atomics.  Writes dy (stride of dy tensor)."""
     dev = y.device
     Cy = d.P * d.R * d.Cg
-    ds = torch.zeros((d.B, Cy), dtype=torch.float32, device=dev)
+    ds = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)     # overwritten by usseg_splitattn_apply_bwd_reduce
     dg = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
     lib = L.load()
     lddo = geom(dout)[4]
