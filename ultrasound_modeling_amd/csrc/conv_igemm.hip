@@ -45,12 +45,17 @@ struct IgemmParams {
   int64_t xs1, xs2, ws1, ws2, ys1, ys2;
 };
 
-template <int NT>
+// KC = 16-byte K chunks per step: 4 (K step 32, one MFMA k-step per barrier) or 8 (K step 64: half the barriers and twice
+// the bytes in flight per thread; used when the K loop is long).
+template <int NT, int KC>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-  constexpr int BM = 128, BN = 16 * NT, LDSS = 40;  // LDS row stride in elements (64 B data + 16 B pad)
-  constexpr int WCH = (BN * 4 + 255) / 256;         // weight chunks per thread per K step
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2][(BM + BN) * LDSS];
-  __shared__ int s_tap[128];
+  constexpr int BM = 128, BN = 16 * NT, LDSS = KC * 8 + 8;  // LDS row stride in elements (data + 16 B pad)
+  constexpr int WCH = (BN * KC + 255) / 256;         // weight chunks per thread per K step
+  constexpr int AH = BM * KC / 256, RSTEP = 256 / KC; // A rows per thread and their spacing
+  constexpr int BUF = (BM + BN) * LDSS;
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];   // [2][BUF] operand stages, then the tap table
+  bf16_t* const lds0 = lds_dyn;
+  int* const s_tap = reinterpret_cast<int*>(lds_dyn + 2 * BUF);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -73,14 +78,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const bf16_t* const wbase = p.w + bz1 * p.ws1 + bz2 * p.ws2;
   const int64_t ybatch = bz1 * p.ys1 + bz2 * p.ys2;
 
-  // --- per-thread staging coordinates: chunk column q (0..3) of rows r0 and r0+64
-  const int q = tid & 3;
-  const int r0 = tid >> 2;
-  int py[2], px[2], pb[2];
-  bool pv[2];
+  // --- per-thread staging coordinates: chunk column q (0..KC-1) of rows r0 + RSTEP*h
+  const int q = tid & (KC - 1);
+  const int r0 = tid / KC;
+  int py[AH], px[AH], pb[AH];
+  bool pv[AH];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    int64_t m = m0 + r0 + 64 * h;
+  for (int h = 0; h < AH; ++h) {
+    int64_t m = m0 + r0 + RSTEP * h;
     pv[h] = m < p.M;
     int mm = pv[h] ? (int)m : 0;
     int b = mm / HWg;
@@ -91,13 +96,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     py[h] = gy * p.isy;
     px[h] = gx * p.isx;
   }
-  // (tap, chunk-in-tap) of this thread's chunk column, advanced by 4 chunks per K step
+  // (tap, chunk-in-tap) of this thread's chunk column, advanced by KC chunks per K step
   int ti = q / p.cpt;
   int c8 = q - ti * p.cpt;
-  const int nks = (ntaps * p.cpt + 3) >> 2;
+  const int nks = (ntaps * p.cpt + KC - 1) / KC;
   const int Cin = p.cpt * 8;
 
-  uint4 ra[2], rw[WCH];
+  uint4 ra[AH], rw[WCH];
   __syncthreads();  // tap table visible
 
   auto load_step = [&]() {
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     int dy = 0, dx = 0, tw = 0, tc = 0;
     if (tv) { dy = s_tap[tbase + ti]; dx = s_tap[32 + tbase + ti]; tw = s_tap[64 + tbase + ti]; tc = s_tap[96 + tbase + ti]; }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < AH; ++h) {
       uint4 v = make_uint4(0, 0, 0, 0);
       int iy = py[h] + dy, ix = px[h] + dx;
       if (tv && pv[h] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
@@ -117,26 +122,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
       int idx = tid + 256 * j;
-      int n = idx >> 2;
+      int n = idx / KC;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < BN * 4 && tv && (n0 + n) < p.Nw) {
+      if (idx < BN * KC && tv && (n0 + n) < p.Nw) {
         const bf16_t* src = wbase + (int64_t)(n0 + n) * p.Kw + tw * Cin + c8 * 8;
         v = *reinterpret_cast<const uint4*>(src);
       }
       rw[j] = v;
     }
     // advance to the next K step
-    c8 += 4;
+    c8 += KC;
     while (c8 >= p.cpt) { c8 -= p.cpt; ++ti; }
   };
   auto store_step = [&](int buf) {
+    bf16_t* const L = lds0 + buf * BUF;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      *reinterpret_cast<uint4*>(&lds[buf][(r0 + 64 * h) * LDSS + q * 8]) = ra[h];
+    for (int h = 0; h < AH; ++h)
+      *reinterpret_cast<uint4*>(&L[(r0 + RSTEP * h) * LDSS + q * 8]) = ra[h];
 #pragma unroll
     for (int j = 0; j < WCH; ++j) {
       int idx = tid + 256 * j;
-      if (idx < BN * 4) *reinterpret_cast<uint4*>(&lds[buf][(BM + (idx >> 2)) * LDSS + q * 8]) = rw[j];
+      if (idx < BN * KC) *reinterpret_cast<uint4*>(&L[(BM + idx / KC) * LDSS + q * 8]) = rw[j];
     }
   };
 
@@ -155,18 +161,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int cur = ks & 1;
     const bool more = (ks + 1) < nks;
     if (more) load_step();
-    bf16x8_t xf[2], wf[NT];
+    const bf16_t* const L = lds0 + cur * BUF;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-      xf[a] = *reinterpret_cast<const bf16x8_t*>(&lds[cur][(wv * 32 + a * 16 + frow) * LDSS + fk]);
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      bf16x8_t xf[2], wf[NT];
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
-      wf[b] = *reinterpret_cast<const bf16x8_t*>(&lds[cur][(BM + b * 16 + frow) * LDSS + fk]);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
+        xf[a] = *reinterpret_cast<const bf16x8_t*>(&L[(wv * 32 + a * 16 + frow) * LDSS + fk + 32 * kk]);
 #pragma unroll
       for (int b = 0; b < NT; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+        wf[b] = *reinterpret_cast<const bf16x8_t*>(&L[(BM + b * 16 + frow) * LDSS + fk + 32 * kk]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    }
     if (more) store_step(cur ^ 1);
     __syncthreads();
   }
@@ -239,11 +249,27 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   int nt = p.Nout <= 16 ? 1 : (p.Nout <= 32 ? 2 : (p.Nout <= 64 ? 4 : 8));
   while (nt > 2 && gx * ((p.Nout + 16 * nt - 1) / (16 * nt)) * gz < wg_min) nt >>= 1;
   const unsigned gy = (unsigned)((p.Nout + 16 * nt - 1) / (16 * nt));
+  // K step 64 when the K loop is long enough to amortise the bigger stage (>= 16 chunks of 8 channels)
+  static const int kc_env = getenv("USSEG_IGEMM_KC") ? atoi(getenv("USSEG_IGEMM_KC")) : 0;
+  const int kc = kc_env ? kc_env : (p.ntaps * p.cpt >= 16 ? 8 : 4);
+  const dim3 grid((unsigned)gx, gy, gz);
   const int slot = usseg_prof_start(1, s);
-  if (nt == 1) hipLaunchKernelGGL(igemm_kernel<1>, dim3((unsigned)gx, gy, gz), block, 0, s, p);
-  else if (nt == 2) hipLaunchKernelGGL(igemm_kernel<2>, dim3((unsigned)gx, gy, gz), block, 0, s, p);
-  else if (nt == 4) hipLaunchKernelGGL(igemm_kernel<4>, dim3((unsigned)gx, gy, gz), block, 0, s, p);
-  else hipLaunchKernelGGL(igemm_kernel<8>, dim3((unsigned)gx, gy, gz), block, 0, s, p);
+#define USSEG_IGEMM_LAUNCH(NT_, KC_)                                                                                         \
+  do {                                                                                                                         \
+    const size_t dyn = (size_t)2 * (128 + 16 * NT_) * (KC_ * 8 + 8) * sizeof(bf16_t) + 128 * sizeof(int);                      \
+    static bool attr = false;                                                                                                  \
+    if (!attr) {                                                                                                               \
+      (void)hipFuncSetAttribute((const void*)igemm_kernel<NT_, KC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   \
+      attr = true;                                                                                                             \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((igemm_kernel<NT_, KC_>), grid, block, dyn, s, p);                                                      \
+  } while (0)
+  if (kc == 8) {
+    if (nt == 1) USSEG_IGEMM_LAUNCH(1, 8); else if (nt == 2) USSEG_IGEMM_LAUNCH(2, 8); else if (nt == 4) USSEG_IGEMM_LAUNCH(4, 8); else USSEG_IGEMM_LAUNCH(8, 8);
+  } else {
+    if (nt == 1) USSEG_IGEMM_LAUNCH(1, 4); else if (nt == 2) USSEG_IGEMM_LAUNCH(2, 4); else if (nt == 4) USSEG_IGEMM_LAUNCH(4, 4); else USSEG_IGEMM_LAUNCH(8, 4);
+  }
+#undef USSEG_IGEMM_LAUNCH
   usseg_prof_stop(1, slot, s);
   return usseg_check_launch("igemm");
 }
