@@ -125,6 +125,30 @@ def layer_probe(dev):
         out.append({"layer": name, "us": round(us, 2), "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4),
                     "ai_flop_per_byte": round(flops / byts, 1), "roofline_tflops": round(roof, 1), "frac_of_roofline": round(tf / roof, 4),
                     "gb_per_s": round(byts / us / 1e3, 1)})
+    # the decoder's three dilated 3x3 512->64 branches at 32x32 (Decoder.py:14-25) as ONE multi-job launch, B=32
+    B, HW, ci, co = 32, 32, 512, 64
+    convs = torch.nn.ModuleList([Conv2D(ci, co, 3, d) for d in (2, 4, 8)])
+    FlatParams(convs, dev)
+    x = torch.randn(B, HW, HW, ci, device=dev).to(torch.bfloat16)
+    y = ops.new_act(B, HW, HW, 3 * co, dev)
+    jobs = [(x, c.wp_f, c.bias.data, 3, c.dil, y[..., j * co:(j + 1) * co], 0, 0.0) for j, c in enumerate(convs)]
+    for _ in range(3):
+        ops.conv2d_fwd_multi(jobs)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        ops.conv2d_fwd_multi(jobs)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    flops = 3 * 2.0 * B * HW * HW * 9 * ci * co
+    byts = 2.0 * B * HW * HW * (ci + 3 * co) + 3 * 2.0 * 9 * ci * co
+    tf = flops / us / 1e6
+    roof = min(PEAK_BF16_TFLOPS, flops / byts * 8.0)
+    out.append({"layer": "decoder b0: three dilated 3x3 512->64 (d=2,4,8) @32x32 B=32, one multi-job launch", "us": round(us, 2),
+                "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4), "ai_flop_per_byte": round(flops / byts, 1),
+                "roofline_tflops": round(roof, 1), "frac_of_roofline": round(tf / roof, 4), "gb_per_s": round(byts / us / 1e3, 1)})
     return out
 
 
