@@ -88,6 +88,53 @@ CONV_CASES = [
 ]
 
 
+# streaming kernel (conv_big.hip conv_stream_kernel): persistent workgroups, weights resident, double-buffered halo DMA.
+# (B, H, W, Cin, Cout, dil, forced workgroups or 0): the forced grid drives small shapes through many steps per workgroup.
+STREAM_CASES = [
+    (8, 256, 256, 32, 32, 1, 0),   # natural plan at 2048 groups: 256-pixel tiles, 4 steps per workgroup, counted wait
+    (4, 256, 256, 8, 64, 1, 0),    # fwd: 128-pixel tiles x 64 channels; dgrad 64 -> 8: two resident chunks, 16-channel tile
+    (3, 48, 32, 24, 16, 1, 8),     # 18 groups on 8 workgroups: ragged per-XCD split, Cin tail, one workgroup per XCD
+    (2, 64, 64, 40, 24, 2, 8),     # dilation 2 (32x32 lattices), two chunks (second partial), Cout 24: partial channel tile
+    (5, 32, 64, 16, 40, 1, 16),    # Cout 40 of a 64-wide tile (no counted wait), 40 groups on 16 workgroups
+    (1, 128, 128, 32, 32, 4, 8),   # dilation 4 on 128x128: 32x32 lattices, 64 groups: 8 steps per workgroup
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,dil,wgx", STREAM_CASES)
+def test_conv_stream(gen, monkeypatch, B, H, W, Cin, Cout, dil, wgx):
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    if wgx:
+        monkeypatch.setenv("USSEG_STREAM_MIN_STEPS", "1")
+        monkeypatch.setenv("USSEG_STREAM_WGX", str(wgx))
+    layer = Conv2D(Cin, Cout, 3, dil)
+    w = rnd(gen, 3, 3, Cin, Cout, scale=1.0 / math.sqrt(9 * Cin))
+    b = rnd(gen, Cout, scale=0.5)
+    layer.kernel.data.copy_(w)
+    layer.bias.data.copy_(b)
+    finalize(layer)
+    x = rnd(gen, B, H, W, Cin)
+    xd = to_dev_padded(x)
+    ref = O.conv2d_same(x, w, b, dil)
+    y = layer.forward(xd, act=ops.ACT_LRELU, alpha=0.3)
+    torch.cuda.synchronize()
+    assert rel(y[..., :Cout], bf(O.leaky_relu(ref))) < REL_BF16
+    assert y[..., Cout:].abs().max().item() == 0 if layer.cout_p > Cout else True
+    # the other kernels on the same input must agree to the bf16 bit (same products, fp32 accumulation order aside)
+    monkeypatch.setenv("USSEG_STREAM_MIN_STEPS", "1000000")
+    y2 = layer.forward(xd, act=ops.ACT_LRELU, alpha=0.3)
+    assert rel(y, y2) < 2e-3
+    monkeypatch.setenv("USSEG_STREAM_MIN_STEPS", "1" if wgx else "4")
+    # backward data through the same kernel (flipped taps, no bias)
+    layer.forward(xd)
+    dy = rnd(gen, B, H, W, Cout)
+    xr = x.clone().requires_grad_(True)
+    (O.conv2d_same(xr, w, b, dil) * dy).sum().backward()
+    dx = layer.backward(to_dev_padded(dy), skip_wgrad=True)
+    torch.cuda.synchronize()
+    assert rel(dx[..., :Cin], bf(xr.grad)) < 2 * REL_BF16
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,dil", CONV_CASES)
 def test_conv2d_fwd_dgrad_wgrad(gen, B, H, W, Cin, Cout, k, dil):
     from ultrasound_modeling_amd import ops

@@ -16,6 +16,10 @@ LAYERS = [
     ("b1 256->32 d2 @64", 64, 256, 32, 2), ("b1 256->32 d8 @64", 64, 256, 32, 8), ("b1' 128->32 d4 @64", 64, 128, 32, 4),
     ("b2 128->16 d2 @128", 128, 128, 16, 2), ("b2' 64->16 d8 @128", 128, 64, 16, 8),
 ]
+import os
+if os.environ.get("STEM"):
+    LAYERS = [("stem 8->32 @256", 256, 8, 32, 1), ("stem 32->32 @256", 256, 32, 32, 1), ("stem 32->64 @256", 256, 32, 64, 1),
+              ("s1 32->32 @128", 128, 32, 32, 1), ("s1 32->16 @128", 128, 32, 16, 1)]
 
 
 def timeit(fn, reps=10):

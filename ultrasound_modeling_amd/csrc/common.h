@@ -51,6 +51,130 @@ __device__ __forceinline__ float act_grad(float v, int act, float alpha) {
   }
 }
 
+// ---- shared epilogue of the conv kernels (16x16 MFMA layout: a lane holds Y[pixel = lane&15][n = nbase + 16*bt + j]) ----------------
+// vmcnt retires in issue order and counts stores, so a load issued after a store waits for that store's write latency
+// (about 1k cycles): the per-tile "load bias, add, store" loop these kernels started with serialized 2*NT store latencies
+// per workgroup.  Every load of the epilogue (scale, bias, residual, old output) is therefore issued BEFORE its first store.
+struct EpiArgs {
+  const float* scale;
+  const float* bias;
+  const bf16_t* res;
+  void* y;
+  int32_t ldy, ldr, Nout, act;
+  float alpha;
+  int32_t out_f32, accumulate;
+};
+template <int NT>
+struct EpiConst {
+  float4 bb[NT];   // this lane's bias values (zero without a bias)
+};
+template <int NT>
+__device__ __forceinline__ void epi_const_load(EpiConst<NT>& c, const float* bias, int nbase, int Nout) {
+#pragma unroll
+  for (int bt = 0; bt < NT; ++bt) {
+    const int n = nbase + bt * 16;
+    c.bb[bt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) c.bb[bt] = *reinterpret_cast<const float4*>(bias + (n < Nout ? n : 0));   // clamped: unconditional per lane
+  }
+}
+// The bias comes preloaded (EpiConst).  The rarer operands (scale of a folded BatchNorm, residual, old output when accumulating)
+// are loaded per pixel strip `a` for all its channel tiles before that strip's first store: at most NA exposed store latencies.
+// SIMPLE: bias + activation + bf16 store only (the caller guarantees no scale / residual / accumulate / fp32 output): the
+// streaming kernel's per-step epilogue must not contain even untaken load paths, the compiler's waits for them would drain
+// the prefetch DMA.
+template <int NA, int NT, bool SIMPLE = false>
+__device__ __forceinline__ void conv_epilogue(const EpiArgs& e, const EpiConst<NT>& c, const f32x4_t (&acc)[NA][NT], const int64_t (&opix)[NA],
+                                              const bool (&ovalid)[NA], int nbase, int64_t ybatch = 0) {
+  if constexpr (SIMPLE) {
+    // one uniform branch on the activation for the whole tile (apply_act's per-element switch costs ~10 scalar branches each)
+    auto run = [&](auto actf) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        if (!ovalid[a]) continue;
+#pragma unroll
+        for (int bt = 0; bt < NT; ++bt) {
+          const int n = nbase + bt * 16;
+          if (n >= e.Nout) continue;
+          uint2 o;
+          o.x = pack2bf(actf(acc[a][bt][0] + c.bb[bt].x), actf(acc[a][bt][1] + c.bb[bt].y));
+          o.y = pack2bf(actf(acc[a][bt][2] + c.bb[bt].z), actf(acc[a][bt][3] + c.bb[bt].w));
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(e.y) + ybatch + opix[a] * e.ldy + n) = o;
+        }
+      }
+    };
+    const float alpha = e.alpha;
+    const int act = e.act;
+    if (act == USSEG_ACT_NONE) run([](float v) { return v; });
+    else if (act == USSEG_ACT_LRELU) run([alpha](float v) { return v >= 0.f ? v : alpha * v; });
+    else if (act == USSEG_ACT_RELU) run([](float v) { return v > 0.f ? v : 0.f; });
+    else run([act, alpha](float v) { return apply_act(v, act, alpha); });
+    return;
+  }
+  const bool acc_bf = e.accumulate && !e.out_f32;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    if (!ovalid[a]) continue;
+    uint2 rr[NT], oo[NT];
+    float4 sc[NT];
+    if (e.res) {
+#pragma unroll
+      for (int bt = 0; bt < NT; ++bt) {
+        const int n = nbase + bt * 16;
+        rr[bt] = make_uint2(0, 0);
+        if (n < e.Nout) rr[bt] = *reinterpret_cast<const uint2*>(e.res + opix[a] * e.ldr + n);
+      }
+    }
+    if (acc_bf) {
+#pragma unroll
+      for (int bt = 0; bt < NT; ++bt) {
+        const int n = nbase + bt * 16;
+        oo[bt] = make_uint2(0, 0);
+        if (n < e.Nout) oo[bt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(e.y) + ybatch + opix[a] * e.ldy + n);
+      }
+    }
+    if (e.scale) {
+#pragma unroll
+      for (int bt = 0; bt < NT; ++bt) {
+        const int n = nbase + bt * 16;
+        sc[bt] = *reinterpret_cast<const float4*>(e.scale + (n < e.Nout ? n : 0));
+      }
+    }
+#pragma unroll
+    for (int bt = 0; bt < NT; ++bt) {
+      const int n = nbase + bt * 16;
+      if (n >= e.Nout) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
+      if (e.scale) { v[0] *= sc[bt].x; v[1] *= sc[bt].y; v[2] *= sc[bt].z; v[3] *= sc[bt].w; }
+      v[0] += c.bb[bt].x; v[1] += c.bb[bt].y; v[2] += c.bb[bt].z; v[3] += c.bb[bt].w;
+      if (e.act != USSEG_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], e.act, e.alpha);
+      }
+      if (e.res) {
+        v[0] += __uint_as_float(rr[bt].x << 16); v[1] += __uint_as_float(rr[bt].x & 0xffff0000u);
+        v[2] += __uint_as_float(rr[bt].y << 16); v[3] += __uint_as_float(rr[bt].y & 0xffff0000u);
+      }
+      if (e.out_f32) {   // the <=4-class heads only: tiny outputs, element-wise tail handling
+        float* dst = reinterpret_cast<float*>(e.y) + ybatch + opix[a] * e.ldy + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < e.Nout) dst[j] = e.accumulate ? dst[j] + v[j] : v[j];
+      } else {
+        if (acc_bf) {
+          v[0] += __uint_as_float(oo[bt].x << 16); v[1] += __uint_as_float(oo[bt].x & 0xffff0000u);
+          v[2] += __uint_as_float(oo[bt].y << 16); v[3] += __uint_as_float(oo[bt].y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(e.y) + ybatch + opix[a] * e.ldy + n) = o;
+      }
+    }
+  }
+}
+
 // destination map of a weight gradient (UssegWgradDst by value in the kernel parameters); nblocks == 0: identity
 struct WgMap {
   int32_t nblocks, pad;

@@ -182,51 +182,167 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
   }
 
   // ---- epilogue: lane holds Y[its pixel][n = 4*(lane>>4) + j] per n-tile
+  const EpiArgs e = {p.scale, p.bias, p.res, p.y, p.ldy, p.ldr, p.Nout, p.act, p.alpha, p.out_f32, p.accumulate};
+  const int nbase = n0 + qk * 4;
+  EpiConst<NT> ec;
+  epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
+  conv_epilogue<NS, NT>(e, ec, acc, opix, ovalid, nbase);
+#endif
+}
+
+// ---- streaming variant for the HBM-bound layers (few input channels, many pixels: the stem and stage-1 convs) -------------
+// The workgroup is persistent: the whole weight operand of its channel tile (nchunks x 9 x BN x 32, <= 40 KB) is DMA'd into
+// LDS once, then it walks over pixel groups with the halo tiles double-buffered: the DMA of step s+1 is in flight under the
+// MFMAs and the stores of step s.  Nothing passes through VGPRs on the way in, the bias sits in registers, and the epilogue
+// issues no loads, so the only wait of a step is `vmcnt(stores of the previous step)` - the stores themselves keep flying.
+// One patch per pixel group (NV == 1): the group's geometry is four scalars read from a small LDS table.
+// Walk: XCD x (= blockIdx.x % 8) owns a contiguous eighth of the groups and its workgroups take adjacent groups at the
+// same time, so concurrently staged halo tiles are neighbours in memory and shared halo columns hit in that XCD's L2.
+template <int NT, int NS>
+__global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigJob p, const int fast_wait) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BN = 16 * NT;
+  constexpr int W_BYTES = 9 * BN * 64;
+  constexpr int NPW = 9 * BN / 16;            // W pieces per chunk
+  constexpr int A_IT = NS == 4 ? 6 : 3;       // A pieces per wave: halo tile 18x18 = 324 pixels (NS=4) / 10x18 = 180 (NS=2)
+  constexpr int MAXG = 64;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  __shared__ int s_grp[MAXG][4];               // per group: DMA origin (bytes), output pixel base, ly0 - 1, lx0 - 1
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.y * BN;
+  const int HW2 = p.PW + 2, NHP = (p.PH + 2) * HW2;
+  const int a_bytes = p.npa * 1024;
+  char* const wlds = lds;
+  char* const alds = lds + p.nchunks * W_BYTES;
+  const int dd = p.d * p.d;
+
+  const int ngroups = p.npatches;
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3, nj = gridDim.x >> 3;   // gridDim.x is a multiple of 8
+  const int gpx = (ngroups + 7) >> 3;
+  const int g_lo = xcd * gpx + wj;
+  int g_hi = (xcd + 1) * gpx;
+  if (g_hi > ngroups) g_hi = ngroups;
+  int ng = g_lo < g_hi ? (g_hi - g_lo + nj - 1) / nj : 0;
+  if (ng > MAXG) ng = MAXG;                    // the host sizes the grid so that this never truncates
+  if (ng == 0) return;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const int slot_q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+  const int cq = slot_q * 8;
+
+  // weights: every chunk, once
+  for (int j = wv; j < p.nchunks * NPW; j += 4) {
+    const int ck = j / NPW, r = j - ck * NPW;
+    const int row = 16 * r + (lane >> 2);      // t*BN + n
+    const int t = row / BN, n = row - t * BN;
+    const int tw = p.flip ? 8 - t : t;
+    const bool ok = (n0 + n) < p.Nw && (ck * 32 + cq) < p.Cin;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wlds + j * 1024), 16,
+                                             ok ? (uint32_t)((n0 + n) * p.Kw + tw * p.Cin + ck * 32 + cq) * 2u : OOB_OFF, 0, 0, 0);
+  }
+  // group table
+  for (int i = tid; i < ng; i += 256) {
+    const int g = g_lo + i * nj;
+    const int v = g / p.tiles_per_v, tt = g - v * p.tiles_per_v;
+    const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+    const int b = v / dd, ab = v - b * dd;
+    const int la = ab / p.d, lb = ab - la * p.d;
+    const int64_t org = (((int64_t)(b * p.H + la + p.d * (ty * p.PH - 1))) * p.W + lb + p.d * (tx * p.PW - 1)) * p.ldx * 2;
+    s_grp[i][0] = (int)(uint32_t)org;          // may wrap below zero: only in-image lanes (true offset >= 0) use it
+    s_grp[i][1] = (b * p.H + la + p.d * ty * p.PH) * p.W + lb + p.d * tx * p.PW;
+    s_grp[i][2] = ty * p.PH - 1;
+    s_grp[i][3] = tx * p.PW - 1;
+  }
+  // this lane's halo items: byte offset relative to the group origin, and (hy, hx) for the in-image test
+  uint32_t a_rel[A_IT];
+  int a_hy[A_IT], a_hx[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int hp = 16 * (wv + 4 * it) + (lane >> 2);
+    const int hy = hp / HW2, hx = hp - hy * HW2;
+    a_hy[it] = hp < NHP ? hy : -(1 << 20);     // never in range
+    a_hx[it] = hx;
+    a_rel[it] = (uint32_t)(((p.d * hy) * p.W + p.d * hx) * p.ldx + cq) * 2u;
+  }
+  // this lane's NS output pixels
+  const int pl = lane & 15, qk = lane >> 4;
+  const int rows_per_strip = 16 / p.PW;
+  int hb[NS], orel[NS];
 #pragma unroll
   for (int a = 0; a < NS; ++a) {
-    if (!ovalid[a]) continue;
+    const int sl = wv * NS + a;
+    const int r = pl / p.PW, c = pl - r * p.PW;
+    const int row = sl * rows_per_strip + r;
+    hb[a] = row * HW2 + c;
+    orel[a] = p.d * row * p.W + p.d * c;
+  }
+  const int w_lane = pl * 64 + ((qk ^ (((pl >> 2) & 1) << 1)) << 4);
+  const EpiArgs e = {p.scale, p.bias, p.res, p.y, p.ldy, p.ldr, p.Nout, p.act, p.alpha, p.out_f32, p.accumulate};
+  const int nbase = n0 + qk * 4;
+  EpiConst<NT> ec;
+  epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
+  __syncthreads();                             // group table visible
+
+  auto issue_a = [&](int s) {
+    const int gl = s / p.nchunks, ck = s - gl * p.nchunks;
+    char* abuf = alds + (s & 1) * a_bytes;
+    const uint32_t org = (uint32_t)s_grp[gl][0] + ck * 64;
+    const int lym1 = s_grp[gl][2], lxm1 = s_grp[gl][3];
+    const bool cok = ck * 32 + cq < p.Cin;
 #pragma unroll
-    for (int bt = 0; bt < NT; ++bt) {
-      int n = n0 + bt * 16 + qk * 4;
-      if (n >= p.Nout) continue;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
-      if (p.scale) {
-        float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-      }
-      if (p.bias) {
-        float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
-      if (p.act != USSEG_ACT_NONE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act, p.alpha);
-      }
-      if (p.res) {
-        uint2 rr = *reinterpret_cast<const uint2*>(p.res + opix[a] * p.ldr + n);
-        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-      }
-      if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.y) + opix[a] * p.ldy + n;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < p.Nout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
-      } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + opix[a] * p.ldy + n;
-        if (p.accumulate) {
-          uint2 o = *reinterpret_cast<const uint2*>(dst);
-          v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-          v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
-        }
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(dst) = o;
+    for (int it = 0; it < A_IT; ++it) {
+      const int j = wv + 4 * it;
+      if (j < p.npa) {
+        const bool ok = cok && (unsigned)(lym1 + a_hy[it]) < (unsigned)p.Hl && (unsigned)(lxm1 + a_hx[it]) < (unsigned)p.Wl;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(abuf + j * 1024), 16, ok ? org + a_rel[it] : OOB_OFF, 0, 0, 0);
       }
     }
+  };
+
+  f32x4_t acc[NS][NT];
+  const int total = ng * p.nchunks;
+  issue_a(0);
+  for (int s = 0; s < total; ++s) {
+    const int gl = s / p.nchunks, ck = s - gl * p.nchunks;
+    // step s has landed: everything older than the previous step's NS*NT stores is complete (vmcnt retires in order)
+    // (a bare s_barrier: __syncthreads() would prepend its own vmcnt(0) and drain the stores after all)
+    if (fast_wait && s > 0 && ck == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NS * NT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ... for every wave, and everyone is done reading the other buffer
+    if (s + 1 < total) issue_a(s + 1);
+    if (ck == 0) {
+#pragma unroll
+      for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const char* abuf = alds + (s & 1) * a_bytes;
+    const char* wbuf = wlds + ck * W_BYTES + w_lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int toff = (t / 3) * HW2 + (t % 3);
+      bf16x8_t xf[NS], wf[NT];
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const int hp = hb[a] + toff;
+        xf[a] = *reinterpret_cast<const bf16x8_t*>(abuf + (hp << 6) + ((qk << 4) ^ ((hp & 4) << 3)));
+      }
+#pragma unroll
+      for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8_t*>(wbuf + (t * BN + b * 16) * 64);
+#pragma unroll
+      for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    }
+    if (ck != p.nchunks - 1) continue;
+    int64_t opix[NS];
+    bool ovalid[NS];
+    const int obase = s_grp[gl][1];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) { opix[a] = obase + orel[a]; ovalid[a] = true; }
+    conv_epilogue<NS, NT, true>(e, ec, acc, opix, ovalid, nbase);
   }
 #endif
 }
@@ -234,9 +350,9 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
 // Fills a job from a conv geometry; returns 0 if the geometry does not fit the 256-pixel tiling.
 static int big_fill_job(BigJob& p, const bf16_t* x, const bf16_t* w, void* y, const float* bias, const bf16_t* res, int B, int H, int W,
                         int d, int Cin, int ldx, int Nout, int ldy, int ldr, int Nw, int Kw, int act, float alpha, int out_f32,
-                        int accumulate, int flip, int PX) {
+                        int accumulate, int flip, int PX, int any_cin = 0) {
   static const int min_cin = getenv("USSEG_BIG_MIN_CIN") ? atoi(getenv("USSEG_BIG_MIN_CIN")) : 33;
-  if (d < 1 || H % d || W % d || Cin < min_cin) return 0;
+  if (d < 1 || H % d || W % d || (Cin < min_cin && !any_cin)) return 0;
   const int Hl = H / d, Wl = W / d;
   int PW;
   if (Wl % 16 == 0) PW = 16;
@@ -309,6 +425,72 @@ struct BigGeom {   // what big_fill_job needs, so that a job can be re-filled fo
   int B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act; float alpha; int out_f32, accumulate, flip;
 };
 
+template <int NT, int NS>
+static void stream_launch_t(const BigJob& p, dim3 grid, size_t dyn, int fast_wait, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_stream_kernel<NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);   // + 1 KB static
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_stream_kernel<NT, NS>), grid, dim3(256), dyn, s, p, fast_wait);
+}
+
+// Streaming kernel for one job whose weights fit in LDS and whose launch has enough pixel groups to amortise them.
+static int stream_plan_and_launch(const BigGeom& g, const float* epi_scale, int dry, hipStream_t s) {
+  static const int mode = getenv("USSEG_STREAM") ? atoi(getenv("USSEG_STREAM")) : 1;
+  static const int px_env = getenv("USSEG_STREAM_PX") ? atoi(getenv("USSEG_STREAM_PX")) : 0;
+  // read per call (not cached): the parity tests use these two to drive small shapes through many steps per workgroup
+  const char* ms_env = getenv("USSEG_STREAM_MIN_STEPS");
+  const char* wgx_env = getenv("USSEG_STREAM_WGX");
+  const int min_steps = ms_env ? atoi(ms_env) : 1;
+  static const int occ_env = getenv("USSEG_STREAM_OCC") ? atoi(getenv("USSEG_STREAM_OCC")) : 0;
+  if (!mode || usseg_tap_mask.group_ch) return 0;
+  // its epilogue is bias + activation + bf16 store only (no loads inside the streaming loop)
+  if (g.out_f32 || g.res || g.accumulate || (!g.flip && epi_scale)) return 0;
+  const int nt = nt_for(g.Nout);
+  const int nchunks = (g.Cin + 31) / 32;
+  const size_t wbytes = (size_t)nchunks * 9 * 16 * nt * 64;
+  if (wbytes > 40960) return 0;
+  const int gy = (g.Nout + 16 * nt - 1) / (16 * nt);
+  BigJob p;
+  for (int PX = 256; PX >= 128; PX >>= 1) {
+    if (px_env && PX != px_env) continue;
+    if (!big_fill_job(p, g.x, g.w, g.y, g.bias, g.res, g.B, g.H, g.W, g.d, g.Cin, g.ldx, g.Nout, g.ldy, g.ldr, g.Nw, g.Kw, g.act, g.alpha,
+                      g.out_f32, g.accumulate, g.flip, PX, 1))
+      continue;
+    if (p.NV != 1 || p.PW != 16) continue;
+    const size_t dyn = wbytes + 2 * (size_t)p.npa * 1024;
+    int occ = (int)((160 * 1024 - 2048) / (dyn + 1024));
+    if (occ > 4) occ = 4;
+    if (occ_env > 0 && occ_env < occ) occ = occ_env;
+    if (occ < 1) continue;
+    int wgx = (256 * occ / gy) & ~7;             // one resident wave of workgroups, a multiple of 8 (per-XCD walk)
+    if (wgx < 8) wgx = 8;
+    if (wgx_env && atoi(wgx_env) >= 8) wgx = atoi(wgx_env) & ~7;
+    const int gpx = (p.npatches + 7) / 8;        // groups per XCD
+    int per_wg = (gpx + wgx / 8 - 1) / (wgx / 8);
+    if (per_wg * nchunks < min_steps && !px_env) continue;   // too few steps to amortise the weights: the tiled kernels win
+    if (per_wg > 64) { wgx = ((gpx + 63) / 64) * 8; per_wg = 64; }
+    // the in-order wait on "all but the youngest NS*NT operations" needs every step to issue exactly that many stores
+    const int fast_wait = g.Nout % (16 * nt) == 0;
+    if (dry) return 1;
+    const dim3 grid(wgx, gy, 1);
+    const int slot = usseg_prof_start(1, s);
+    if (PX == 256) {
+      if (nt == 1) stream_launch_t<1, 4>(p, grid, dyn, fast_wait, s);
+      else if (nt == 2) stream_launch_t<2, 4>(p, grid, dyn, fast_wait, s);
+      else stream_launch_t<4, 4>(p, grid, dyn, fast_wait, s);
+    } else {
+      if (nt == 1) stream_launch_t<1, 2>(p, grid, dyn, fast_wait, s);
+      else if (nt == 2) stream_launch_t<2, 2>(p, grid, dyn, fast_wait, s);
+      else stream_launch_t<4, 2>(p, grid, dyn, fast_wait, s);
+    }
+    usseg_prof_stop(1, slot, s);
+    return 1;
+  }
+  return 0;
+}
+
 // Chooses the tile (pixels per workgroup, channel tile) and launches; 0 if no tiling fits or the launch would be too small.
 static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
   static const int mode = getenv("USSEG_BIG") ? atoi(getenv("USSEG_BIG")) : 1;
@@ -317,6 +499,15 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
   static const int min_wg = getenv("USSEG_BIG_MIN_WG") ? atoi(getenv("USSEG_BIG_MIN_WG")) : 128;
   static const int wg_min = getenv("USSEG_BIG_WG_TILE") ? atoi(getenv("USSEG_BIG_WG_TILE")) : 512;
   if (!mode) return 0;
+  {   // HBM-bound jobs whose weights fit in LDS: the streaming kernel, one full-chip launch per job
+    static const int multi = getenv("USSEG_STREAM_MULTI") ? atoi(getenv("USSEG_STREAM_MULTI")) : 1;
+    bool all = njobs == 1 || multi;
+    for (int j = 0; j < njobs && all; ++j) all = stream_plan_and_launch(g[j], usseg_epi_scale[j], 1, s) != 0;
+    if (all) {
+      for (int j = 0; j < njobs; ++j) (void)stream_plan_and_launch(g[j], usseg_epi_scale[j], 0, s);
+      return 1;
+    }
+  }
   int nt_max = 1;
   for (int j = 0; j < njobs; ++j) nt_max = nt_for(g[j].Nout) > nt_max ? nt_for(g[j].Nout) : nt_max;
   BigParams P;

@@ -175,52 +175,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloMulti P) {
   }
 
   // ---- epilogue (same contract as the gather kernel): lane holds Y[its pixel][n = 4*(lane>>4) + j] per n-tile
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    if (!ovalid[a]) continue;
-#pragma unroll
-    for (int bt = 0; bt < NT; ++bt) {
-      int n = n0 + bt * 16 + (lane >> 4) * 4;
-      if (n >= p.Nout) continue;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
-      if (p.scale) {
-        float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-      }
-      if (p.bias) {
-        float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
-      if (p.act != USSEG_ACT_NONE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act, p.alpha);
-      }
-      if (p.res) {
-        uint2 rr = *reinterpret_cast<const uint2*>(p.res + opix[a] * p.ldr + n);
-        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-      }
-      if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.y) + opix[a] * p.ldy + n;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < p.Nout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
-      } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + opix[a] * p.ldy + n;
-        if (p.accumulate) {
-          uint2 o = *reinterpret_cast<const uint2*>(dst);
-          v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-          v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
-        }
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(dst) = o;
-      }
-    }
-  }
+  const EpiArgs e = {p.scale, p.bias, p.res, p.y, p.ldy, p.ldr, p.Nout, p.act, p.alpha, p.out_f32, p.accumulate};
+  const int nbase = n0 + (lane >> 4) * 4;
+  EpiConst<NT> ec;
+  epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
+  conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase);
 }
 
 // ---- persistent variant for the HBM-bound layers (few input channels, many pixels) ------------------------------
@@ -242,9 +201,16 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel
   const int n0 = blockIdx.y * BN;
   const int HW2 = p.PW + 2, HPP = (p.PH + 2) * HW2, NHP = p.NV * HPP;
   const int ngroups = (p.npatches + p.NV - 1) / p.NV;
-  const int g_begin = blockIdx.x * gpb;
-  int ng = ngroups - g_begin;
-  if (ng > gpb) ng = gpb;
+  // XCD-aware walk (workgroup i runs on XCD i % 8): each XCD owns a contiguous eighth of the pixel groups and its
+  // workgroups take ADJACENT groups at the same time, so concurrent halo tiles are neighbours in memory (spread over all
+  // L2 channels, shared halos hit in that XCD's L2) instead of sitting a power-of-two stride apart.
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3, nj = gridDim.x >> 3;   // gridDim.x is a multiple of 8
+  const int gpx = (ngroups + 7) >> 3;
+  const int g_lo = xcd * gpx + wj;
+  int g_hi = (xcd + 1) * gpx;
+  if (g_hi > ngroups) g_hi = ngroups;
+  int ng = g_lo < g_hi ? (g_hi - g_lo + nj - 1) / nj : 0;
+  if (ng > gpb) ng = gpb;   // host sizes gpb so that this never truncates
   const int q = tid & 3;
 
   // weights: all chunks, once
@@ -260,7 +226,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel
   }
   // patch table of every group this workgroup owns
   for (int i = tid; i < ng * p.NV; i += 256) {
-    int gp = (g_begin + i / p.NV) * p.NV + (i % p.NV);
+    int gp = (g_lo + (i / p.NV) * nj) * p.NV + (i % p.NV);
     int valid = gp < p.npatches;
     int gpc = valid ? gp : 0;
     int v = gpc / p.tiles_per_v, tt = gpc - v * p.tiles_per_v;
@@ -295,6 +261,10 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel
     a_base[s2] = (pi * HPP + o_row[s2] * HW2 + c) * LDSS + fk;
   }
   const int w_base = (lane & 15) * LDSS + fk;
+  const EpiArgs e = {p.scale, p.bias, p.res, p.y, p.ldy, p.ldr, p.Nout, p.act, p.alpha, p.out_f32, p.accumulate};
+  const int nbase = n0 + (lane >> 4) * 4;
+  EpiConst<NT> ec;                               // per-lane bias: loaded once for all pixel groups
+  epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
   __syncthreads();
 
   uint4 ra[A_IT];
@@ -349,54 +319,15 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel
     __syncthreads();
     if (ck != p.nchunks - 1) continue;
     // ---- epilogue of pixel group gl
+    int64_t opix[2];
+    bool ovalid[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int* pt = s_patch[gl * 8 + o_pi[a]];
-      if (!pt[5]) continue;
-      const int64_t opix = ((int64_t)pt[0] * p.H + pt[1] + p.d * (pt[3] + o_row[a])) * p.W + pt[2] + p.d * (pt[4] + o_col[a]);
-#pragma unroll
-      for (int bt = 0; bt < NT; ++bt) {
-        int n = n0 + bt * 16 + (lane >> 4) * 4;
-        if (n >= p.Nout) continue;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
-        if (p.scale) {
-          float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-          v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-        }
-        if (p.bias) {
-          float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-        }
-        if (p.act != USSEG_ACT_NONE) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act, p.alpha);
-        }
-        if (p.res) {
-          uint2 rr = *reinterpret_cast<const uint2*>(p.res + opix * p.ldr + n);
-          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-        }
-        if (p.out_f32) {
-          float* dst = reinterpret_cast<float*>(p.y) + opix * p.ldy + n;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (n + j < p.Nout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
-        } else {
-          bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + opix * p.ldy + n;
-          if (p.accumulate) {
-            uint2 o = *reinterpret_cast<const uint2*>(dst);
-            v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-            v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
-          }
-          uint2 o;
-          o.x = pack2bf(v[0], v[1]);
-          o.y = pack2bf(v[2], v[3]);
-          *reinterpret_cast<uint2*>(dst) = o;
-        }
-      }
+      ovalid[a] = pt[5] != 0;
+      opix[a] = ((int64_t)pt[0] * p.H + pt[1] + p.d * (pt[3] + o_row[a])) * p.W + pt[2] + p.d * (pt[4] + o_col[a]);
     }
+    conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase);
   }
 }
 
@@ -448,10 +379,23 @@ static int halo_launch(HaloMulti& P, int njobs, hipStream_t s) {
   static const int no_persist = getenv("USSEG_NO_PERSIST") != nullptr;
   const size_t wbytes = (size_t)p0.nchunks * 9 * 16 * nt * 40 * sizeof(bf16_t);
   if (!no_persist && wbytes <= 46080 && gx >= 1024) {
-    int gpb = (gx * njobs + 1023) / 1024;          // ~1024 workgroups (2 per CU resident, two waves of them)
-    if (gpb > 16) gpb = 16;
-    const int pgx = (gx + gpb - 1) / gpb;
     const size_t dyn = wbytes + (size_t)maxhp * 40 * sizeof(bf16_t);   // weights + the largest halo tile of the jobs
+    // One resident wave of workgroups: `occ` per CU by LDS (160 KB) and by the launch bounds.  A second, partly filled wave
+    // would cost a whole extra pass (3 resident + 1024 workgroups used to run as 768 + 256).
+    static const int occ_env = getenv("USSEG_PERSIST_OCC") ? atoi(getenv("USSEG_PERSIST_OCC")) : 0;
+    int occ = (int)((160 * 1024) / (dyn + 3072 + 256));
+    const int occ_max = nt <= 2 ? 4 : 2;
+    if (occ > occ_max) occ = occ_max;
+    if (occ < 1) occ = 1;
+    if (occ_env > 0) occ = occ_env;
+    const int64_t total_groups = (int64_t)gx * njobs;
+    int waves = 1;
+    while ((total_groups + 256 * occ * waves - 1) / (256 * occ * waves) > 16) ++waves;   // at most 16 groups per workgroup
+    int gpb = (int)((total_groups + 256 * occ * waves - 1) / (256 * occ * waves));
+    if (gpb < 1) gpb = 1;
+    int pgx = ((gx + gpb - 1) / gpb + 7) & ~7;       // a multiple of 8: workgroups per XCD = pgx / 8
+    gpb = (((gx + 7) >> 3) + (pgx >> 3) - 1) / (pgx >> 3);   // groups per workgroup under the per-XCD split
+    if (gpb > 16) { pgx = ((((gx + 7) >> 3) + 15) / 16) * 8; gpb = 16; }
     static bool attr_done = false;   // > 64 KB of LDS per workgroup needs the opt-in (one-time host call, never a stream op)
     if (!attr_done) {
       (void)hipFuncSetAttribute((const void*)conv_halo_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -182,59 +182,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 
   // --- epilogue: lane holds Y[pixel = lane&15][n = 4*(lane>>4) + j]
+  int64_t opix[2];
+  bool ovalid[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     int64_t m = m0 + wv * 32 + a * 16 + frow;
-    if (m >= p.M) continue;
-    int mm = (int)m;
+    ovalid[a] = m < p.M;
+    int mm = ovalid[a] ? (int)m : 0;
     int b = mm / HWg;
     int rem = mm - b * HWg;
     int gy = rem / p.Wg;
     int gx = rem - gy * p.Wg;
-    int64_t opix = ((int64_t)(b * p.Ho + gy * p.osy + oay)) * p.Wo + gx * p.osx + oax;
-#pragma unroll
-    for (int bt = 0; bt < NT; ++bt) {
-      int n = n0 + bt * 16 + (lane >> 4) * 4;
-      if (n >= p.Nout) continue;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[a][bt][j];
-      if (p.scale) {
-        float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-      }
-      if (p.bias) {
-        float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
-      if (p.act != USSEG_ACT_NONE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act, p.alpha);
-      }
-      if (p.res) {
-        uint2 rr = *reinterpret_cast<const uint2*>(p.res + opix * p.ldr + n);
-        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-      }
-      if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.y) + ybatch + opix * p.ldy + n;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < p.Nout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
-      } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + ybatch + opix * p.ldy + n;
-        if (p.accumulate) {
-          uint2 o = *reinterpret_cast<const uint2*>(dst);
-          v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-          v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
-        }
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(dst) = o;
-      }
-    }
+    opix[a] = ((int64_t)(b * p.Ho + gy * p.osy + oay)) * p.Wo + gx * p.osx + oax;
   }
+  const EpiArgs e = {p.scale, p.bias, p.res, p.y, p.ldy, p.ldr, p.Nout, p.act, p.alpha, p.out_f32, p.accumulate};
+  const int nbase = n0 + (lane >> 4) * 4;
+  EpiConst<NT> ec;
+  epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
+  conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase, ybatch);
 }
 
 static int launch_igemm(const IgemmParams& p, hipStream_t s) {
