@@ -79,36 +79,88 @@ __device__ __forceinline__ void epi_const_load(EpiConst<NT>& c, const float* bia
 }
 // The bias comes preloaded (EpiConst).  The rarer operands (scale of a folded BatchNorm, residual, old output when accumulating)
 // are loaded per pixel strip `a` for all its channel tiles before that strip's first store: at most NA exposed store latencies.
-// SIMPLE: bias + activation + bf16 store only (the caller guarantees no scale / residual / accumulate / fp32 output): the
-// streaming kernel's per-step epilogue must not contain even untaken load paths, the compiler's waits for them would drain
-// the prefetch DMA.
+// Straight-line epilogue body for bf16 outputs, specialised at compile time on (residual, accumulate): the loads of a pixel
+// strip precede its stores and there is no untaken load path, so the compiler's vmcnt bookkeeping is exact.  (With the
+// optional operands behind runtime branches it put a vmcnt(0) in front of every store: 16 serialized write latencies, half
+// the lifetime of a short-K workgroup.)
+template <int NA, int NT, bool RES, bool ACC, typename ActF>
+__device__ __forceinline__ void epi_fast(const EpiArgs& e, const EpiConst<NT>& c, const f32x4_t (&acc)[NA][NT], const int64_t (&opix)[NA],
+                                         const bool (&ovalid)[NA], int nbase, int64_t ybatch, ActF actf) {
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    if (!ovalid[a]) continue;
+    bf16_t* const yrow = reinterpret_cast<bf16_t*>(e.y) + ybatch + opix[a] * e.ldy;
+    uint2 rr[NT], oo[NT];
+    if constexpr (RES) {
+#pragma unroll
+      for (int bt = 0; bt < NT; ++bt) {
+        const int n = nbase + bt * 16;
+        rr[bt] = *reinterpret_cast<const uint2*>(e.res + opix[a] * e.ldr + (n < e.Nout ? n : 0));
+      }
+    }
+    if constexpr (ACC) {
+#pragma unroll
+      for (int bt = 0; bt < NT; ++bt) {
+        const int n = nbase + bt * 16;
+        oo[bt] = *reinterpret_cast<const uint2*>(yrow + (n < e.Nout ? n : 0));
+      }
+    }
+#pragma unroll
+    for (int bt = 0; bt < NT; ++bt) {
+      const int n = nbase + bt * 16;
+      if (n >= e.Nout) continue;
+      float v0 = actf(acc[a][bt][0] + c.bb[bt].x), v1 = actf(acc[a][bt][1] + c.bb[bt].y);
+      float v2 = actf(acc[a][bt][2] + c.bb[bt].z), v3 = actf(acc[a][bt][3] + c.bb[bt].w);
+      if constexpr (RES) {
+        v0 += __uint_as_float(rr[bt].x << 16); v1 += __uint_as_float(rr[bt].x & 0xffff0000u);
+        v2 += __uint_as_float(rr[bt].y << 16); v3 += __uint_as_float(rr[bt].y & 0xffff0000u);
+      }
+      if constexpr (ACC) {
+        v0 += __uint_as_float(oo[bt].x << 16); v1 += __uint_as_float(oo[bt].x & 0xffff0000u);
+        v2 += __uint_as_float(oo[bt].y << 16); v3 += __uint_as_float(oo[bt].y & 0xffff0000u);
+      }
+      uint2 o;
+      o.x = pack2bf(v0, v1);
+      o.y = pack2bf(v2, v3);
+      *reinterpret_cast<uint2*>(yrow + n) = o;
+    }
+  }
+}
+
+// SIMPLE: the caller guarantees no scale / residual / accumulate / fp32 output (the streaming kernel's per-step epilogue must
+// not contain even untaken load paths: the compiler's waits for them would drain the prefetch DMA).
 template <int NA, int NT, bool SIMPLE = false>
 __device__ __forceinline__ void conv_epilogue(const EpiArgs& e, const EpiConst<NT>& c, const f32x4_t (&acc)[NA][NT], const int64_t (&opix)[NA],
                                               const bool (&ovalid)[NA], int nbase, int64_t ybatch = 0) {
-  if constexpr (SIMPLE) {
-    // one uniform branch on the activation for the whole tile (apply_act's per-element switch costs ~10 scalar branches each)
-    auto run = [&](auto actf) {
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        if (!ovalid[a]) continue;
-#pragma unroll
-        for (int bt = 0; bt < NT; ++bt) {
-          const int n = nbase + bt * 16;
-          if (n >= e.Nout) continue;
-          uint2 o;
-          o.x = pack2bf(actf(acc[a][bt][0] + c.bb[bt].x), actf(acc[a][bt][1] + c.bb[bt].y));
-          o.y = pack2bf(actf(acc[a][bt][2] + c.bb[bt].z), actf(acc[a][bt][3] + c.bb[bt].w));
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(e.y) + ybatch + opix[a] * e.ldy + n) = o;
-        }
-      }
-    };
-    const float alpha = e.alpha;
-    const int act = e.act;
-    if (act == USSEG_ACT_NONE) run([](float v) { return v; });
-    else if (act == USSEG_ACT_LRELU) run([alpha](float v) { return v >= 0.f ? v : alpha * v; });
-    else if (act == USSEG_ACT_RELU) run([](float v) { return v > 0.f ? v : 0.f; });
-    else run([act, alpha](float v) { return apply_act(v, act, alpha); });
+  const float alpha = e.alpha;
+  const int act = e.act;
+  auto a_none = [](float v) { return v; };
+  auto a_lrelu = [alpha](float v) { return v >= 0.f ? v : alpha * v; };
+  auto a_relu = [](float v) { return v > 0.f ? v : 0.f; };
+  auto a_any = [act, alpha](float v) { return apply_act(v, act, alpha); };
+  const bool plain = SIMPLE || (!e.scale && !e.out_f32 && !e.res && !e.accumulate);
+  if (plain) {   // one uniform branch on the activation for the whole tile (apply_act's per-element switch costs ~10 scalar branches each)
+    if (act == USSEG_ACT_NONE) epi_fast<NA, NT, false, false>(e, c, acc, opix, ovalid, nbase, ybatch, a_none);
+    else if (act == USSEG_ACT_LRELU) epi_fast<NA, NT, false, false>(e, c, acc, opix, ovalid, nbase, ybatch, a_lrelu);
+    else if (act == USSEG_ACT_RELU) epi_fast<NA, NT, false, false>(e, c, acc, opix, ovalid, nbase, ybatch, a_relu);
+    else epi_fast<NA, NT, false, false>(e, c, acc, opix, ovalid, nbase, ybatch, a_any);
     return;
+  }
+  if constexpr (!SIMPLE) {
+    if (!e.scale && !e.out_f32 && e.ldr % 4 == 0) {
+      const bool ac = e.accumulate != 0;
+      if (e.res && !ac) {
+        if (act == USSEG_ACT_NONE) epi_fast<NA, NT, true, false>(e, c, acc, opix, ovalid, nbase, ybatch, a_none);
+        else if (act == USSEG_ACT_LRELU) epi_fast<NA, NT, true, false>(e, c, acc, opix, ovalid, nbase, ybatch, a_lrelu);
+        else epi_fast<NA, NT, true, false>(e, c, acc, opix, ovalid, nbase, ybatch, a_any);
+        return;
+      }
+      if (!e.res && ac) {
+        if (act == USSEG_ACT_NONE) epi_fast<NA, NT, false, true>(e, c, acc, opix, ovalid, nbase, ybatch, a_none);
+        else epi_fast<NA, NT, false, true>(e, c, acc, opix, ovalid, nbase, ybatch, a_any);
+        return;
+      }
+    }
   }
   const bool acc_bf = e.accumulate && !e.out_f32;
 #pragma unroll

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloMulti P) {
 // kernel a 128-pixel workgroup of the 32->32 stem conv moves 18 KB of weights for 11 KB of activations.)
 // `gpb` consecutive pixel groups per workgroup; their patch geometry is decoded once into LDS.
 template <int NT>
-__global__ __launch_bounds__(256, NT <= 2 ? 4 : 2) void conv_halo_persist_kernel(const HaloMulti P, const int gpb) {
+__global__ __launch_bounds__(256, NT <= 1 ? 4 : (NT == 2 ? 3 : 2)) void conv_halo_persist_kernel(const HaloMulti P, const int gpb) {
   const HaloParams& p = P.job[blockIdx.z];
   constexpr int BN = 16 * NT, LDSS = 40, MAXHP = 288, MAXG = 16;
   constexpr int A_IT = (MAXHP * 4 + 255) / 256;
