@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
         for (int i = 0; i < WM; ++i) {
           bf16x8_t af = tr8(lds_x, xb[ks][0] + toff + 16 * i, xb[ks][1] + toff + 16 * i);
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[tt][i][j], 0, 0, 0);
+          for (int j = 0; j < WN; ++j) acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[tt][i][j], 0, 0, 0);   // D^T: lane holds 4 consecutive n
         }
       }
     }
@@ -221,9 +221,12 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     }
   }
 
-  // D[row = m_local = 4g + r][col = n_local = li].  With a partials workspace every split stores its own
-  // [9][Ma][Nb] slab with plain stores (summed by wgrad_finish_kernel); without one it falls back to atomics.
+  // The MFMA runs with dy as its row operand, so a lane holds D[n_local = 4g + r][m_local = li]: four consecutive output
+  // channels of one input channel = one 16-byte store into the [9][Ma][Nb] slab (80 -> 20 store instructions per lane for
+  // the 64x64 tile).  With a partials workspace every split stores its own slab with plain stores (summed by
+  // wgrad_finish_kernel); without one it falls back to atomics.
   float* dst = p.ws ? p.ws + (int64_t)blockIdx.x * 9 * p.Ma * p.Nb : p.out;
+  const bool vec_ok = (p.Nb & 3) == 0;
 #pragma unroll
   for (int tt = 0; tt < TPG; ++tt)
 #pragma unroll
@@ -232,16 +235,19 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       for (int j = 0; j < WN; ++j) {
         const int t = t0 + tt;
         if (NTG > 1 && t >= 9) continue;
-        int n = n0 + wn * 16 * WN + j * 16 + li;
-        if (n >= p.Nb) continue;
+        const int m = m0 + wm * 16 * WM + i * 16 + li;
+        const int n = n0 + wn * 16 * WN + j * 16 + g * 4;
+        if (m >= p.Ma || n >= p.Nb) continue;
+        float* q = dst + ((int64_t)t * p.Ma + m) * p.Nb + n;
+        if (p.ws && vec_ok && n + 3 < p.Nb) {
+          *reinterpret_cast<float4*>(q) = make_float4(acc[tt][i][j][0], acc[tt][i][j][1], acc[tt][i][j][2], acc[tt][i][j][3]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int m = m0 + wm * 16 * WM + i * 16 + g * 4 + r;
-          if (m < p.Ma) {
-            float* q = dst + ((int64_t)t * p.Ma + m) * p.Nb + n;
-            if (p.ws) *q = acc[tt][i][j][r];
-            else atomicAdd(q, acc[tt][i][j][r]);
-          }
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.Nb) {
+              if (p.ws) q[r] = acc[tt][i][j][r];
+              else atomicAdd(q + r, acc[tt][i][j][r]);
+            }
         }
       }
 }
