@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
   constexpr int X_IT = (MAXHP * XCH + NTHR - 1) / NTHR, Y_IT = (128 * YCH + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) bf16_t lds_x[MAXHP * XS];
   __shared__ __attribute__((aligned(16))) bf16_t lds_y[128 * YS];
-  __shared__ int s_patch[8][8];  // per patch: b, la, lb, ly0, lx0, valid
+  __shared__ __attribute__((aligned(16))) int s_patch[8][8];  // per patch: x origin, dy origin, ly0 - 1, lx0 - 1, valid
 
   const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, tg = tid >> 8;   // tile wave, tap group
   const int t0 = tg * TPG;
@@ -80,6 +80,20 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
   }
   const int xq = tid % XCH, yq = tid % YCH;  // NTHR % XCH == 0 and NTHR % YCH == 0, so the chunk column is fixed
   const bool x_cok = (m0 + xq * 8) < p.Ma, y_cok = (n0 + yq * 8) < p.Nb;
+  // element offsets of each item relative to its patch origin (the per-group part comes from the patch table): the loads
+  // are then branch-free - one 16-byte table read, an add, a clamped unconditional load and a mask.  (The version that
+  // decoded the patch and tested the bounds under per-item branches spent ~430 cycles per item, more than the MFMAs.)
+  int x_rel[X_IT], y_rel[Y_IT];
+#pragma unroll
+  for (int it = 0; it < X_IT; ++it) {
+    const int hy = (x_geo[it] >> 8) & 255, hx = x_geo[it] & 255;
+    x_rel[it] = (p.d * hy * p.W + p.d * hx) * p.ldx + m0 + xq * 8;
+  }
+#pragma unroll
+  for (int it = 0; it < Y_IT; ++it) {
+    const int row = (y_geo[it] >> 8) & 255, col = y_geo[it] & 255;
+    y_rel[it] = (p.d * row * p.W + p.d * col) * p.lddy + n0 + yq * 8;
+  }
 
   // ---- fragment addressing (fixed): 16-lane group g covers K rows (pixels) 8g..8g+7 of each 32-pixel step
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
@@ -126,29 +140,30 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
       int dd = p.d * p.d;
       int b = v / dd, ab = v - b * dd;
-      tab[tid][0] = b; tab[tid][1] = ab / p.d; tab[tid][2] = ab - (ab / p.d) * p.d;
-      tab[tid][3] = ty * p.PH; tab[tid][4] = tx * p.PW; tab[tid][5] = valid;
+      const int la = ab / p.d, lb = ab - la * p.d, ly0 = ty * p.PH, lx0 = tx * p.PW;
+      // [0] x offset of halo pixel (0,0) (may be "negative": only in-image items use it), [1] dy offset of patch pixel (0,0),
+      // [2] ly0 - 1 (far out of range for an invalid patch: every bounds test then fails), [3] lx0 - 1, [4] valid
+      tab[tid][0] = (int)(((int64_t)(b * p.H + la + p.d * (ly0 - 1)) * p.W + lb + p.d * (lx0 - 1)) * p.ldx);
+      tab[tid][1] = (int)(((int64_t)(b * p.H + la + p.d * ly0) * p.W + lb + p.d * lx0) * p.lddy);
+      tab[tid][2] = valid ? ly0 - 1 : -(1 << 24);
+      tab[tid][3] = lx0 - 1;
+      tab[tid][4] = valid;
     }
   };
   auto load_x = [&](int it, int (*tab)[8]) -> uint4 {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (x_geo[it] < 0) return v;
-    const int* pt = tab[x_geo[it] >> 16];
-    int ly = pt[3] + ((x_geo[it] >> 8) & 255) - 1, lx = pt[4] + (x_geo[it] & 255) - 1;
-    if (x_cok && pt[5] && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl) {
-      int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * ly) * p.W + pt[2] + p.d * lx;
-      v = *reinterpret_cast<const uint4*>(p.x + pix * p.ldx + m0 + xq * 8);
-    }
+    const int geo = x_geo[it] < 0 ? 0 : x_geo[it];
+    const int4 e = *reinterpret_cast<const int4*>(tab[geo >> 16]);
+    const int ly = e.z + ((geo >> 8) & 255), lx = e.w + (geo & 255);
+    const bool ok = x_geo[it] >= 0 && x_cok && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl;
+    uint4 v = *reinterpret_cast<const uint4*>(p.x + (ok ? e.x + x_rel[it] : 0));
+    if (!ok) v = make_uint4(0, 0, 0, 0);
     return v;
   };
   auto load_y = [&](int it, int (*tab)[8]) -> uint4 {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (tid + NTHR * it >= 128 * YCH) return v;
     const int* pt = tab[y_geo[it] >> 16];
-    if (y_cok && pt[5]) {
-      int64_t pix = ((int64_t)pt[0] * p.H + pt[1] + p.d * (pt[3] + ((y_geo[it] >> 8) & 255))) * p.W + pt[2] + p.d * (pt[4] + (y_geo[it] & 255));
-      v = *reinterpret_cast<const uint4*>(p.dy + pix * p.lddy + n0 + yq * 8);
-    }
+    const bool ok = (tid + NTHR * it < 128 * YCH) && y_cok && pt[4];
+    uint4 v = *reinterpret_cast<const uint4*>(p.dy + (ok ? pt[1] + y_rel[it] : 0));
+    if (!ok) v = make_uint4(0, 0, 0, 0);
     return v;
   };
   const uint32_t tmask = p.mask_ch ? p.tapmask[n0 / p.mask_ch] : 0x1ffu;   // workgroup-uniform
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       compute();
     }
   } else {
-    __shared__ int s_patch2[8][8];
+    __shared__ __attribute__((aligned(16))) int s_patch2[8][8];
     uint4 rx[X_IT], ry[Y_IT];
     if (g_begin < g_end) {
       patch_fill(g_begin, s_patch);
@@ -290,6 +305,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     p.ngroups = (p.npatches + NV - 1) / NV;
     p.ldx = q.ldx; p.lddy = q.lddy; p.Ma = Ma; p.Nb = Nb;
     if (p.ngroups != P.job[0].ngroups) return 0;
+    if ((int64_t)q.B * q.H * q.W * q.ldx >= (1ll << 31) || (int64_t)q.B * q.H * q.W * q.lddy >= (1ll << 31)) return 0;   // 32-bit element offsets
   }
   if (ws) ws = usseg_defer_wgrad_ws(s, ws, ws_floats, &ws_floats);   // deferred finishing: a private region of the step's workspace
   // tile shape by channel counts: 64x64, 32x32 (both small), 64x16 / 64x32 (few output channels, e.g. the decoder branches)
