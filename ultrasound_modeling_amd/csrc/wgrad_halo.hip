@@ -34,14 +34,17 @@ struct WgHaloMulti {
 // have the registers for it; without it a group is a serial load -> LDS -> barrier -> MFMA chain of ~4 us).
 // NTG: tap groups.  NTG = 2 runs 8 waves: waves 0-3 accumulate taps 0-4, waves 4-7 taps 5-8 of the SAME LDS tiles, which
 // halves the accumulator registers per wave (144 -> 80 for the 64x64 tile) and makes room for the prefetch registers.
-template <int WVM, int WM, int WN, bool PF, int NTG>
+template <int WVM, int WM, int WN, bool PF, int NTG, bool MASKED>
 __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel(const WgHaloMulti P) {
   constexpr int NTHR = 256 * NTG, TPG = NTG == 1 ? 9 : 5;   // threads, taps per group
   const WgHaloParams& p = P.job[blockIdx.z];
   constexpr int MAXHP = 288;
   constexpr int WVN = 4 / WVM;
   constexpr int BMc = 16 * WM * WVM, BNc = 16 * WN * WVN;      // channels per workgroup tile
-  constexpr int XS = BMc + 8, YS = BNc + 8;        // LDS row strides (elements): +16 B pad
+  // LDS row strides (elements).  A transposed fragment read covers 16 consecutive pixel rows x 32 B, 8 rows per 32-lane
+  // pass: with a stride of 16 (mod 32) elements the 8 rows start at 8 distinct multiples of 8 banks - conflict-free
+  // (the +8 padding this started with was 2-way conflicted for every row mapping).
+  constexpr int XS = BMc + 16, YS = BNc == 16 ? 48 : BNc + 16;
   constexpr int XCH = BMc / 8, YCH = BNc / 8;      // 16-byte chunks per pixel row
   constexpr int X_IT = (MAXHP * XCH + NTHR - 1) / NTHR, Y_IT = (128 * YCH + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) bf16_t lds_x[MAXHP * XS];
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     y_rel[it] = (p.d * row * p.W + p.d * col) * p.lddy + n0 + yq * 8;
   }
 
-  // ---- fragment addressing (fixed): 16-lane group g covers K rows (pixels) 8g..8g+7 of each 32-pixel step
+  // ---- fragment addressing (fixed): K index 8g + 4h + tq of a 32-pixel step is pixel 16h + 4g + tq (same permutation for x and dy)
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   const int wm = wv / WVN, wn = wv % WVN;
   int xb[4][2], yb[4][2];
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int pk = 32 * ks + 8 * g + 4 * h + tq;
+      int pk = 32 * ks + 16 * h + 4 * g + tq;   // one read (fixed h) = one 16-pixel strip
       int s = pk >> 4, pl = pk & 15;
       int pi = s / spp, sl = s - pi * spp;
       int r = pl / p.PW, c = pl - r * p.PW;
@@ -166,26 +169,52 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     if (!ok) v = make_uint4(0, 0, 0, 0);
     return v;
   };
-  const uint32_t tmask = p.mask_ch ? p.tapmask[n0 / p.mask_ch] : 0x1ffu;   // workgroup-uniform
+  const uint32_t tmask = (MASKED && p.mask_ch) ? p.tapmask[n0 / p.mask_ch] : 0x1ffu;   // workgroup-uniform
+  // LDS offset of each of this wave's taps (uniform values): no tap arithmetic, and - without the mask, which is its own
+  // instantiation - no branch inside the tap loop except in front of the second tap group's absent fifth tap, so the
+  // compiler can hoist a tap's fragment reads above the previous tap's MFMAs (with a branch per tap every tap paid the
+  // LDS latency: 4 reads -> wait -> 4 MFMAs, 3.4x the MFMA time).
+  int toff_t[TPG];
+#pragma unroll
+  for (int tt = 0; tt < TPG; ++tt) {
+    const int t = (t0 + tt) < 9 ? (t0 + tt) : 8;
+    toff_t[tt] = __builtin_amdgcn_readfirstlane(((t / 3) * HW2 + (t % 3)) * XS);
+  }
+  const bool last_ok = __builtin_amdgcn_readfirstlane(t0 + TPG - 1) < 9;
+  // Software-pipelined by hand over the 4 x TPG (K step, tap) stages: the fragment reads of stage s+1 are issued before the
+  // MFMAs of stage s and pinned there with scheduling barriers (left to itself the compiler emits, per tap, 4 reads -> wait
+  // -> 4 MFMAs, and every tap pays the LDS latency).
   auto compute = [&]() {
+    bf16x8_t af[2][WM], bfr[2][WN];
+    auto load_b = [&](int ks, bf16x8_t (&b)[WN]) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8_t bfr[WN];
+      for (int j = 0; j < WN; ++j) b[j] = tr8(lds_y, yb[ks][0] + 16 * j, yb[ks][1] + 16 * j);
+    };
+    auto load_a = [&](int ks, int tt, bf16x8_t (&a)[WM]) {
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bfr[j] = tr8(lds_y, yb[ks][0] + 16 * j, yb[ks][1] + 16 * j);
+      for (int i = 0; i < WM; ++i) a[i] = tr8(lds_x, xb[ks][0] + toff_t[tt] + 16 * i, xb[ks][1] + toff_t[tt] + 16 * i);
+    };
+    load_b(0, bfr[0]);
+    load_a(0, 0, af[0]);
 #pragma unroll
-      for (int tt = 0; tt < TPG; ++tt) {
-        const int t = t0 + tt;
-        if (NTG > 1 && t >= 9) break;        // the second tap group has four taps
-        if (!((tmask >> t) & 1u)) continue;  // masked taps keep a zero accumulator (their slab entries are written as zeros)
-        const int toff = ((t / 3) * HW2 + (t % 3)) * XS;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          bf16x8_t af = tr8(lds_x, xb[ks][0] + toff + 16 * i, xb[ks][1] + toff + 16 * i);
-#pragma unroll
-          for (int j = 0; j < WN; ++j) acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[tt][i][j], 0, 0, 0);   // D^T: lane holds 4 consecutive n
-        }
+    for (int st = 0; st < 4 * TPG; ++st) {
+      const int ks = st / TPG, tt = st - ks * TPG;
+      if (st + 1 < 4 * TPG) {
+        const int ks1 = (st + 1) / TPG, tt1 = (st + 1) - ks1 * TPG;
+        if (tt1 == 0) load_b(ks1, bfr[ks1 & 1]);
+        load_a(ks1, tt1, af[(st + 1) & 1]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool skip = (NTG > 1 && tt == TPG - 1 && !last_ok) ||      // the second tap group has four taps
+                        (MASKED && !((tmask >> (t0 + tt)) & 1u));        // masked taps keep a zero accumulator
+      if (!skip) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks & 1][j], af[st & 1][i], acc[tt][i][j], 0, 0, 0);   // D^T: lane holds 4 consecutive n
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -349,6 +378,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     P.job[j].groups_per_block = gpb;
     P.job[j].ws = use_ws ? ws + (int64_t)j * splits * slab : nullptr;
   }
+  const bool masked = usseg_tap_mask.group_ch != 0;
   if (usseg_tap_mask.group_ch) {
     if (njobs != 1 || usseg_tap_mask.group_ch % bn) return 0;      // an output-channel tile must lie inside one class
     P.job[0].mask_ch = usseg_tap_mask.group_ch;
@@ -358,18 +388,18 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   const int slot = usseg_prof_start(2, s);
   static const int pf = getenv("USSEG_WGRAD_PF") ? atoi(getenv("USSEG_WGRAD_PF")) : 1;
   if (shape == 1) {
-    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, true, 1>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, false, 1>), grid, dim3(256), 0, s, P);
+    if (pf) { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, true, 1, true>), grid, dim3(256), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, true, 1, false>), grid, dim3(256), 0, s, P); }
+    else { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, false, 1, true>), grid, dim3(256), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<2, 1, 1, false, 1, false>), grid, dim3(256), 0, s, P); }
   } else if (shape == 2) {
-    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, true, 1>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, false, 1>), grid, dim3(256), 0, s, P);
+    if (pf) { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, true, 1, true>), grid, dim3(256), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, true, 1, false>), grid, dim3(256), 0, s, P); }
+    else { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, false, 1, true>), grid, dim3(256), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 1, false, 1, false>), grid, dim3(256), 0, s, P); }
   } else if (shape == 3) {
-    if (pf) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, true, 1>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, false, 1>), grid, dim3(256), 0, s, P);
+    if (pf) { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, true, 1, true>), grid, dim3(256), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, true, 1, false>), grid, dim3(256), 0, s, P); }
+    else { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, false, 1, true>), grid, dim3(256), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<4, 1, 2, false, 1, false>), grid, dim3(256), 0, s, P); }
   } else {
     static const int tg8 = getenv("USSEG_WGRAD_8W") ? atoi(getenv("USSEG_WGRAD_8W")) : 1;
-    if (tg8) hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, true, 2>), grid, dim3(512), 0, s, P);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, false, 1>), grid, dim3(256), 0, s, P);
+    if (tg8) { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, true, 2, true>), grid, dim3(512), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, true, 2, false>), grid, dim3(512), 0, s, P); }
+    else { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, false, 1, true>), grid, dim3(256), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, false, 1, false>), grid, dim3(256), 0, s, P); }
   }
   if (use_ws)
     for (int j = 0; j < njobs; ++j) usseg_launch_wgrad_finish(P.job[j].ws, splits, slab, gm[j].out, gm[j].map, Ma, Nb, s);
