@@ -202,6 +202,169 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase, ybatch);
 }
 
+// ---- LDS-DMA variant (plain mode: no parity classes, no batching) -------------------------------------------------------
+// Same tiling and tap tables, but the operand pieces go global -> LDS directly (buffer_load ... lds: no staging registers,
+// no ds_write pass, out-of-image / out-of-range pieces are zero-filled by the buffer range check) into a ring of NSTAGE
+// stages, so the pieces of K step ks+NSTAGE-1 are in flight under the MFMAs of step ks, and the only wait of a step is
+// `vmcnt(pieces of the younger steps)`.  The register-staged kernel keeps one step in flight and then waits for it
+// (measured on the fused branch backward-data: 1.5k cycles issuing + 0.7k waiting per step around 0.6k of MFMA).
+// LDS image of a stage: [128 + max(BN,32) rows][8 chunks of 16 B], dense 128-B rows; slot j of row R holds chunk
+// j ^ ((R >> 1) & 7): a fragment read (16 consecutive rows, one chunk) then touches every bank exactly once, and a DMA
+// wave-instruction (8 rows x 8 slots, lane -> row lane/8, slot lane%8) keeps a fixed chunk per lane.
+typedef __attribute__((address_space(3))) void* igemm_lds_ptr_t;
+#define IGEMM_OOB 0x80000000u
+
+template <int NT, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 16 * NT, BNP = BN < 32 ? 32 : BN;   // weight rows padded so every wave issues W_IT pieces
+  constexpr int STAGE = (BM + BNP) * 128;                           // bytes
+  constexpr int A_IT = BM / 32, W_IT = BNP / 32;                    // 8-row pieces per wave per step
+  constexpr int NI = A_IT + W_IT;                                   // DMA instructions per wave per step
+  constexpr int D = NSTAGE - 1;                                     // prefetch distance
+  extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+  __shared__ int s_tap[128];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 32) {
+    s_tap[tid] = p.tap_dy[tid];
+    s_tap[32 + tid] = p.tap_dx[tid];
+    s_tap[64 + tid] = p.tap_w[tid];
+    s_tap[96 + tid] = p.tap_c[tid];
+  }
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int HWg = p.Hg * p.Wg;
+  const int ntaps = p.ntaps;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
+
+  // ---- this lane's pieces: row (lane / 8) of piece wv + 4*it, chunk column q (fixed: see the layout note)
+  const int lrow = lane >> 3;
+  const int q = (lane & 7) ^ (((lane >> 4) + 4 * (wv & 1)) & 7);
+  int abase[A_IT], py[A_IT], px[A_IT];
+  bool pv[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int64_t m = m0 + 8 * (wv + 4 * it) + lrow;
+    pv[it] = m < p.M;
+    const int mm = pv[it] ? (int)m : 0;
+    const int b = mm / HWg, rem = mm - b * HWg;
+    const int gy = rem / p.Wg, gx = rem - gy * p.Wg;
+    py[it] = gy * p.isy;
+    px[it] = gx * p.isx;
+    abase[it] = ((b * p.Hi + py[it]) * p.Wi + px[it]) * p.ldx;
+  }
+  int wrow[W_IT];
+  bool wok[W_IT];
+#pragma unroll
+  for (int it = 0; it < W_IT; ++it) {
+    const int n = 8 * (wv + 4 * it) + lrow;
+    wok[it] = n < BN && (n0 + n) < p.Nw;
+    wrow[it] = wok[it] ? (n0 + n) * p.Kw : 0;
+  }
+  int ti = q / p.cpt;
+  int c8 = q - ti * p.cpt;
+  const int nks = (ntaps * p.cpt + 7) / 8;
+  const int Cin = p.cpt * 8;
+  __syncthreads();  // tap table visible
+
+  auto issue = [&](int stage) {
+    char* const sb = lds_raw + stage * STAGE;
+    const bool tv = ti < ntaps;
+    const int tis = tv ? ti : 0;
+    const int dy = s_tap[tis], dx = s_tap[32 + tis], tw = s_tap[64 + tis], tc = s_tap[96 + tis];
+    const int da = (dy * p.Wi + dx) * p.ldx + tc + c8 * 8;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int iy = py[it] + dy, ix = px[it] + dx;
+      const bool ok = tv && pv[it] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (igemm_lds_ptr_t)(sb + (wv + 4 * it) * 1024), 16, ok ? (uint32_t)(abase[it] + da) * 2u : IGEMM_OOB, 0, 0, 0);
+    }
+    const int dw = tw * Cin + c8 * 8;
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const bool ok = tv && wok[it];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (igemm_lds_ptr_t)(sb + BM * 128 + (wv + 4 * it) * 1024), 16, ok ? (uint32_t)(wrow[it] + dw) * 2u : IGEMM_OOB, 0, 0, 0);
+    }
+    c8 += 8;
+    while (c8 >= p.cpt) { c8 -= p.cpt; ++ti; }
+  };
+
+  f32x4_t acc[2][NT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, g = lane >> 4;
+  int a_off[2], w_off[NT];   // byte offset of this lane's fragment row; its swizzle key is (row >> 1) & 7
+#pragma unroll
+  for (int a = 0; a < 2; ++a) a_off[a] = (wv * 32 + a * 16 + frow) * 128;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) w_off[b] = (BM + b * 16 + frow) * 128;
+  const int key = (frow >> 1) & 7;   // all fragment rows are frow + a multiple of 16: the same key
+
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nks) issue(s);
+  for (int ks = 0; ks < nks; ++ks) {
+    // step ks has landed once at most the pieces of the younger steps are outstanding (vmcnt retires in issue order);
+    // bare s_barrier: __syncthreads() would prepend a vmcnt(0)
+    if (D >= 2 && ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // everyone is also done reading stage (ks-1) % NSTAGE, which the next issue overwrites
+    if (ks + D < nks) issue((ks + D) % NSTAGE);
+    const char* const L = lds_raw + (ks % NSTAGE) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int sl = ((4 * kk + g) ^ key) << 4;
+      bf16x8_t xf[2], wf[NT];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) xf[a] = *reinterpret_cast<const bf16x8_t*>(L + a_off[a] + sl);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8_t*>(L + w_off[b] + sl);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  int64_t opix[2];
+  bool ovalid[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    int64_t m = m0 + wv * 32 + a * 16 + frow;
+    ovalid[a] = m < p.M;
+    int mm = ovalid[a] ? (int)m : 0;
+    int b = mm / HWg;
+    int rem = mm - b * HWg;
+    int gy = rem / p.Wg;
+    int gx = rem - gy * p.Wg;
+    opix[a] = ((int64_t)(b * p.Ho + gy * p.osy + p.oay)) * p.Wo + gx * p.osx + p.oax;
+  }
+  const EpiArgs e = {p.scale, p.bias, p.res, p.y, p.ldy, p.ldr, p.Nout, p.act, p.alpha, p.out_f32, p.accumulate};
+  const int nbase = n0 + g * 4;
+  EpiConst<NT> ec;
+  epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
+  conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase, 0);
+#endif
+}
+
+template <int NT, int NSTAGE>
+static void igemm_dma_launch_t(const IgemmParams& p, dim3 grid, hipStream_t s) {
+  constexpr int BNP = 16 * NT < 32 ? 32 : 16 * NT;
+  const size_t dyn = (size_t)NSTAGE * (128 + BNP) * 128;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)igemm_dma_kernel<NT, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((igemm_dma_kernel<NT, NSTAGE>), grid, dim3(256), dyn, s, p);
+}
+
 static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   if (p.M <= 0) return USSEG_OK;
   dim3 block(256);
@@ -219,6 +382,19 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   const int kc = kc_env ? kc_env : (p.ntaps * p.cpt >= 16 ? 8 : 4);
   const dim3 grid((unsigned)gx, gy, gz);
   const int slot = usseg_prof_start(1, s);
+  {   // plain mode with a K loop worth a stage ring: the LDS-DMA variant
+    static const int dma = getenv("USSEG_IGEMM_DMA") ? atoi(getenv("USSEG_IGEMM_DMA")) : 1;
+    const int64_t nb = cdiv64(p.M, (int64_t)p.Hg * p.Wg);
+    const bool fits = nb * p.Hi * p.Wi * p.ldx * 2 < 0x7fff0000ll && (int64_t)p.Nw * p.Kw * 2 < 0x7fff0000ll;
+    if (dma && !p.cls_mode && p.nb2 <= 0 && kc == 8 && fits) {
+      if (nt == 1) igemm_dma_launch_t<1, 3>(p, grid, s);
+      else if (nt == 2) igemm_dma_launch_t<2, 3>(p, grid, s);
+      else if (nt == 4) igemm_dma_launch_t<4, 3>(p, grid, s);
+      else igemm_dma_launch_t<8, 2>(p, grid, s);
+      usseg_prof_stop(1, slot, s);
+      return usseg_check_launch("igemm_dma");
+    }
+  }
 #define USSEG_IGEMM_LAUNCH(NT_, KC_)                                                                                         \
   do {                                                                                                                         \
     const size_t dyn = (size_t)2 * (128 + 16 * NT_) * (KC_ * 8 + 8) * sizeof(bf16_t) + 128 * sizeof(int);                      \
