@@ -127,6 +127,56 @@ __device__ __forceinline__ void epi_fast(const EpiArgs& e, const EpiConst<NT>& c
   }
 }
 
+// Plain bf16 epilogue through LDS: the MFMA layout gives a lane 4 channels (8 B) of one pixel, so a direct store touches
+// 16 pixel rows x 32 B per instruction - sixteen partial cache lines, and the write path serialises on them (measured ~450
+// cycles per store instruction on a 128-channel output).  Here each wave transposes its [16*NA pixels][16*NT channels] tile
+// through a private LDS slice and stores 16 B per lane with a pixel's channels in consecutive lanes: whole 128-byte lines,
+// half the instructions.  `wl`: this wave's slice, epi_lds_bytes<NA,NT>() bytes, free of other users.
+template <int NA, int NT>
+__host__ __device__ constexpr int epi_lds_bytes() { return 16 * NA * (16 * NT * 2 + 16) + 16 * NA * 4; }
+template <int NA, int NT, typename ActF>
+__device__ __forceinline__ void epi_lds_body(char* wl, const EpiArgs& e, const EpiConst<NT>& c, const f32x4_t (&acc)[NA][NT], const int64_t (&opix)[NA],
+                                             const bool (&ovalid)[NA], int n0, int lane, int64_t ybatch, ActF actf) {
+  constexpr int BN = 16 * NT, RB = BN * 2 + 16, NP = 16 * NA, CH = BN / 8, PPI = 64 / CH;
+  int* const pixtab = reinterpret_cast<int*>(wl + NP * RB);
+  const int frow = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+#pragma unroll
+    for (int bt = 0; bt < NT; ++bt) {
+      uint2 o;
+      o.x = pack2bf(actf(acc[a][bt][0] + c.bb[bt].x), actf(acc[a][bt][1] + c.bb[bt].y));
+      o.y = pack2bf(actf(acc[a][bt][2] + c.bb[bt].z), actf(acc[a][bt][3] + c.bb[bt].w));
+      *reinterpret_cast<uint2*>(wl + (a * 16 + frow) * RB + (bt * 16 + 4 * g) * 2) = o;
+    }
+    if (g == 0) pixtab[a * 16 + frow] = ovalid[a] ? (int)opix[a] : -1;
+  }
+  // same wave, in-order LDS queue: the reads below see the writes above
+  const int ch = lane % CH, pl = lane / CH;
+  const int n = n0 + ch * 8;
+  bf16_t* const ybase = reinterpret_cast<bf16_t*>(e.y) + ybatch + n;
+#pragma unroll
+  for (int i = 0; i < NP / PPI; ++i) {
+    const int P = i * PPI + pl;
+    const int pix = pixtab[P];
+    const uint4 v = *reinterpret_cast<const uint4*>(wl + P * RB + ch * 16);
+    if (pix >= 0 && n < e.Nout) *reinterpret_cast<uint4*>(ybase + (int64_t)pix * e.ldy) = v;
+  }
+}
+// true if it took the tile (plain bf16 output, 16-byte aligned rows); false: the caller runs conv_epilogue
+template <int NA, int NT>
+__device__ __forceinline__ bool conv_epilogue_lds(char* wl, const EpiArgs& e, const EpiConst<NT>& c, const f32x4_t (&acc)[NA][NT],
+                                                  const int64_t (&opix)[NA], const bool (&ovalid)[NA], int n0, int lane, int64_t ybatch = 0) {
+  if (e.scale || e.out_f32 || e.res || e.accumulate || (e.ldy & 7) || (ybatch & 7)) return false;
+  const float alpha = e.alpha;
+  const int act = e.act;
+  if (act == USSEG_ACT_NONE) epi_lds_body<NA, NT>(wl, e, c, acc, opix, ovalid, n0, lane, ybatch, [](float v) { return v; });
+  else if (act == USSEG_ACT_LRELU) epi_lds_body<NA, NT>(wl, e, c, acc, opix, ovalid, n0, lane, ybatch, [alpha](float v) { return v >= 0.f ? v : alpha * v; });
+  else if (act == USSEG_ACT_RELU) epi_lds_body<NA, NT>(wl, e, c, acc, opix, ovalid, n0, lane, ybatch, [](float v) { return v > 0.f ? v : 0.f; });
+  else epi_lds_body<NA, NT>(wl, e, c, acc, opix, ovalid, n0, lane, ybatch, [act, alpha](float v) { return apply_act(v, act, alpha); });
+  return true;
+}
+
 // SIMPLE: the caller guarantees no scale / residual / accumulate / fp32 output (the streaming kernel's per-step epilogue must
 // not contain even untaken load paths: the compiler's waits for them would drain the prefetch DMA).
 template <int NA, int NT, bool SIMPLE = false>

@@ -349,7 +349,10 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   const int nbase = n0 + g * 4;
   EpiConst<NT> ec;
   epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
-  conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase, 0);
+  static_assert(4 * epi_lds_bytes<2, NT>() <= NSTAGE * STAGE, "the transposing epilogue reuses the stage ring");
+  __syncthreads();   // every wave is done with the last stage
+  if (!conv_epilogue_lds<2, NT>(lds_raw + wv * epi_lds_bytes<2, NT>(), e, ec, acc, opix, ovalid, n0, lane))
+    conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase, 0);
 #endif
 }
 
