@@ -153,21 +153,42 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       tab[tid][4] = valid;
     }
   };
-  auto load_x = [&](int it, int (*tab)[8]) -> uint4 {
-    const int geo = x_geo[it] < 0 ? 0 : x_geo[it];
-    const int4 e = *reinterpret_cast<const int4*>(tab[geo >> 16]);
-    const int ly = e.z + ((geo >> 8) & 255), lx = e.w + (geo & 255);
-    const bool ok = x_geo[it] >= 0 && x_cok && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl;
-    uint4 v = *reinterpret_cast<const uint4*>(p.x + (ok ? e.x + x_rel[it] : 0));
-    if (!ok) v = make_uint4(0, 0, 0, 0);
-    return v;
-  };
-  auto load_y = [&](int it, int (*tab)[8]) -> uint4 {
-    const int* pt = tab[y_geo[it] >> 16];
-    const bool ok = (tid + NTHR * it < 128 * YCH) && y_cok && pt[4];
-    uint4 v = *reinterpret_cast<const uint4*>(p.dy + (ok ? pt[1] + y_rel[it] : 0));
-    if (!ok) v = make_uint4(0, 0, 0, 0);
-    return v;
+  // two passes so that the table reads of every item are in flight together, then the global loads back to back
+  auto load_xy = [&](int (*tab)[8], uint4 (&rx)[X_IT], uint4 (&ry)[Y_IT]) {
+    int4 ex[X_IT];
+    int yorg[Y_IT], yval[Y_IT];
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int geo = x_geo[it] < 0 ? 0 : x_geo[it];
+      ex[it] = *reinterpret_cast<const int4*>(tab[geo >> 16]);
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int* pt = tab[y_geo[it] >> 16];
+      yorg[it] = pt[1];
+      yval[it] = pt[4];
+    }
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) asm volatile("" : "+v"(ex[it].x), "+v"(ex[it].z), "+v"(ex[it].w));   // pin the reads above the loads
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) asm volatile("" : "+v"(yorg[it]), "+v"(yval[it]));
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int geo = x_geo[it] < 0 ? 0 : x_geo[it];
+      const int ly = ex[it].z + ((geo >> 8) & 255), lx = ex[it].w + (geo & 255);
+      // bitwise &: with && the compiler evaluates lazily and puts a branch per condition back
+      const bool ok = (x_geo[it] >= 0) & x_cok & ((unsigned)ly < (unsigned)p.Hl) & ((unsigned)lx < (unsigned)p.Wl);
+      uint4 v = *reinterpret_cast<const uint4*>(p.x + (ok ? ex[it].x + x_rel[it] : 0));
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      rx[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const bool ok = (tid + NTHR * it < 128 * YCH) & y_cok & (yval[it] != 0);
+      uint4 v = *reinterpret_cast<const uint4*>(p.dy + (ok ? yorg[it] + y_rel[it] : 0));
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      ry[it] = v;
+    }
   };
   const uint32_t tmask = (MASKED && p.mask_ch) ? p.tapmask[n0 / p.mask_ch] : 0x1ffu;   // workgroup-uniform
   // LDS offset of each of this wave's taps (uniform values): no tap arithmetic, and - without the mask, which is its own
@@ -222,12 +243,14 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     for (int grp = g_begin; grp < g_end; ++grp) {
       patch_fill(grp, s_patch);
       __syncthreads();  // patch table ready; also: previous iteration's LDS reads are done
+      uint4 rx[X_IT], ry[Y_IT];
+      load_xy(s_patch, rx, ry);
 #pragma unroll
       for (int it = 0; it < X_IT; ++it)
-        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = load_x(it, s_patch);
+        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = rx[it];
 #pragma unroll
       for (int it = 0; it < Y_IT; ++it)
-        if (tid + NTHR * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = load_y(it, s_patch);
+        if (tid + NTHR * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = ry[it];
       __syncthreads();
       compute();
     }
@@ -237,10 +260,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     if (g_begin < g_end) {
       patch_fill(g_begin, s_patch);
       __syncthreads();
-#pragma unroll
-      for (int it = 0; it < X_IT; ++it) rx[it] = load_x(it, s_patch);
-#pragma unroll
-      for (int it = 0; it < Y_IT; ++it) ry[it] = load_y(it, s_patch);
+      load_xy(s_patch, rx, ry);
     }
     int par = 0;
     for (int grp = g_begin; grp < g_end; ++grp, par ^= 1) {
@@ -255,10 +275,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       if (more) patch_fill(grp + 1, nxt);
       __syncthreads();      // this group's tile and the next group's patch table are visible
       if (more) {
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) rx[it] = load_x(it, nxt);
-#pragma unroll
-        for (int it = 0; it < Y_IT; ++it) ry[it] = load_y(it, nxt);
+        load_xy(nxt, rx, ry);
       }
       compute();
       __syncthreads();      // everyone is done reading the tile before the next stores
