@@ -45,8 +45,10 @@ WGRAD_WS_FLOATS = 64 << 20   # 256 MB of the 288 GB: split-K partial slabs of th
 # most CUs under-occupied at batch 16).  Both streams are captured into the same HIP graph (fork by event, join at the
 # end of the region).  Workspaces are per stream; the tensors a side launch reads are kept alive until the join so the
 # caching allocator cannot hand their memory to a later main-stream tensor.
+# Off by default since the conv / wgrad kernels got ~1.5x faster: the fork/join edges of the captured graph now cost more
+# than the overlap returns (Arch B 4.17 vs 4.23 ms, Arch A 9.47 vs 9.87 ms per step; USSEG_SIDE_STREAM=1 turns it back on).
 class _Side:
-    enabled = os.environ.get("USSEG_SIDE_STREAM", "1") != "0"
+    enabled = os.environ.get("USSEG_SIDE_STREAM", "0") != "0"
     defer = os.environ.get("USSEG_DEFER", "1") != "0"
     depth = 0
     stream = None
