@@ -9,7 +9,7 @@ Weak scaling: the per-GPU batch is fixed, the global batch (which divides the lo
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 Prints ONE JSON line on rank 0 (see the keys below).  Extra objects:
-  roofline     - the dominant kernel family (the gather implicit-GEMM that runs every conv / tconv forward and
+  roofline     - the dominant kernel family (the conv kernels that run every conv / tconv forward and
                  backward-data pass): algorithmic FLOPs of its launches in one step / the summed duration of
                  those launches, measured with HIP events recorded by the library on the launch stream.
   cpu_baseline - the CPU oracle (a PyTorch-CPU fp32 restatement of the reference path; TensorFlow, hence the
@@ -262,8 +262,8 @@ def main():
         fwd_f, ig_f, wg_f = algorithmic_flops(net)
         net._graph, net.grad_sync = net._graph_saved, sync_saved
         achieved = ig_f / (ig_ms * 1e-3) / 1e12
-        roofline = {"kernel": "conv family: conv_big_kernel / conv_halo_kernel / conv_halo_persist_kernel / igemm_kernel (every conv + tconv "
-                              "forward and backward-data launch, single stream)", "bound": "mfma", "achieved": round(achieved, 2),
+        roofline = {"kernel": "conv family: conv_stream_kernel / conv_big_kernel / igemm_dma_kernel / igemm_kernel / conv_halo_kernel (every conv + "
+                              "tconv forward and backward-data launch, single stream)", "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
                     "algorithmic_gflop_per_step": round(ig_f / 1e9, 2), "kernel_ms_per_step": round(ig_ms, 3),

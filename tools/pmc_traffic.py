@@ -17,7 +17,7 @@ def load(path, counter):
 fetch, nf = load(sys.argv[1], "FETCH_SIZE")
 write, nw = load(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3])
-fam = lambda k: k.startswith("igemm_kernel") or k.startswith("conv_halo") or k.startswith("conv_big")
+fam = lambda k: k.startswith("igemm") or k.startswith("conv_halo") or k.startswith("conv_big") or k.startswith("conv_stream")
 out = {"per_gpu_batch": 16, "hw": 256, "steps_profiled": steps, "kernels": {}}
 cb = cl = 0.0
 for k in sorted(set(fetch) | set(write)):
