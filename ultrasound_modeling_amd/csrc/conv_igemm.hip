@@ -223,14 +223,17 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   constexpr int NI = A_IT + W_IT;                                   // DMA instructions per wave per step
   constexpr int D = NSTAGE - 1;                                     // prefetch distance
   extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
-  __shared__ int s_tap[128];
+  // per tap: source pixel shift and the element offsets (activation, weight) its chunks start from - decoded once per
+  // workgroup; a K step then costs one 16-byte table read per lane and no integer multiplies
+  __shared__ __attribute__((aligned(16))) int s_tap4[32][4];   // dy, dx, da, dw
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < 32) {
-    s_tap[tid] = p.tap_dy[tid];
-    s_tap[32 + tid] = p.tap_dx[tid];
-    s_tap[64 + tid] = p.tap_w[tid];
-    s_tap[96 + tid] = p.tap_c[tid];
+    const int dy = p.tap_dy[tid], dx = p.tap_dx[tid];
+    s_tap4[tid][0] = dy;
+    s_tap4[tid][1] = dx;
+    s_tap4[tid][2] = (dy * p.Wi + dx) * p.ldx + p.tap_c[tid];
+    s_tap4[tid][3] = p.tap_w[tid] * p.cpt * 8;
   }
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
@@ -263,32 +266,32 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
     wok[it] = n < BN && (n0 + n) < p.Nw;
     wrow[it] = wok[it] ? (n0 + n) * p.Kw : 0;
   }
-  int ti = q / p.cpt;
-  int c8 = q - ti * p.cpt;
   const int nks = (ntaps * p.cpt + 7) / 8;
-  const int Cin = p.cpt * 8;
+  int ti = q / p.cpt;               // this lane's K chunk of the step being issued: (tap, chunk of it), 8 chunks further per step
+  int c8 = q - ti * p.cpt;
+  const int adv_t = 8 / p.cpt, adv_c = 8 - adv_t * p.cpt;
   __syncthreads();  // tap table visible
 
   auto issue = [&](int stage) {
     char* const sb = lds_raw + stage * STAGE;
     const bool tv = ti < ntaps;
-    const int tis = tv ? ti : 0;
-    const int dy = s_tap[tis], dx = s_tap[32 + tis], tw = s_tap[64 + tis], tc = s_tap[96 + tis];
-    const int da = (dy * p.Wi + dx) * p.ldx + tc + c8 * 8;
+    int4 e = *reinterpret_cast<const int4*>(s_tap4[tv ? ti : 0]);
+    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one table read, here (not sunk under the selects below)
+    const int da = e.z + c8 * 8, dw = e.w + c8 * 8;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      const int iy = py[it] + dy, ix = px[it] + dx;
-      const bool ok = tv && pv[it] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const int iy = py[it] + e.x, ix = px[it] + e.y;
+      const bool ok = tv & pv[it] & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (igemm_lds_ptr_t)(sb + (wv + 4 * it) * 1024), 16, ok ? (uint32_t)(abase[it] + da) * 2u : IGEMM_OOB, 0, 0, 0);
     }
-    const int dw = tw * Cin + c8 * 8;
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
-      const bool ok = tv && wok[it];
+      const bool ok = tv & wok[it];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (igemm_lds_ptr_t)(sb + BM * 128 + (wv + 4 * it) * 1024), 16, ok ? (uint32_t)(wrow[it] + dw) * 2u : IGEMM_OOB, 0, 0, 0);
     }
-    c8 += 8;
-    while (c8 >= p.cpt) { c8 -= p.cpt; ++ti; }
+    ti += adv_t;                    // 8 chunks further, branch-free
+    c8 += adv_c;
+    if (c8 >= p.cpt) { c8 -= p.cpt; ++ti; }
   };
 
   f32x4_t acc[2][NT];
