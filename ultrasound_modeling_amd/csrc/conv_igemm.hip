@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase, ybatch);
 }
 
-// ---- LDS-DMA variant (plain mode: no parity classes, no batching) -------------------------------------------------------
+// ---- LDS-DMA variant (everything but the batched attention GEMMs) -------------------------------------------------------
 // Same tiling and tap tables, but the operand pieces go global -> LDS directly (buffer_load ... lds: no staging registers,
 // no ds_write pass, out-of-image / out-of-range pieces are zero-filled by the buffer range check) into a ring of NSTAGE
 // stages, so the pieces of K step ks+NSTAGE-1 are in flight under the MFMAs of step ks, and the only wait of a step is
@@ -238,7 +238,11 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int HWg = p.Hg * p.Wg;
-  const int ntaps = p.ntaps;
+  // Conv2DTranspose forward: blockIdx.z = output-parity class, which owns tap-table entries [4c, 4c+4) and its own output pixels
+  const int cls = p.cls_mode ? (int)blockIdx.z : 0;
+  const int tbase = cls * 4;
+  const int ntaps = p.cls_mode ? (int)p.cls_ntaps[cls] : p.ntaps;
+  const int oay = p.cls_mode ? (cls >> 1) : p.oay, oax = p.cls_mode ? (cls & 1) : p.oax;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
 
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   auto issue = [&](int stage) {
     char* const sb = lds_raw + stage * STAGE;
     const bool tv = ti < ntaps;
-    int4 e = *reinterpret_cast<const int4*>(s_tap4[tv ? ti : 0]);
+    int4 e = *reinterpret_cast<const int4*>(s_tap4[tbase + (tv ? ti : 0)]);
     asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one table read, here (not sunk under the selects below)
     const int da = e.z + c8 * 8, dw = e.w + c8 * 8;
 #pragma unroll
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
     int rem = mm - b * HWg;
     int gy = rem / p.Wg;
     int gx = rem - gy * p.Wg;
-    opix[a] = ((int64_t)(b * p.Ho + gy * p.osy + p.oay)) * p.Wo + gx * p.osx + p.oax;
+    opix[a] = ((int64_t)(b * p.Ho + gy * p.osy + oay)) * p.Wo + gx * p.osx + oax;
   }
   const EpiArgs e = {p.scale, p.bias, p.res, p.y, p.ldy, p.ldr, p.Nout, p.act, p.alpha, p.out_f32, p.accumulate};
   const int nbase = n0 + g * 4;
@@ -392,7 +396,8 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
     static const int dma = getenv("USSEG_IGEMM_DMA") ? atoi(getenv("USSEG_IGEMM_DMA")) : 1;
     const int64_t nb = cdiv64(p.M, (int64_t)p.Hg * p.Wg);
     const bool fits = nb * p.Hi * p.Wi * p.ldx * 2 < 0x7fff0000ll && (int64_t)p.Nw * p.Kw * 2 < 0x7fff0000ll;
-    if (dma && !p.cls_mode && p.nb2 <= 0 && kc == 8 && fits) {
+    const int k_chunks = p.cls_mode ? 4 * p.cpt : p.ntaps * p.cpt;   // a parity class has up to four taps
+    if (dma && p.nb2 <= 0 && k_chunks >= 16 && fits) {
       if (nt == 1) igemm_dma_launch_t<1, 3>(p, grid, s);
       else if (nt == 2) igemm_dma_launch_t<2, 3>(p, grid, s);
       else if (nt == 4) igemm_dma_launch_t<4, 3>(p, grid, s);
