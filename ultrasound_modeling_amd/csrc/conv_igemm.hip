@@ -397,7 +397,8 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
     const int64_t nb = cdiv64(p.M, (int64_t)p.Hg * p.Wg);
     const bool fits = nb * p.Hi * p.Wi * p.ldx * 2 < 0x7fff0000ll && (int64_t)p.Nw * p.Kw * 2 < 0x7fff0000ll;
     const int k_chunks = p.cls_mode ? 4 * p.cpt : p.ntaps * p.cpt;   // a parity class has up to four taps
-    if (dma && p.nb2 <= 0 && k_chunks >= 16 && fits) {
+    static const int dma_min = getenv("USSEG_IGEMM_DMA_MIN") ? atoi(getenv("USSEG_IGEMM_DMA_MIN")) : 4;
+    if (dma && p.nb2 <= 0 && k_chunks >= dma_min && fits) {
       if (nt == 1) igemm_dma_launch_t<1, 3>(p, grid, s);
       else if (nt == 2) igemm_dma_launch_t<2, 3>(p, grid, s);
       else if (nt == 4) igemm_dma_launch_t<4, 3>(p, grid, s);
