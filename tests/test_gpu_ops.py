@@ -85,6 +85,10 @@ CONV_CASES = [
     (2, 256, 256, 16, 32, 3, 1),  # stem convtmp_1 class, 1024 groups
     (2, 256, 256, 64, 16, 3, 4),  # decoder b2 class: 2 channel chunks resident, dilation 4
     (5, 256, 128, 24, 8, 3, 2),   # 1280 groups, 2 per workgroup, Cin not a multiple of 32
+    # LDS-DMA gather GEMM (igemm_dma_kernel): K tail inside the last stage, ragged pixel tile, partial channel tiles, long K ring
+    (3, 9, 7, 136, 200, 1, 1),    # 17 K chunks (last step 1/8 full), 189 pixels (second tile partial), N = 128 + 72
+    (2, 12, 12, 1024, 40, 1, 1),  # 128 K chunks through the 3-stage ring, 64-wide channel tile with 40 valid
+    (1, 6, 10, 40, 8, 1, 1),      # 5 K chunks: shorter than one K step
 ]
 
 
@@ -211,6 +215,7 @@ def test_conv2d_channel_slices(gen):
 TCONV_CASES = [
     (1, 4, 4, 8, 8, 3), (2, 5, 3, 16, 24, 3), (1, 8, 8, 72, 3, 3), (1, 16, 16, 160, 64, 3),
     (1, 4, 4, 8, 8, 4), (2, 3, 5, 24, 16, 4), (1, 8, 8, 160, 3, 4), (1, 1, 1, 16, 8, 4),
+    (3, 9, 7, 136, 72, 4), (1, 16, 16, 264, 136, 3),   # parity classes on the LDS-DMA kernel: K tails, ragged pixel tiles, N = 128 + 8
 ]
 
 
