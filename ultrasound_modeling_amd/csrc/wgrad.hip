@@ -136,9 +136,188 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---- LDS-DMA variant -------------------------------------------------------------------------------------------------------
+// Same per-tap GEMM over pixels, but: 64-pixel K steps whose operand rows go global -> LDS directly (buffer_load ... lds, out of
+// range pixels and channel tails zero-filled by the range check) into a ring of NSTAGE stages with counted vmcnt waits and bare
+// barriers; (64*TM) x (64*TM) tiles (TM = 2: 16 MFMA tiles per wave per 32 pixels instead of 4 for the same fragment reads);
+// pixel coordinates by a float-reciprocal division instead of two integer divisions per load.
+// LDS image of an operand stage: [64 pixels][64*TM channels], dense rows; the 32-byte block b (16 channels = one MFMA tile
+// column) of pixel row r sits at block b ^ f(r), f(r) = (r >> 1) & 3 for 128-byte rows, r & 7 for 256-byte rows: a transposed
+// fragment read (8 consecutive pixel rows x 32 B per 32-lane pass) then covers all 64 banks once, and the lane -> (row, block)
+// map of a DMA wave-instruction keeps one source channel offset per lane.
+typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
+#define WGRAD_OOB 0x80000000u
+
+template <int TM, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, const float rcp_hw, const float rcp_w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BT = 64 * TM;                 // channels per tile side
+  constexpr int ROWB = BT * 2;                // bytes per pixel row of an operand stage
+  constexpr int OPB = 64 * ROWB;              // bytes per operand stage (64 pixels)
+  constexpr int STAGE = 2 * OPB;
+  constexpr int RPI = 1024 / ROWB;            // pixel rows per DMA instruction (8 or 4)
+  constexpr int IT = 64 / RPI / 4;            // instructions per wave per operand per step (2 or 4)
+  constexpr int NI = 2 * IT;
+  constexpr int D = NSTAGE - 1;
+  constexpr int MT = 2 * TM;                  // MFMA tiles per wave per side
+  extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = (int)blockIdx.z;
+  const int mt = blockIdx.y / p.ntiles, nt = blockIdx.y - mt * p.ntiles;
+  const int m0 = mt * BT, n0 = nt * BT;
+  const int64_t k_begin = (int64_t)blockIdx.x * p.chunk;
+  int64_t k_end = k_begin + p.chunk;
+  if (k_end > p.M) k_end = p.M;
+  if (k_begin >= k_end) return;
+  const int nks = (int)((k_end - k_begin + 63) >> 6);
+  const int ady = p.ady[t], adx = p.adx[t], bdy = p.bdy[t], bdx = p.bdx[t];
+  const int HWg = p.Hg * p.Wg;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, 0x7fffffff, 0x00020000);
+
+  // ---- this lane's DMA pieces: row lrow of instruction wv + 4*it, one fixed 16-byte channel slot
+  const int lrow = TM == 1 ? (lane >> 3) : (lane >> 4);
+  const int slot = TM == 1 ? (lane & 7) : (lane & 15);                       // 16-byte slot within the row
+  const int fkey = TM == 1 ? ((lane >> 4) & 3) : ((4 * (wv & 1) + (lane >> 4)) & 7);   // f(row) of every row this lane touches
+  const int ch = (((slot >> 1) ^ fkey) << 4) + ((slot & 1) << 3);             // source channel of that slot
+  const bool a_cok = (m0 + ch) < p.Ma, b_cok = (n0 + ch) < p.Nb;
+  const int a_c = m0 + ch, b_c = n0 + ch;
+
+  int kpos = 0;   // pixel offset (within the split) of the step being issued
+  auto issue = [&](int stage) {
+    char* const sa = lds_raw + stage * STAGE;
+    char* const sb = sa + OPB;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int j = wv + 4 * it;
+      const int64_t m = k_begin + kpos + RPI * j + lrow;
+      const bool pv = m < k_end;
+      const int mm = pv ? (int)m : 0;
+      // (image, row, column) of grid pixel mm: float-reciprocal quotients corrected by one step either way (mm < 2^24)
+      int b = (int)((float)mm * rcp_hw);
+      int rem = mm - b * HWg;
+      if (rem < 0) { --b; rem += HWg; }
+      if (rem >= HWg) { ++b; rem -= HWg; }
+      int gy = (int)((float)rem * rcp_w);
+      int gx = rem - gy * p.Wg;
+      if (gx < 0) { --gy; gx += p.Wg; }
+      if (gx >= p.Wg) { ++gy; gx -= p.Wg; }
+      const int ay = gy * p.asy + ady, ax = gx * p.asx + adx;
+      const int by = gy * p.bsy + bdy, bx = gx * p.bsx + bdx;
+      const bool in_a = ((unsigned)ay < (unsigned)p.Ha) & ((unsigned)ax < (unsigned)p.Wa);
+      const bool in_b = ((unsigned)by < (unsigned)p.Hb) & ((unsigned)bx < (unsigned)p.Wb);
+      const bool oka = pv & in_a & in_b & a_cok;   // a product with a zero operand contributes nothing: one zero suffices
+      const bool okb = pv & in_b & b_cok;
+      const uint32_t offa = (uint32_t)(((b * p.Ha + ay) * p.Wa + ax) * p.lda + a_c) * 2u;
+      const uint32_t offb = (uint32_t)(((b * p.Hb + by) * p.Wb + bx) * p.ldb + b_c) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (wg_lds_ptr_t)(sa + j * 1024), 16, oka ? offa : WGRAD_OOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (wg_lds_ptr_t)(sb + j * 1024), 16, okb ? offb : WGRAD_OOB, 0, 0, 0);
+    }
+    kpos += 64;
+  };
+
+  const int wm = wv >> 1, wn = wv & 1;
+  f32x4_t acc[MT][MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // transposed fragment reads: K index 8g + 4h + tq of a 32-pixel sub-step is pixel 16h + 4g + tq (same permutation for both
+  // operands); the lane supplies the address of 4 channels (8 B) of that pixel and receives 4 pixels of channel (lane & 15)
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  auto tr8 = [&](const char* a0, const char* a1) -> bf16x8_t {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a1));
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  // byte offset of (pixel row r, MFMA tile column blk) within an operand stage, this lane's 8 bytes of it
+  auto frag_off = [&](int r, int blk) -> int {
+    const int f = TM == 1 ? ((r >> 1) & 3) : (r & 7);
+    return r * ROWB + ((blk ^ f) << 5) + (tp << 3);
+  };
+
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nks) issue(s);
+  for (int ks = 0; ks < nks; ++ks) {
+    if (D >= 2 && ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ks + D < nks) issue((ks + D) % NSTAGE);
+    const char* const LA = lds_raw + (ks % NSTAGE) * STAGE;
+    const char* const LB = LA + OPB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int r0 = 32 * kk + 4 * g + tq, r1 = r0 + 16;
+      bf16x8_t af[MT], bfr[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        af[i] = tr8(LA + frag_off(r0, wm * MT + i), LA + frag_off(r1, wm * MT + i));
+        bfr[i] = tr8(LB + frag_off(r0, wn * MT + i), LB + frag_off(r1, wn * MT + i));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D^T: lane holds 4 consecutive n
+    }
+  }
+
+  // lane holds D[n_local = 4g + r][m_local = li] of each tile: 16 bytes of the slab, or four atomics into the (mapped) gradient
+  float* out = p.out + (int64_t)t * p.Ma * p.Nb;
+  float* slab = p.ws ? p.ws + ((int64_t)blockIdx.x * p.ntaps + t) * p.Ma * p.Nb : nullptr;
+  const bool vec_ok = (p.Nb & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + (wm * MT + i) * 16 + li;
+      const int n = n0 + (wn * MT + j) * 16 + g * 4;
+      if (m >= p.Ma || n >= p.Nb) continue;
+      if (slab && vec_ok && n + 3 < p.Nb) {
+        *reinterpret_cast<float4*>(slab + (int64_t)m * p.Nb + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.Nb) continue;
+          if (slab) slab[(int64_t)m * p.Nb + n + r] = acc[i][j][r];
+          else {
+            float* q = wg_map_dst(p.map, out, (int64_t)m * p.Nb + n + r, t, m, n + r);
+            if (q) atomicAdd(q, acc[i][j][r]);
+          }
+        }
+      }
+    }
+#endif
+}
+
+template <int TM, int NSTAGE>
+static void wgrad_dma_launch_t(const WgradParams& p, dim3 grid, hipStream_t s) {
+  const size_t dyn = (size_t)NSTAGE * 2 * 64 * 64 * TM * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<TM, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((wgrad_dma_kernel<TM, NSTAGE>), grid, dim3(256), dyn, s, p, 1.0f / (float)(p.Hg * p.Wg), 1.0f / (float)p.Wg);
+}
+
 static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats, hipStream_t s) {
-  p.mtiles = (p.Ma + 63) / 64;
-  p.ntiles = (p.Nb + 63) / 64;
+  // LDS-DMA variant: unbatched launches whose operands fit 32-bit byte offsets and whose pixel count fits the float division
+  static const int dma_env = getenv("USSEG_WGRAD_DMA") ? atoi(getenv("USSEG_WGRAD_DMA")) : 1;
+  const bool dma = dma_env && p.nb2 <= 0 && p.M < (1 << 24) && (int64_t)p.B * p.Ha * p.Wa * p.lda * 2 < 0x7fff0000ll &&
+                   (int64_t)p.B * p.Hb * p.Wb * p.ldb * 2 < 0x7fff0000ll && p.lda % 8 == 0 && p.ldb % 8 == 0;
+  // 128x128 tiles when both channel counts fill them and there are still enough tiles to go round
+  static const int tm_env = getenv("USSEG_WGRAD_TM") ? atoi(getenv("USSEG_WGRAD_TM")) : 0;
+  int tm = 1;
+  if (dma && p.Ma > 64 && p.Nb > 64 && (int64_t)((p.Ma + 127) / 128) * ((p.Nb + 127) / 128) * ntaps >= 256) tm = 2;
+  if (dma && tm_env) tm = tm_env;
+  const int bt = 64 * tm;
+  p.mtiles = (p.Ma + bt - 1) / bt;
+  p.ntiles = (p.Nb + bt - 1) / bt;
   p.ntaps = ntaps;
   int64_t tiles = (int64_t)p.mtiles * p.ntiles * ntaps;
   // enough splits to give every CU a few workgroups, but at least 256 pixels of work per split
@@ -161,10 +340,14 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
     if (want > 1) p.ws = ws;
   }
   if (want < 1) want = 1;
-  p.chunk = cdiv64(cdiv64(p.M, want), 32) * 32;
+  p.chunk = cdiv64(cdiv64(p.M, want), 64) * 64;
   int64_t splits = cdiv64(p.M, p.chunk);
   const int slot = usseg_prof_start(2, s);
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)splits, (unsigned)(p.mtiles * p.ntiles), (unsigned)ntaps), dim3(256), 0, s, p);
+  const dim3 grid((unsigned)splits, (unsigned)(p.mtiles * p.ntiles), (unsigned)ntaps);
+  if (dma) {
+    if (tm == 2) wgrad_dma_launch_t<2, 2>(p, grid, s);
+    else wgrad_dma_launch_t<1, 3>(p, grid, s);
+  } else hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
   if (p.ws) usseg_launch_wgrad_finish(p.ws, (int)splits, slab, p.out, p.map, p.Ma, p.Nb, s);
   usseg_prof_stop(2, slot, s);
   return usseg_check_launch("wgrad");
