@@ -310,10 +310,10 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
   static const int dma_env = getenv("USSEG_WGRAD_DMA") ? atoi(getenv("USSEG_WGRAD_DMA")) : 1;
   const bool dma = dma_env && p.nb2 <= 0 && p.M < (1 << 24) && (int64_t)p.B * p.Ha * p.Wa * p.lda * 2 < 0x7fff0000ll &&
                    (int64_t)p.B * p.Hb * p.Wb * p.ldb * 2 < 0x7fff0000ll && p.lda % 8 == 0 && p.ldb % 8 == 0;
-  // 128x128 tiles when both channel counts fill them and there are still enough tiles to go round
+  // 128x128 tiles when both channel counts exceed one 64-wide tile (split-K supplies the workgroups if the tiles are few)
   static const int tm_env = getenv("USSEG_WGRAD_TM") ? atoi(getenv("USSEG_WGRAD_TM")) : 0;
   int tm = 1;
-  if (dma && p.Ma > 64 && p.Nb > 64 && (int64_t)((p.Ma + 127) / 128) * ((p.Nb + 127) / 128) * ntaps >= 256) tm = 2;
+  if (dma && p.Ma > 64 && p.Nb > 64) tm = 2;
   if (dma && tm_env) tm = tm_env;
   const int bt = 64 * tm;
   p.mtiles = (p.Ma + bt - 1) / bt;
@@ -344,6 +344,9 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
   int64_t splits = cdiv64(p.M, p.chunk);
   const int slot = usseg_prof_start(2, s);
   const dim3 grid((unsigned)splits, (unsigned)(p.mtiles * p.ntiles), (unsigned)ntaps);
+  static const int dbg = getenv("USSEG_WGRAD_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[wgrad] M %lld (B %d Hg %d Wg %d) Ma %d Nb %d taps %d tm %d splits %lld chunk %lld slab %s asy %d bsy %d lda %d ldb %d\n", (long long)p.M, p.B, p.Hg, p.Wg,
+                   p.Ma, p.Nb, ntaps, tm, (long long)splits, (long long)p.chunk, p.ws ? "yes" : "no", p.asy, p.bsy, p.lda, p.ldb);
   if (dma) {
     if (tm == 2) wgrad_dma_launch_t<2, 2>(p, grid, s);
     else wgrad_dma_launch_t<1, 3>(p, grid, s);
