@@ -641,22 +641,40 @@ extern "C" int usseg_unpack_wgrad_batched(const UssegUnpackJob* jobs_dev, int32_
 
 // ---- all operand packs of a model in ONE launch: blockIdx.y = job ---------------------------------------------
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const UssegPackJob* jobs) {
+  // A pack is a (strided) transpose: 32x32 tiles through LDS, read along whichever of (n, k) is the faster source axis,
+  // written along k (the destination's contiguous axis).  The element-per-thread version read the Keras [k,k,Cin,Cout]
+  // variable with a stride of Cout floats per lane for one of the two operand layouts (0.8 TB/s on Arch A's 31 M parameters).
   const UssegPackJob j = jobs[blockIdx.y];
-  const int total = j.T * j.Nn * j.Kk;          // < 2^31 (checked on the host side of every caller: one conv kernel)
-  if ((int)blockIdx.x * 256 >= total) return;    // the grid is sized for the largest job
-  bf16_t* dst = reinterpret_cast<bf16_t*>(j.dst);
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    int k = i % j.Kk;
-    int r = i / j.Kk;
-    int n = r % j.Nn;
-    int t = r / j.Nn;
-    dst[(int64_t)(j.n_off + n) * j.Kw + (int64_t)t * j.tap_stride + j.k_off + k] = f2bf(j.src[t * j.sT + n * j.sN + k * j.sK]);
+  const int tilesN = (j.Nn + 31) >> 5, tilesK = (j.Kk + 31) >> 5;
+  const int ntile = j.T * tilesN * tilesK;
+  if ((int)blockIdx.x >= ntile) return;          // the grid is sized for the largest job
+  __shared__ float tile[32][33];
+  bf16_t* const dst = reinterpret_cast<bf16_t*>(j.dst);
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const bool k_fast = j.sK <= j.sN;
+  for (int id = blockIdx.x; id < ntile; id += gridDim.x) {
+    const int t = id / (tilesN * tilesK), r = id - t * (tilesN * tilesK);
+    const int n0 = (r / tilesK) << 5, k0 = (r % tilesK) << 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nn = k_fast ? ly + 8 * i : lx, kk = k_fast ? lx : ly + 8 * i;
+      float v = 0.f;
+      if (n0 + nn < j.Nn && k0 + kk < j.Kk) v = j.src[(int64_t)t * j.sT + (int64_t)(n0 + nn) * j.sN + (int64_t)(k0 + kk) * j.sK];
+      tile[nn][kk] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nn = ly + 8 * i;
+      if (n0 + nn < j.Nn && k0 + lx < j.Kk)
+        dst[(int64_t)(j.n_off + n0 + nn) * j.Kw + (int64_t)t * j.tap_stride + j.k_off + k0 + lx] = f2bf(tile[nn][lx]);
+    }
+    __syncthreads();
   }
 }
 extern "C" int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t njobs, usseg_stream_t stream) {
   USSEG_CHECK_ARG(jobs_dev && njobs > 0 && njobs < 65536, "pack_weights_batched: bad args");
-  // 512 x njobs workgroups; a workgroup whose first 256-element slice lies past its job's end exits at once, the others
-  // stride over the job (the largest Arch B operand, 3x3x512x256, is 1.2 M elements = 9 trips)
+  // 512 x njobs workgroups; a workgroup past its job's last 32x32 tile exits at once, the others stride over the tiles
   hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(512, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return usseg_check_launch("pack_weights_batched");
 }
