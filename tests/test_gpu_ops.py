@@ -219,6 +219,32 @@ TCONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(1, 8, 8, 72, 40, 3), (2, 16, 16, 160, 64, 4), (1, 4, 4, 8, 8, 4), (3, 32, 16, 24, 136, 3)])
+def test_tconv_wgrad_parity_class_halo_form(gen, monkeypatch, B, H, W, Cin, Cout, k):
+    """The transposed-conv weight gradient as four tap-masked parity-class jobs of the halo-tile kernel (built, off by default:
+    usseg_try_launch_tconv_wgrad_halo) against the oracle and against the per-tap kernel."""
+    from ultrasound_modeling_amd.layers import Conv2DTranspose
+    w = rnd(gen, k, k, Cout, Cin, scale=1.0 / math.sqrt(k * k * Cin))
+    b = rnd(gen, Cout, scale=0.5)
+    x = rnd(gen, B, H, W, Cin)
+    dy = rnd(gen, B, 2 * H, 2 * W, Cout)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (O.conv2d_transpose_s2_same(xr, wr, br) * dy).sum().backward()
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("USSEG_TCONV_HALO", flag)
+        layer = Conv2DTranspose(Cin, Cout, k)
+        layer.kernel.data.copy_(w)
+        layer.bias.data.copy_(b)
+        finalize(layer)
+        layer.forward(to_dev_padded(x))
+        layer.backward(to_dev_padded(dy))
+        torch.cuda.synchronize()
+        assert rel(layer.kernel.grad, wr.grad) < REL_F32
+        grads.append(layer.kernel.grad.detach().clone())
+    assert rel(grads[0], grads[1]) < 1e-4      # same bf16 products, fp32 sums in a different order
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", TCONV_CASES)
 def test_tconv2d_fwd_dgrad_wgrad(gen, B, H, W, Cin, Cout, k):
     from ultrasound_modeling_amd.layers import Conv2DTranspose

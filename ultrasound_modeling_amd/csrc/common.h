@@ -277,31 +277,44 @@ __device__ __forceinline__ void conv_epilogue(const EpiArgs& e, const EpiConst<N
   }
 }
 
-// destination map of a weight gradient (UssegWgradDst by value in the kernel parameters); nblocks == 0: identity
+// destination map of a weight gradient (UssegWgradDst by value in the kernel parameters); nblocks == 0: identity.
+// Internally a block carries two tap strides - tap t = 3*th + tw lands at th*sTr + tw*sT (plain maps: sTr = 3*sT, i.e. t*sT) -
+// and the map a tap mask: the parity classes of a transposed conv are 3x3 weight gradients whose valid taps are a 2x2 (or
+// smaller) subset sitting at stride 2 in the Keras [k,k,...] variable (wgrad_halo.hip, tconv form).
+struct WgBlock {
+  float* dst;
+  int64_t sT, sTr, sI, sO;
+  int32_t i_off, o_off, ni, no;
+};
 struct WgMap {
-  int32_t nblocks, pad;
-  UssegWgradBlock blk[4];
+  int32_t nblocks;
+  uint32_t tapmask;   // taps that exist in the destination (0x1ff for a plain map; identity maps ignore it)
+  WgBlock blk[4];
 };
 __device__ __forceinline__ float* wg_map_dst(const WgMap& m, float* ident, int64_t ident_idx, int t, int mi, int n) {
   if (m.nblocks == 0) return ident + ident_idx;
+  if (t < 9 && !((m.tapmask >> t) & 1u)) return nullptr;   // (per-tap kernels pass up to 16 taps with a full mask)
+  const int th = t / 3, tw = t - 3 * th;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     if (b < m.nblocks) {
-      const UssegWgradBlock& k = m.blk[b];
+      const WgBlock& k = m.blk[b];
       if ((unsigned)(mi - k.i_off) < (unsigned)k.ni && (unsigned)(n - k.o_off) < (unsigned)k.no)
-        return k.dst + t * k.sT + (mi - k.i_off) * k.sI + (n - k.o_off) * k.sO;
+        return k.dst + th * k.sTr + tw * k.sT + (mi - k.i_off) * k.sI + (n - k.o_off) * k.sO;
     }
   }
   return nullptr;
 }
 static inline int wg_map_fill(WgMap& m, const UssegWgradDst* d) {
   m = {};
+  m.tapmask = 0xffffffffu;
   if (!d) return 1;
   if (d->nblocks < 1 || d->nblocks > 4) return 0;
   m.nblocks = d->nblocks;
   for (int b = 0; b < d->nblocks; ++b) {
-    if (!d->blk[b].dst) return 0;
-    m.blk[b] = d->blk[b];
+    const UssegWgradBlock& u = d->blk[b];
+    if (!u.dst) return 0;
+    m.blk[b] = {u.dst, u.sT, 3 * u.sT, u.sI, u.sO, u.i_off, u.o_off, u.ni, u.no};
   }
   return 1;
 }
@@ -360,6 +373,9 @@ float* usseg_defer_wgrad_ws(hipStream_t s, float* caller_ws, int64_t caller_floa
 void usseg_launch_wgrad_finish(const float* ws, int splits, int64_t slab_floats, float* out, const WgMap& map, int Ma, int Nb, hipStream_t s);
 
 int usseg_try_launch_wgrad_halo_multi(int njobs, const UssegWgradJob* jobs, float* ws, int64_t ws_floats, hipStream_t s);
+// stride-2 transposed-conv weight gradient as four tap-masked parity-class jobs of the halo-tile kernel (wgrad_halo.hip): 1 if taken
+int usseg_try_launch_tconv_wgrad_halo(const bf16_t* x, const bf16_t* dy, const WgMap& map, int B, int H, int W, int Cin, int Cout, int ldx,
+                                      int lddy, int k, float* ws, int64_t ws_floats, hipStream_t s);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

@@ -440,11 +440,14 @@ static int tconv2d_wgrad_impl(const UssegConvDesc* d, const void* x, const void*
         p.bdy[t] = 0; p.bdx[t] = 0;
       }
     for (int b = 0; b < map.nblocks; ++b) {   // kernel axes (m, n) = (output channel, input channel)
-      UssegWgradBlock u = map.blk[b];
+      WgBlock u = map.blk[b];
       map.blk[b].sI = u.sO; map.blk[b].sO = u.sI;
       map.blk[b].i_off = u.o_off; map.blk[b].o_off = u.i_off;
       map.blk[b].ni = u.no; map.blk[b].no = u.ni;
     }
+    if (usseg_try_launch_tconv_wgrad_halo((const bf16_t*)x, (const bf16_t*)dy, map, d->B, d->H, d->W, d->Cin, d->Cout, d->ldx, d->ldy, k, ws,
+                                          ws_floats, (hipStream_t)stream))
+      return usseg_check_launch("tconv_wgrad_halo");
   }
   p.map = map;
   return launch_wgrad(p, k * k, ws, ws_floats, (hipStream_t)stream);

@@ -20,6 +20,11 @@ struct WgHaloParams {
   int32_t ldx, lddy, Ma, Nb, ntiles_n;
   int32_t mask_ch;        // quad-form transposed conv: output channels per parity class (0 = all taps)
   uint16_t tapmask[4];
+  // operand views: lattice pixel (ly, lx) of a patch with lattice offset (la, lb) is image pixel
+  // (va + la + vd*ly, vb + lb + vd*lx) of a vH x vW image.  Conv: both (d, H, W, 0, 0).  Transposed conv, parity class (a, b):
+  // the halo operand is dy seen through (2, 2H, 2W, a, b), the centre operand x through (1, H, W, 0, 0).
+  int32_t xvd, xvH, xvW, xva, xvb;
+  int32_t yvd, yvH, yvW, yva, yvb;
 };
 
 // WVM = waves along the input-channel axis (2 or 4; the other 4/WVM waves split the output channels),
@@ -90,12 +95,12 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
     const int hy = (x_geo[it] >> 8) & 255, hx = x_geo[it] & 255;
-    x_rel[it] = (p.d * hy * p.W + p.d * hx) * p.ldx + m0 + xq * 8;
+    x_rel[it] = (p.xvd * hy * p.xvW + p.xvd * hx) * p.ldx + m0 + xq * 8;
   }
 #pragma unroll
   for (int it = 0; it < Y_IT; ++it) {
     const int row = (y_geo[it] >> 8) & 255, col = y_geo[it] & 255;
-    y_rel[it] = (p.d * row * p.W + p.d * col) * p.lddy + n0 + yq * 8;
+    y_rel[it] = (p.yvd * row * p.yvW + p.yvd * col) * p.lddy + n0 + yq * 8;
   }
 
   // ---- fragment addressing (fixed): K index 8g + 4h + tq of a 32-pixel step is pixel 16h + 4g + tq (same permutation for x and dy)
@@ -146,8 +151,8 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       const int la = ab / p.d, lb = ab - la * p.d, ly0 = ty * p.PH, lx0 = tx * p.PW;
       // [0] x offset of halo pixel (0,0) (may be "negative": only in-image items use it), [1] dy offset of patch pixel (0,0),
       // [2] ly0 - 1 (far out of range for an invalid patch: every bounds test then fails), [3] lx0 - 1, [4] valid
-      tab[tid][0] = (int)(((int64_t)(b * p.H + la + p.d * (ly0 - 1)) * p.W + lb + p.d * (lx0 - 1)) * p.ldx);
-      tab[tid][1] = (int)(((int64_t)(b * p.H + la + p.d * ly0) * p.W + lb + p.d * lx0) * p.lddy);
+      tab[tid][0] = (int)(((int64_t)(b * p.xvH + p.xva + la + p.xvd * (ly0 - 1)) * p.xvW + p.xvb + lb + p.xvd * (lx0 - 1)) * p.ldx);
+      tab[tid][1] = (int)(((int64_t)(b * p.yvH + p.yva + la + p.yvd * ly0) * p.yvW + p.yvb + lb + p.yvd * lx0) * p.lddy);
       tab[tid][2] = valid ? ly0 - 1 : -(1 << 24);
       tab[tid][3] = lx0 - 1;
       tab[tid][4] = valid;
@@ -317,6 +322,8 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
 struct WgHaloGeom {
   const bf16_t* x; const bf16_t* dy; float* out; WgMap map;
   int B, H, W, d, Ma, Nb, ldx, lddy;
+  int tconv_cls = -1;      // >= 0: parity class 2a+b of a stride-2 transposed conv (x = dy tensor at 2H x 2W, dy = x tensor; see the views)
+  uint32_t tapmask = 0x1ff;
 };
 
 // Launches njobs (1..4) weight gradients of identical (B,H,W,Ma,Nb) - dilations may differ as long as the group counts match -
@@ -348,10 +355,18 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     p.tiles_x = Wl / PW;
     p.tiles_per_v = (Hl / PH) * p.tiles_x;
     p.npatches = q.B * d * d * p.tiles_per_v;
+    if (q.tconv_cls >= 0) {
+      p.xvd = 2; p.xvH = 2 * q.H; p.xvW = 2 * q.W; p.xva = q.tconv_cls >> 1; p.xvb = q.tconv_cls & 1;
+      p.yvd = 1; p.yvH = q.H; p.yvW = q.W; p.yva = p.yvb = 0;
+      p.mask_ch = 1 << 30;                       // one class for every channel tile: tapmask[0]
+      p.tapmask[0] = (uint16_t)q.tapmask;
+    } else {
+      p.xvd = p.yvd = d; p.xvH = p.yvH = q.H; p.xvW = p.yvW = q.W; p.xva = p.xvb = p.yva = p.yvb = 0;
+    }
     p.ngroups = (p.npatches + NV - 1) / NV;
     p.ldx = q.ldx; p.lddy = q.lddy; p.Ma = Ma; p.Nb = Nb;
     if (p.ngroups != P.job[0].ngroups) return 0;
-    if ((int64_t)q.B * q.H * q.W * q.ldx >= (1ll << 31) || (int64_t)q.B * q.H * q.W * q.lddy >= (1ll << 31)) return 0;   // 32-bit element offsets
+    if ((int64_t)q.B * p.xvH * p.xvW * q.ldx >= (1ll << 31) || (int64_t)q.B * p.yvH * p.yvW * q.lddy >= (1ll << 31)) return 0;   // 32-bit element offsets
   }
   if (ws) ws = usseg_defer_wgrad_ws(s, ws, ws_floats, &ws_floats);   // deferred finishing: a private region of the step's workspace
   // tile shape by channel counts: 64x64, 32x32 (both small), 64x16 / 64x32 (few output channels, e.g. the decoder branches)
@@ -395,7 +410,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     P.job[j].groups_per_block = gpb;
     P.job[j].ws = use_ws ? ws + (int64_t)j * splits * slab : nullptr;
   }
-  const bool masked = usseg_tap_mask.group_ch != 0;
+  const bool masked = usseg_tap_mask.group_ch != 0 || gm[0].tconv_cls >= 0;
   if (usseg_tap_mask.group_ch) {
     if (njobs != 1 || usseg_tap_mask.group_ch % bn) return 0;      // an output-channel tile must lie inside one class
     P.job[0].mask_ch = usseg_tap_mask.group_ch;
@@ -442,4 +457,43 @@ int usseg_try_launch_wgrad_halo_multi(int njobs, const UssegWgradJob* jobs, floa
     if (!wg_map_fill(g[j].map, q.dst)) return 0;
   }
   return wgrad_halo_launch(g, njobs, ws, ws_floats, s);
+}
+
+// Weight gradient of a stride-2 'same' Conv2DTranspose (k = 3 or 4) on the halo-tile kernel: its four output-parity classes are
+// four 3x3 stride-1 weight gradients between x and dy seen through a stride-2 view,
+//   dW[kh][kw][co][ci] = sum_g x[g][ci] * dy[2g + (kh-pad, kw-pad)][co] = sum_g x[g][ci] * dy_(a,b)[g + (th-1, tw-1)][co],
+//   kh = a + pad - 2 + 2*th (likewise kw), so class (a, b) owns the taps whose (kh, kw) fall inside the k x k kernel: a 2x2
+// (or smaller) subset of the 3x3 - the kernel's tap mask - that sits at stride 2 in the Keras [k,k,Cout,Cin] variable - the map's
+// two tap strides.  One launch, blockIdx.z = class; both operands staged once per 128 pixels for all taps instead of once per tap
+// (the per-tap kernel moves 16x the operand bytes for k = 4).  `map`: kernel axes (m, n) = (output channel, input channel).
+int usseg_try_launch_tconv_wgrad_halo(const bf16_t* x, const bf16_t* dy, const WgMap& map, int B, int H, int W, int Cin, int Cout, int ldx,
+                                      int lddy, int k, float* ws, int64_t ws_floats, hipStream_t s) {
+  // Built and parity-tested, off by default: with 4 of 9 taps live per class the 64x64 halo tile is staging-bound and loses to the
+  // per-tap LDS-DMA kernel with 128x128 tiles (Arch A 9.20 vs 8.78 ms, Arch B 4.32 vs 4.22 ms per step).
+  const char* en = getenv("USSEG_TCONV_HALO");   // read per call: the parity test flips it inside one process
+  const int enabled = en ? atoi(en) : 0;
+  if (!enabled || map.nblocks < 1 || (k != 3 && k != 4)) return 0;
+  const int pad = k == 4 ? 1 : 0;
+  WgHaloGeom g[4];
+  for (int c = 0; c < 4; ++c) {
+    const int a = c >> 1, b = c & 1;
+    uint32_t mask = 0;
+    for (int th = 0; th < 3; ++th)
+      for (int tw = 0; tw < 3; ++tw) {
+        const int kh = a + pad - 2 + 2 * th, kw = b + pad - 2 + 2 * tw;
+        if (kh >= 0 && kh < k && kw >= 0 && kw < k) mask |= 1u << (3 * th + tw);
+      }
+    g[c] = {dy, x, nullptr, map, B, H, W, 1, Cout, Cin, lddy, ldx};
+    g[c].tconv_cls = c;
+    g[c].tapmask = mask;
+    g[c].map.tapmask = mask;
+    for (int i = 0; i < map.nblocks; ++i) {
+      WgBlock& u = g[c].map.blk[i];
+      const int64_t sk = map.blk[i].sT;           // stride of one Keras tap (kh*k + kw)
+      u.dst = map.blk[i].dst + ((int64_t)(a + pad - 2) * k + (b + pad - 2)) * sk;
+      u.sTr = 2 * k * sk;
+      u.sT = 2 * sk;
+    }
+  }
+  return wgrad_halo_launch(g, 4, ws, ws_floats, s);
 }
