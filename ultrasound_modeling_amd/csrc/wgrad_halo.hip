@@ -398,6 +398,27 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   else if ((int64_t)max_splits * slab * njobs > ws_floats) max_splits = (int)(ws_floats / (slab * njobs));
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  {
+    // Wave quantisation: the 64x64 shape runs one workgroup per CU (8 waves), the others two, so a launch of 528 workgroups
+    // is three rounds of 256 where 504 would be two.  Around the target, pick the split count with the cheapest
+    // rounds x (groups per workgroup + fixed cost) estimate (fixed cost ~ 3 group times: prologue + slab epilogue).
+    static const int quant = getenv("USSEG_WG_QUANT") ? atoi(getenv("USSEG_WG_QUANT")) : 1;
+    if (quant && max_splits > 1) {
+      const int slots = 256 * (shape == 0 ? 1 : 2);
+      const int64_t tj = (int64_t)tiles * njobs;
+      int best = splits;
+      double best_cost = 1e30;
+      const int lo = splits / 2 > 1 ? splits / 2 : 1, hi = splits * 2 < max_splits ? splits * 2 : max_splits;
+      for (int sp = lo; sp <= hi; ++sp) {
+        const int g = (ngroups + sp - 1) / sp;
+        const int real = (ngroups + g - 1) / g;
+        const double rounds = (double)((tj * real + slots - 1) / slots);
+        const double cost = rounds * (g + 3.0) + 0.02 * real;   // mild preference for fewer slabs at equal time
+        if (cost < best_cost) { best_cost = cost; best = sp; }
+      }
+      splits = best;
+    }
+  }
   bool mapped = false;
   for (int j = 0; j < njobs; ++j) mapped = mapped || gm[j].map.nblocks;
   // a mapped destination is scattered by the finishing kernel, so it always goes through a slab
