@@ -330,6 +330,7 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
   // 32x16 cardinal conv1 gradient took 35-120 us that way).  Slab traffic is kept within ~8x the operand bytes.
   const int64_t slab = (int64_t)ntaps * p.Ma * p.Nb;
   p.ws = nullptr;
+  int64_t cap_splits = 1;
   if (ws) ws = usseg_defer_wgrad_ws(s, ws, ws_floats, &ws_floats);
   if (ws && want > 1) {
     const int64_t in_bytes = p.M * (p.Ma + p.Nb) * 2;
@@ -337,9 +338,29 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
     if (cap < 4) cap = 4;
     if (cap > ws_floats / slab) cap = ws_floats / slab;
     if (want > cap) want = cap;
+    cap_splits = cap;
     if (want > 1) p.ws = ws;
   }
   if (want < 1) want = 1;
+  {
+    // wave quantisation (see wgrad_halo_launch): 3 (64x64 tiles) or 2 (128x128) workgroups per CU resident; near the target pick
+    // the split count with the cheapest rounds x (K steps per workgroup + fixed cost) estimate
+    static const int quant = getenv("USSEG_WG_QUANT") ? atoi(getenv("USSEG_WG_QUANT")) : 1;
+    const int64_t hi_cap = p.ws ? (want * 2 < cap_splits ? want * 2 : cap_splits) : want;   // within the slab traffic cap; without slabs (atomics) never more splits
+    if (quant && dma && want > 1) {
+      const int64_t slots = 256 * (tm == 2 ? 2 : 3);
+      int64_t best = want;
+      double best_cost = 1e30;
+      for (int64_t sp = want / 2 > 1 ? want / 2 : 1; sp <= hi_cap && sp <= cdiv64(p.M, 256); ++sp) {
+        if (p.ws && sp * slab > ws_floats) break;
+        const int64_t ch = cdiv64(cdiv64(p.M, sp), 64) * 64, real = cdiv64(p.M, ch);
+        const double rounds = (double)((tiles * real + slots - 1) / slots);
+        const double cost = rounds * ((double)(ch / 64) + 8.0) + 0.02 * (double)real;
+        if (cost < best_cost) { best_cost = cost; best = sp; }
+      }
+      want = best;
+    }
+  }
   p.chunk = cdiv64(cdiv64(p.M, want), 64) * 64;
   int64_t splits = cdiv64(p.M, p.chunk);
   const int slot = usseg_prof_start(2, s);
