@@ -193,8 +193,17 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
 
     if (!BWD) {
       float o[8];
+      // one uniform branch on the activation per 8 elements (apply_act's switch costs ~10 scalar branches per element)
+      if (p.act == USSEG_ACT_LRELU) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = okf[j] * apply_act(ga[j] * xh[j] + be[j], p.act, p.alpha);
+        for (int j = 0; j < 8; ++j) { const float v = ga[j] * xh[j] + be[j]; o[j] = okf[j] * (v >= 0.f ? v : p.alpha * v); }
+      } else if (p.act == USSEG_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = okf[j] * (ga[j] * xh[j] + be[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = okf[j] * apply_act(ga[j] * xh[j] + be[j], p.act, p.alpha);
+      }
       if (p.mask && valid) {
         float mk[8];
         unpack8(*reinterpret_cast<const uint4*>(p.mask + m * p.ldm + c0), mk);
