@@ -438,6 +438,9 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     for (int c = 0; c < 4; ++c) P.job[0].tapmask[c] = usseg_tap_mask.mask[c];
   }
   const dim3 grid(splits, tiles, njobs);
+  static const int dbg = getenv("USSEG_WGRAD_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[wgrad_halo] B %d H %d W %d d %d Ma %d Nb %d jobs %d shape %d tiles %d ngroups %d splits %d gpb %d max_splits %d traffic_cap %lld slab_MB %.2f in_MB %.2f\n",
+                   gm[0].B, gm[0].H, gm[0].W, gm[0].d, Ma, Nb, njobs, shape, tiles, ngroups, splits, gpb, max_splits, (long long)traffic_cap, slab_bytes / 1e6, in_bytes / 1e6);
   const int slot = usseg_prof_start(2, s);
   static const int pf = getenv("USSEG_WGRAD_PF") ? atoi(getenv("USSEG_WGRAD_PF")) : 1;
   if (shape == 1) {
