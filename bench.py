@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_BYTES_PER_S = 8.0e12     # HBM3E peak, MI355X_MICROARCH.md
 B_PER_GPU = 16
 H = W = 256
 C_IN = 1
@@ -59,6 +60,10 @@ def algorithmic_flops(net):
     from ultrasound_modeling_amd.ResNest import residual_S
     from ultrasound_modeling_amd import ops
     fwd = igemm = 0.0
+    attain = [0.0]      # seconds the fwd + dgrad launches would take on their own rooflines: max(FLOPs / MFMA peak, min bytes / HBM)
+
+    def roof(f, M, cin, cout, passes):
+        attain[0] += passes * max(f / (PEAK_BF16_TFLOPS * 1e12), 2.0 * M * (cin + cout) / HBM_BYTES_PER_S)
     managed = set()
     for m in net.modules():
         if isinstance(m, residual_S):
@@ -69,6 +74,8 @@ def algorithmic_flops(net):
             f = 2.0 * M * g.P * (g.cin * g.cv11 + g.k * g.k * g.cv11 * g.cvkk)
             fwd += f
             igemm += 2 * f
+            roof(2.0 * M * g.P * g.cin * g.cv11, M, g.cin, g.P * g.cv11, 2)
+            roof(2.0 * M * g.P * g.k * g.k * g.cv11 * g.cvkk, M, g.P * g.cv11, g.P * g.cvkk, 2)
             for c in g.cards:
                 managed.update((id(c.conv1), id(c.conv2), id(c.split.dense1), id(c.split.dense2)))
     first = net.transformer.embeddings.hybrid_model.conv1
@@ -78,6 +85,9 @@ def algorithmic_flops(net):
             f = 2.0 * Bx * Hx * Wx * m.k * m.k * m.cin * m.cout
             fwd += f
             igemm += f if m is first else 2 * f      # the first layer needs no input gradient
+            Mo = Bx * Hx * Wx * (4 if getattr(m, "transposed", False) else 1)
+            roof(f, 0.5 * (Bx * Hx * Wx + Mo), m.cin, m.cout, 1 if m is first else 2)
+    algorithmic_flops.attainable_s = attain[0]
     return fwd, igemm, fwd
 
 
@@ -269,7 +279,11 @@ def main():
                     "algorithmic_gflop_per_step": round(ig_f / 1e9, 2), "kernel_ms_per_step": round(ig_ms, 3),
                     "wgrad": {"launches_per_step": wg_n, "kernel_ms_per_step": round(wg_ms, 3),
                               "achieved": round(wg_f / (wg_ms * 1e-3) / 1e12, 2), "algorithmic_gflop_per_step": round(wg_f / 1e9, 2)},
-                    "fwd_gflop_per_image": round(fwd_f / B_PER_GPU / 1e9, 3)}
+                    "fwd_gflop_per_image": round(fwd_f / B_PER_GPU / 1e9, 3),
+                    # time-weighted: what the same launches would take if each ran on its own roofline (HBM-bound stem /
+                    # stage-1 layers priced on bytes, the deep ones on FLOPs) over what they took
+                    "attainable_ms_per_step": round(algorithmic_flops.attainable_s * 1e3, 3),
+                    "frac_of_attainable": round(algorithmic_flops.attainable_s * 1e3 / max(ig_ms, 1e-9), 4)}
         roofline["traffic"] = pmc_traffic(ig_n)
         roofline["layers"] = layer_probe(dev)
 
