@@ -337,6 +337,33 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const bf16_t* in, const f
         for (int j = 0; j < 8; ++j) sv[j] = s[(int64_t)b * Cy + min(c0 + j, Co - 1)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Co) ? mult * v[j] * sv[j] : 0.f;
+      } else if ((Cg & 7) == 0) {
+        // groups are whole 8-channel chunks: the chunk lies in one path and each branch's operands are one 16-byte load of y
+        // and two of s (the element-wise form below issues 64 scalar loads per thread: 1.8 TB/s on Arch A's stage-1 tensor)
+        const int p = c0 / Cg, cc = c0 - p * Cg;
+        const bool ok = c0 < Co;
+        uint4 raw[4];
+        float4 w0[4], w1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cy = ok ? (p * R + min(r, R - 1)) * Cg + cc : 0;
+          raw[r] = *reinterpret_cast<const uint4*>(in + pix * ldi + cy);
+          w0[r] = *reinterpret_cast<const float4*>(s + (int64_t)b * Cy + cy);
+          w1[r] = *reinterpret_cast<const float4*>(s + (int64_t)b * Cy + cy + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r < R) {
+            float v[8];
+            unpack8(raw[r], v);
+            o[0] += v[0] * w0[r].x; o[1] += v[1] * w0[r].y; o[2] += v[2] * w0[r].z; o[3] += v[3] * w0[r].w;
+            o[4] += v[4] * w1[r].x; o[5] += v[5] * w1[r].y; o[6] += v[6] * w1[r].z; o[7] += v[7] * w1[r].w;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = ok ? mult * o[j] : 0.f;
       } else {
         // R <= 4 distinct branches: all R*8 (value, weight) pairs are loaded unconditionally at clamped indices first
         float xv[4][8], wv[4][8];
@@ -372,6 +399,21 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const bf16_t* in, const f
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (c0 + j < Cy) ? mult * v[j] * sv[j] + dv[j] : 0.f;
+      } else if ((Cg & 7) == 0) {
+        const bool ok = c0 < Cy;
+        const int cy = ok ? c0 : 0;
+        const int pr = cy / Cg;
+        const int co = (pr / R) * Cg + (cy - pr * Cg);
+        float dv[8];
+        unpack8(*reinterpret_cast<const uint4*>(in + pix * ldi + co), dv);
+        const float4 s0 = *reinterpret_cast<const float4*>(s + (int64_t)b * Cy + cy), s1 = *reinterpret_cast<const float4*>(s + (int64_t)b * Cy + cy + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(dg + (int64_t)b * Cy + cy), g1 = *reinterpret_cast<const float4*>(dg + (int64_t)b * Cy + cy + 4);
+        o[0] = mult * dv[0] * s0.x + g0.x; o[1] = mult * dv[1] * s0.y + g0.y; o[2] = mult * dv[2] * s0.z + g0.z; o[3] = mult * dv[3] * s0.w + g0.w;
+        o[4] = mult * dv[4] * s1.x + g1.x; o[5] = mult * dv[5] * s1.y + g1.y; o[6] = mult * dv[6] * s1.z + g1.z; o[7] = mult * dv[7] * s1.w + g1.w;
+        if (!ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        }
       } else {
         float dv[8], sv[8], gv[8];
 #pragma unroll
