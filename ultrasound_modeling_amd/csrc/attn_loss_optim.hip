@@ -45,6 +45,11 @@ __global__ __launch_bounds__(256) void sa_reduce_kernel(const bf16_t* y, const b
           unpack8(*reinterpret_cast<const uint4*>(db + m * lddo + chunk * 8), d);
 #pragma unroll
           for (int j = 0; j < 8; ++j) s[j] += v[j] * d[j];
+        } else if ((Cg & 7) == 0) {   // groups are whole chunks: the chunk's output channels are one 16-byte load
+          float dv[8];
+          unpack8(*reinterpret_cast<const uint4*>(db + m * lddo + co[0]), dv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[j] += cok[j] * v[j] * dv[j];
         } else {
           float dv[8];
 #pragma unroll
