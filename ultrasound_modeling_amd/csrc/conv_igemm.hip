@@ -363,6 +363,181 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
 #endif
 }
 
+// ---- persistent form for short K loops (plain mode, bias + activation + bf16 epilogue only) -----------------------------------
+// With 7-14 K steps per tile the prologue (row decode, first-stage latency) and the epilogue are 40 % of a workgroup's life.
+// Here a workgroup walks over pixel tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the stage ring runs on ACROSS tile
+// boundaries: the pieces of the next tile's first steps are in flight under the last MFMAs and the stores of the current one
+// (the issue side keeps its own tile's row constants; the compute side only needs the tile index again for the epilogue).
+template <int NT, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 16 * NT, BNP = BN < 32 ? 32 : BN;
+  constexpr int STAGE = (BM + BNP) * 128;
+  constexpr int A_IT = BM / 32, W_IT = BNP / 32;
+  constexpr int NI = A_IT + W_IT;
+  constexpr int D = NSTAGE - 1;
+  extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+  __shared__ __attribute__((aligned(16))) int s_tap4[32][4];   // dy, dx, da, dw
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 32) {
+    const int dy = p.tap_dy[tid], dx = p.tap_dx[tid];
+    s_tap4[tid][0] = dy;
+    s_tap4[tid][1] = dx;
+    s_tap4[tid][2] = (dy * p.Wi + dx) * p.ldx + p.tap_c[tid];
+    s_tap4[tid][3] = p.tap_w[tid] * p.cpt * 8;
+  }
+  const int n0 = blockIdx.y * BN;
+  const int HWg = p.Hg * p.Wg;
+  const int ntaps = p.ntaps;
+  const int ntile = (int)((p.M + BM - 1) / BM);
+  const int my_tiles = ((int)blockIdx.x < ntile) ? (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  if (my_tiles == 0) return;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
+
+  const int lrow = lane >> 3;
+  const int q = (lane & 7) ^ (((lane >> 4) + 4 * (wv & 1)) & 7);
+  int wrow[W_IT];
+  bool wok[W_IT];
+#pragma unroll
+  for (int it = 0; it < W_IT; ++it) {
+    const int n = 8 * (wv + 4 * it) + lrow;
+    wok[it] = n < BN && (n0 + n) < p.Nw;
+    wrow[it] = wok[it] ? (n0 + n) * p.Kw : 0;
+  }
+  const int nks = (ntaps * p.cpt + 7) / 8;
+  const int ti0 = q / p.cpt, c80 = q - ti0 * p.cpt;
+  const int adv_t = 8 / p.cpt, adv_c = 8 - adv_t * p.cpt;
+
+  // ---- issue side: the tile whose steps are being staged
+  int i_tile = 0, i_ks = 0, ti = ti0, c8 = c80;
+  int abase[A_IT], py[A_IT], px[A_IT];
+  bool pv[A_IT];
+  auto decode_rows = [&](int tile_no) {
+    const int64_t m0 = ((int64_t)blockIdx.x + (int64_t)tile_no * gridDim.x) * BM;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int64_t m = m0 + 8 * (wv + 4 * it) + lrow;
+      pv[it] = m < p.M;
+      const int mm = pv[it] ? (int)m : 0;
+      const int b = mm / HWg, rem = mm - b * HWg;
+      const int gy = rem / p.Wg, gx = rem - gy * p.Wg;
+      py[it] = gy * p.isy;
+      px[it] = gx * p.isx;
+      abase[it] = ((b * p.Hi + py[it]) * p.Wi + px[it]) * p.ldx;
+    }
+  };
+  decode_rows(0);
+  __syncthreads();  // tap table visible
+
+  auto issue = [&](int stage) {
+    char* const sb = lds_raw + stage * STAGE;
+    const bool tv = ti < ntaps;
+    int4 e = *reinterpret_cast<const int4*>(s_tap4[tv ? ti : 0]);
+    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));
+    const int da = e.z + c8 * 8, dw = e.w + c8 * 8;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int iy = py[it] + e.x, ix = px[it] + e.y;
+      const bool ok = tv & pv[it] & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (igemm_lds_ptr_t)(sb + (wv + 4 * it) * 1024), 16, ok ? (uint32_t)(abase[it] + da) * 2u : IGEMM_OOB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const bool ok = tv & wok[it];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (igemm_lds_ptr_t)(sb + BM * 128 + (wv + 4 * it) * 1024), 16, ok ? (uint32_t)(wrow[it] + dw) * 2u : IGEMM_OOB, 0, 0, 0);
+    }
+    ti += adv_t;
+    c8 += adv_c;
+    if (c8 >= p.cpt) { c8 -= p.cpt; ++ti; }
+    if (++i_ks == nks) {            // next step belongs to the next tile of this workgroup
+      i_ks = 0;
+      ti = ti0;
+      c8 = c80;
+      if (++i_tile < my_tiles) decode_rows(i_tile);
+    }
+  };
+
+  f32x4_t acc[2][NT];
+  const int frow = lane & 15, g = lane >> 4;
+  int a_off[2], w_off[NT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) a_off[a] = (wv * 32 + a * 16 + frow) * 128;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) w_off[b] = (BM + b * 16 + frow) * 128;
+  const int key = (frow >> 1) & 7;
+  const EpiArgs e = {nullptr, p.bias, nullptr, p.y, p.ldy, 0, p.Nout, p.act, p.alpha, 0, 0};
+  const int nbase = n0 + g * 4;
+  EpiConst<NT> ec;
+  epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
+
+  const int G = my_tiles * nks;
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < G) issue(s);
+  int c_ks = 0, c_tile = 0;
+  for (int gs = 0; gs < G; ++gs) {
+    // at most the pieces of the younger steps (and, right after a tile end, that tile's stores - younger still) outstanding
+    if (D >= 2 && gs + 1 < G) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (gs + D < G) issue((gs + D) % NSTAGE);
+    if (c_ks == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const char* const L = lds_raw + (gs % NSTAGE) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int sl = ((4 * kk + g) ^ key) << 4;
+      bf16x8_t xf[2], wf[NT];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) xf[a] = *reinterpret_cast<const bf16x8_t*>(L + a_off[a] + sl);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8_t*>(L + w_off[b] + sl);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    }
+    if (++c_ks < nks) continue;
+    c_ks = 0;
+    // ---- epilogue of this tile: no loads (bias in registers), the stores fly under the next tile's steps
+    const int64_t m0 = ((int64_t)blockIdx.x + (int64_t)c_tile * gridDim.x) * BM;
+    ++c_tile;
+    int64_t opix[2];
+    bool ovalid[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int64_t m = m0 + wv * 32 + a * 16 + frow;
+      ovalid[a] = m < p.M;
+      int mm = ovalid[a] ? (int)m : 0;
+      int b = mm / HWg;
+      int rem = mm - b * HWg;
+      int gy = rem / p.Wg;
+      int gx = rem - gy * p.Wg;
+      opix[a] = ((int64_t)(b * p.Ho + gy * p.osy + p.oay)) * p.Wo + gx * p.osx + p.oax;
+    }
+    conv_epilogue<2, NT, true>(e, ec, acc, opix, ovalid, nbase, 0);
+  }
+#endif
+}
+
+template <int NT, int NSTAGE>
+static void igemm_dma_persist_launch_t(const IgemmParams& p, dim3 grid, hipStream_t s) {
+  constexpr int BNP = 16 * NT < 32 ? 32 : 16 * NT;
+  const size_t dyn = (size_t)NSTAGE * (128 + BNP) * 128;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)igemm_dma_persist_kernel<NT, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((igemm_dma_persist_kernel<NT, NSTAGE>), grid, dim3(256), dyn, s, p);
+}
+
 template <int NT, int NSTAGE>
 static void igemm_dma_launch_t(const IgemmParams& p, dim3 grid, hipStream_t s) {
   constexpr int BNP = 16 * NT < 32 ? 32 : 16 * NT;
@@ -399,6 +574,20 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
     const int k_chunks = p.cls_mode ? 4 * p.cpt : p.ntaps * p.cpt;   // a parity class has up to four taps
     static const int dma_min = getenv("USSEG_IGEMM_DMA_MIN") ? atoi(getenv("USSEG_IGEMM_DMA_MIN")) : 4;
     if (dma && p.nb2 <= 0 && k_chunks >= dma_min && fits) {
+      // short K loops with several pixel tiles per resident workgroup slot: the persistent form
+      static const int persist = getenv("USSEG_IGEMM_PERSIST") ? atoi(getenv("USSEG_IGEMM_PERSIST")) : 1;
+      const int nks = (p.ntaps * p.cpt + 7) / 8;
+      const bool plain = !p.cls_mode && !p.res && !p.accumulate && !p.scale && !p.out_f32;
+      const int64_t slots_x = 512 / (int64_t)gy;      // two workgroups per CU resident
+      if (persist && plain && nks <= 16 && slots_x >= 32 && gx >= 2 * slots_x) {
+        const dim3 pgrid((unsigned)slots_x, gy, 1);
+        if (nt == 1) igemm_dma_persist_launch_t<1, 3>(p, pgrid, s);
+        else if (nt == 2) igemm_dma_persist_launch_t<2, 3>(p, pgrid, s);
+        else if (nt == 4) igemm_dma_persist_launch_t<4, 3>(p, pgrid, s);
+        else igemm_dma_persist_launch_t<8, 2>(p, pgrid, s);
+        usseg_prof_stop(1, slot, s);
+        return usseg_check_launch("igemm_dma_persist");
+      }
       if (nt == 1) igemm_dma_launch_t<1, 3>(p, grid, s);
       else if (nt == 2) igemm_dma_launch_t<2, 3>(p, grid, s);
       else if (nt == 4) igemm_dma_launch_t<4, 3>(p, grid, s);
