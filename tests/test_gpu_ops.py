@@ -139,6 +139,37 @@ def test_conv_stream(gen, monkeypatch, B, H, W, Cin, Cout, dil, wgx):
     assert rel(dx[..., :Cin], bf(xr.grad)) < 2 * REL_BF16
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,dil", [(2, 32, 32, 256, 64, 1), (1, 32, 16, 40, 64, 1), (2, 16, 16, 72, 136, 2), (3, 16, 16, 96, 40, 4),
+                                                (5, 8, 8, 64, 24, 1), (2, 64, 64, 128, 16, 2)])
+def test_conv_big_eight_wave_tile(gen, monkeypatch, B, H, W, Cin, Cout, dil):
+    """conv_big's 256-pixel tile on eight waves (forced: the planner only picks it for large launches) against the oracle and
+    against the four-wave tiles, forward and backward-data."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    layer = Conv2D(Cin, Cout, 3, dil)
+    w = rnd(gen, 3, 3, Cin, Cout, scale=1.0 / math.sqrt(9 * Cin))
+    b = rnd(gen, Cout, scale=0.5)
+    layer.kernel.data.copy_(w)
+    layer.bias.data.copy_(b)
+    finalize(layer)
+    x = rnd(gen, B, H, W, Cin)
+    xd = to_dev_padded(x)
+    ref = O.conv2d_same(x, w, b, dil)
+    dy = rnd(gen, B, H, W, Cout)
+    xr = x.clone().requires_grad_(True)
+    (O.conv2d_same(xr, w, b, dil) * dy).sum().backward()
+    outs = []
+    for mode in ("2", "0"):
+        monkeypatch.setenv("USSEG_BIG_W8", mode)
+        y = layer.forward(xd, act=ops.ACT_LRELU, alpha=0.3)
+        dx = layer.backward(to_dev_padded(dy), skip_wgrad=True)
+        torch.cuda.synchronize()
+        assert rel(y[..., :Cout], bf(O.leaky_relu(ref))) < REL_BF16
+        assert rel(dx[..., :Cin], bf(xr.grad)) < 2 * REL_BF16
+        outs.append((y.clone(), dx.clone()))
+    assert rel(outs[0][0], outs[1][0]) < 2e-3 and rel(outs[0][1], outs[1][1]) < 2e-3
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,dil", CONV_CASES)
 def test_conv2d_fwd_dgrad_wgrad(gen, B, H, W, Cin, Cout, k, dil):
     from ultrasound_modeling_amd import ops

@@ -41,14 +41,17 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // between pointers).  OOB_OFF stays out of range after a chunk offset (< 64 KB) is added.
 #define OOB_OFF 0x80000000u
 
-template <int NT, int NS>   // NS = 16-pixel strips per wave: workgroup tile = 64*NS pixels x 16*NT channels
-__global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
+// NS = 16-pixel strips per wave, NW = waves: workgroup tile = 16*NS*NW pixels x 16*NT channels.  NW = 8 with NS = 2 is the
+// 256-pixel tile run by eight waves: the weight stage (18-36 KB per 32-channel chunk, the larger half of what a 128-pixel
+// workgroup moves through the ~33 B/clk L2->LDS path) is shared by twice the pixels while the CU keeps the same number of waves.
+template <int NT, int NS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
   constexpr int BN = 16 * NT;
   constexpr int W_BYTES = 9 * BN * 64;
   constexpr int NPW = 9 * BN / 16;            // W pieces per stage
-  constexpr int W_IT = (NPW + 3) / 4;
-  constexpr int A_IT = NS == 4 ? 9 : 5;       // A pieces per wave: halo tile <= 576 (NS=4) / 288 (NS=2) pixels
+  constexpr int W_IT = (NPW + NW - 1) / NW;
+  constexpr int A_IT = ((NS * NW == 16 ? 36 : 18) + NW - 1) / NW;   // A pieces per wave: halo tile <= 576 (256-pixel tile) / 288 pixels
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const BigJob& p = P.job[blockIdx.z];
   if ((int)blockIdx.x >= p.gx || (int)blockIdx.y >= p.gy) return;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
   uint32_t a_off[A_IT], w_off[W_IT];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    const int hp = 16 * (wv + 4 * it) + (lane >> 2);
+    const int hp = 16 * (wv + NW * it) + (lane >> 2);
     uint32_t off = OOB_OFF;
     if (hp < NHP) {
       int pi = hp / HPP, rem = hp - pi * HPP;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
   }
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) {
-    const int row = 16 * (wv + 4 * it) + (lane >> 2);   // t*BN + n
+    const int row = 16 * (wv + NW * it) + (lane >> 2);   // t*BN + n
     uint32_t off = OOB_OFF;
     if (row < 9 * BN) {
       int t = row / BN, n = row - t * BN;
@@ -104,14 +107,14 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const BigParams P) {
     const bool cok = ck * 32 + cq < p.Cin;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      const int j = wv + 4 * it;
+      const int j = wv + NW * it;
       if (j < p.npa) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(abuf + j * 1024), 16, cok ? a_off[it] + cb : OOB_OFF, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
-      const int j = wv + 4 * it;
+      const int j = wv + NW * it;
       if (j < NPW) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wbuf + j * 1024), 16, cok ? w_off[it] + cb : OOB_OFF, 0, 0, 0);
       }
@@ -382,17 +385,17 @@ static int big_fill_job(BigJob& p, const bf16_t* x, const bf16_t* w, void* y, co
 
 static int nt_for(int nout) { return nout <= 16 ? 1 : (nout <= 32 ? 2 : 4); }
 
-template <int NT, int NS>
+template <int NT, int NS, int NW = 4>
 static void big_launch_t(const BigParams& P, dim3 grid, size_t dyn, hipStream_t s) {
   static bool attr_done = false;   // > 64 KB of LDS per workgroup needs the opt-in (one-time host call, never a stream op)
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_big_kernel<NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_big_kernel<NT, NS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_big_kernel<NT, NS>), grid, dim3(256), dyn, s, P);
+  hipLaunchKernelGGL((conv_big_kernel<NT, NS, NW>), grid, dim3(64 * NW), dyn, s, P);
 }
 
-static void big_launch(BigParams& P, int njobs, int nt, int PX, hipStream_t s) {
+static void big_launch(BigParams& P, int njobs, int nt, int PX, hipStream_t s, int w8 = 0) {
   int gx = 0, gy = 0, npa = 0;
   for (int j = 0; j < njobs; ++j) {
     BigJob& p = P.job[j];
@@ -408,7 +411,11 @@ static void big_launch(BigParams& P, int njobs, int nt, int PX, hipStream_t s) {
   const size_t dyn = nstages * ((size_t)npa * 1024 + (size_t)9 * 16 * nt * 64);
   const dim3 grid(gx, gy, njobs);
   const int slot = usseg_prof_start(1, s);
-  if (PX == 256) {
+  if (PX == 256 && w8) {          // 256-pixel tile on eight waves (two strips each)
+    if (nt == 1) big_launch_t<1, 2, 8>(P, grid, dyn, s);
+    else if (nt == 2) big_launch_t<2, 2, 8>(P, grid, dyn, s);
+    else big_launch_t<4, 2, 8>(P, grid, dyn, s);
+  } else if (PX == 256) {
     if (nt == 1) big_launch_t<1, 4>(P, grid, dyn, s);
     else if (nt == 2) big_launch_t<2, 4>(P, grid, dyn, s);
     else big_launch_t<4, 4>(P, grid, dyn, s);
@@ -535,6 +542,24 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
     }
   }
   if (!best_px || (best_wg < min_wg && !(px_env || nt_env))) return 0;
+  // 128-pixel plan: if the 256-pixel tiling fits too and still leaves enough workgroups, run it on eight waves - the same
+  // waves per CU, half the weight-stage traffic (read per call: the parity tests force it with USSEG_BIG_W8=2)
+  int w8 = 0;
+  {
+    const char* w8e = getenv("USSEG_BIG_W8");
+    const int w8_mode = w8e ? atoi(w8e) : 1;
+    static const int w8_min = getenv("USSEG_BIG_W8_MIN") ? atoi(getenv("USSEG_BIG_W8_MIN")) : 256;
+    if (w8_mode && best_px == 128) {
+      bool ok = true;
+      int64_t wg = 0;
+      for (int j = 0; j < njobs && ok; ++j) {
+        ok = big_fill_job(P.job[j], g[j].x, g[j].w, g[j].y, g[j].bias, g[j].res, g[j].B, g[j].H, g[j].W, g[j].d, g[j].Cin, g[j].ldx, g[j].Nout,
+                          g[j].ldy, g[j].ldr, g[j].Nw, g[j].Kw, g[j].act, g[j].alpha, g[j].out_f32, g[j].accumulate, g[j].flip, 256);
+        if (ok) wg += (int64_t)P.job[j].gx * ((P.job[j].Nout + 16 * best_nt - 1) / (16 * best_nt));
+      }
+      if (ok && (wg >= w8_min || w8_mode == 2)) { w8 = 1; best_px = 256; }
+    }
+  }
   for (int j = 0; j < njobs; ++j)
     if (!big_fill_job(P.job[j], g[j].x, g[j].w, g[j].y, g[j].bias, g[j].res, g[j].B, g[j].H, g[j].W, g[j].d, g[j].Cin, g[j].ldx, g[j].Nout,
                       g[j].ldy, g[j].ldr, g[j].Nw, g[j].Kw, g[j].act, g[j].alpha, g[j].out_f32, g[j].accumulate, g[j].flip, best_px))
@@ -547,7 +572,7 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
     P.job[0].mask_ch = usseg_tap_mask.group_ch;
     for (int c = 0; c < 4; ++c) P.job[0].tapmask[c] = usseg_tap_mask.mask[c];
   }
-  big_launch(P, njobs, best_nt, best_px, s);
+  big_launch(P, njobs, best_nt, best_px, s, w8);
   return 1;
 }
 
