@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round's committed evidence on a GPU box: kernel stats, PMC traffic, bench JSON.  usage: bash tools/profile_round.sh <tag>
 set -e
-TAG=${1:-r01_v12}
+TAG=${1:-r01_v13}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_$TAG -o r --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > gpurun_out/stats_$TAG.log 2>&1
