@@ -548,7 +548,7 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
   {
     const char* w8e = getenv("USSEG_BIG_W8");
     const int w8_mode = w8e ? atoi(w8e) : 1;
-    static const int w8_min = getenv("USSEG_BIG_W8_MIN") ? atoi(getenv("USSEG_BIG_W8_MIN")) : 256;
+    static const int w8_min = getenv("USSEG_BIG_W8_MIN") ? atoi(getenv("USSEG_BIG_W8_MIN")) : 128;
     if (w8_mode && best_px == 128) {
       bool ok = true;
       int64_t wg = 0;
@@ -557,7 +557,9 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
                           g[j].ldy, g[j].ldr, g[j].Nw, g[j].Kw, g[j].act, g[j].alpha, g[j].out_f32, g[j].accumulate, g[j].flip, 256);
         if (ok) wg += (int64_t)P.job[j].gx * ((P.job[j].Nout + 16 * best_nt - 1) / (16 * best_nt));
       }
-      if (ok && (wg >= w8_min || w8_mode == 2)) { w8 = 1; best_px = 256; }
+      // measured: it pays with the 64-channel tile (36 KB weight stage); with the narrower tiles the planner falls back to
+      // when workgroups are scarce, the halved workgroup count costs more than the shared stage saves
+      if (ok && ((wg >= w8_min && best_nt == 4) || w8_mode == 2)) { w8 = 1; best_px = 256; }
     }
   }
   for (int j = 0; j < njobs; ++j)
