@@ -243,8 +243,12 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   const int tbase = cls * 4;
   const int ntaps = p.cls_mode ? (int)p.cls_ntaps[cls] : p.ntaps;
   const int oay = p.cls_mode ? (cls >> 1) : p.oay, oax = p.cls_mode ? (cls & 1) : p.oax;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
+  // batched GEMM (attention): blockIdx.z = b1*nb2 + b2 selects the operand bases (never together with the parity classes)
+  const int bz = (!p.cls_mode && p.nb2 > 0) ? (int)blockIdx.z : 0;
+  const int bz1 = p.nb2 > 0 ? bz / p.nb2 : 0, bz2 = p.nb2 > 0 ? bz - bz1 * p.nb2 : 0;
+  const int64_t ybatch = bz1 * p.ys1 + bz2 * p.ys2;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + bz1 * p.xs1 + bz2 * p.xs2), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + bz1 * p.ws1 + bz2 * p.ws2), 0, 0x7fffffff, 0x00020000);
 
   // ---- this lane's pieces: row (lane / 8) of piece wv + 4*it, chunk column q (fixed: see the layout note)
   const int lrow = lane >> 3;
@@ -358,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   epi_const_load<NT>(ec, p.bias, nbase, p.Nout);
   static_assert(4 * epi_lds_bytes<2, NT>() <= NSTAGE * STAGE, "the transposing epilogue reuses the stage ring");
   __syncthreads();   // every wave is done with the last stage
-  if (!conv_epilogue_lds<2, NT>(lds_raw + wv * epi_lds_bytes<2, NT>(), e, ec, acc, opix, ovalid, n0, lane))
-    conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase, 0);
+  if (!conv_epilogue_lds<2, NT>(lds_raw + wv * epi_lds_bytes<2, NT>(), e, ec, acc, opix, ovalid, n0, lane, ybatch))
+    conv_epilogue<2, NT>(e, ec, acc, opix, ovalid, nbase, ybatch);
 #endif
 }
 
@@ -573,11 +577,13 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
     const bool fits = nb * p.Hi * p.Wi * p.ldx * 2 < 0x7fff0000ll && (int64_t)p.Nw * p.Kw * 2 < 0x7fff0000ll;
     const int k_chunks = p.cls_mode ? 4 * p.cpt : p.ntaps * p.cpt;   // a parity class has up to four taps
     static const int dma_min = getenv("USSEG_IGEMM_DMA_MIN") ? atoi(getenv("USSEG_IGEMM_DMA_MIN")) : 4;
-    if (dma && p.nb2 <= 0 && k_chunks >= dma_min && fits) {
+    static const int dma_batched = getenv("USSEG_IGEMM_DMA_BATCHED") ? atoi(getenv("USSEG_IGEMM_DMA_BATCHED")) : 1;
+    const bool bat_ok = p.nb2 <= 0 || (dma_batched && !p.cls_mode && (p.xs1 | p.xs2 | p.ws1 | p.ws2) % 8 == 0);   // 16-byte aligned batch bases
+    if (dma && bat_ok && k_chunks >= dma_min && fits) {
       // short K loops with several pixel tiles per resident workgroup slot: the persistent form
       static const int persist = getenv("USSEG_IGEMM_PERSIST") ? atoi(getenv("USSEG_IGEMM_PERSIST")) : 1;
       const int nks = (p.ntaps * p.cpt + 7) / 8;
-      const bool plain = !p.cls_mode && !p.res && !p.accumulate && !p.scale && !p.out_f32;
+      const bool plain = !p.cls_mode && p.nb2 <= 0 && !p.res && !p.accumulate && !p.scale && !p.out_f32;
       const int64_t slots_x = 512 / (int64_t)gy;      // two workgroups per CU resident
       if (persist && plain && nks <= 16 && slots_x >= 32 && gx >= 2 * slots_x) {
         const dim3 pgrid((unsigned)slots_x, gy, 1);
