@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
   extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t = (int)blockIdx.z;
+  // batched form (attention): blockIdx.z = b1*nb2 + b2 selects the operand / output bases instead of the tap
+  const int t = p.nb2 > 0 ? 0 : (int)blockIdx.z;
+  const int bz1 = p.nb2 > 0 ? (int)blockIdx.z / p.nb2 : 0, bz2 = p.nb2 > 0 ? (int)blockIdx.z - bz1 * p.nb2 : 0;
   const int mt = blockIdx.y / p.ntiles, nt = blockIdx.y - mt * p.ntiles;
   const int m0 = mt * BT, n0 = nt * BT;
   const int64_t k_begin = (int64_t)blockIdx.x * p.chunk;
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
   const int ady = p.ady[t], adx = p.adx[t], bdy = p.bdy[t], bdx = p.bdx[t];
   const int HWg = p.Hg * p.Wg;
 
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + bz1 * p.as1 + bz2 * p.as2), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + bz1 * p.bs1 + bz2 * p.bs2), 0, 0x7fffffff, 0x00020000);
 
   // ---- this lane's DMA pieces: row lrow of instruction wv + 4*it, one fixed 16-byte channel slot
   const int lrow = TM == 1 ? (lane >> 3) : (lane >> 4);
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
   }
 
   // lane holds D[n_local = 4g + r][m_local = li] of each tile: 16 bytes of the slab, or four atomics into the (mapped) gradient
-  float* out = p.out + (int64_t)t * p.Ma * p.Nb;
+  float* out = p.out + (int64_t)t * p.Ma * p.Nb + bz1 * p.os1 + bz2 * p.os2;
   float* slab = p.ws ? p.ws + ((int64_t)blockIdx.x * p.ntaps + t) * p.Ma * p.Nb : nullptr;
   const bool vec_ok = (p.Nb & 3) == 0;
 #pragma unroll
@@ -499,9 +501,15 @@ extern "C" int usseg_gemm_tn_batched(const UssegGemmDesc* d, const void* a, cons
   p.nb2 = d->nb2; p.as1 = d->xs1; p.as2 = d->xs2; p.bs1 = d->ws1; p.bs2 = d->ws2; p.os1 = d->ys1; p.os2 = d->ys2;
   p.mtiles = (p.Ma + 63) / 64;
   p.ntiles = (p.Nb + 63) / 64;
-  p.chunk = ((d->K + 31) / 32) * 32;                     // one split: the batch already fills the chip
+  p.chunk = ((d->K + 63) / 64) * 64;                     // one split: the batch already fills the chip
+  p.ntaps = 1;
   const int slot = usseg_prof_start(2, (hipStream_t)stream);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(1, (unsigned)(p.mtiles * p.ntiles), (unsigned)(d->nb1 * d->nb2)), dim3(256), 0, (hipStream_t)stream, p);
+  static const int dma_env = getenv("USSEG_WGRAD_DMA") ? atoi(getenv("USSEG_WGRAD_DMA")) : 1;
+  const bool dma = dma_env && d->K < (1 << 24) && (int64_t)d->K * d->ldx * 2 < 0x7fff0000ll && (int64_t)d->K * d->ldw * 2 < 0x7fff0000ll &&
+                   (d->xs1 | d->xs2 | d->ws1 | d->ws2) % 8 == 0;
+  const dim3 grid(1, (unsigned)(p.mtiles * p.ntiles), (unsigned)(d->nb1 * d->nb2));
+  if (dma) wgrad_dma_launch_t<1, 3>(p, grid, (hipStream_t)stream);
+  else hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   usseg_prof_stop(2, slot, (hipStream_t)stream);
   return usseg_check_launch("gemm_tn_batched");
 }
