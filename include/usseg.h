@@ -9,8 +9,14 @@
  *
  * Contract (all functions)
  *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
- *  - the caller owns every buffer, including workspaces; the library allocates nothing, keeps no
- *    global mutable state except a thread-local error string, never synchronises and never throws;
+ *  - the caller owns every buffer, including workspaces; the library allocates no device memory,
+ *    never synchronises and never throws.  Process-wide host state it does keep (one process per GPU,
+ *    one host thread per device - the threading model of this repo): a thread-local error string;
+ *    the queue of deferred finishing reductions of every stream between usseg_defer_begin() and
+ *    usseg_defer_end() (defer.hip); the opt-in launch timer of usseg_prof_* (runtime.hip); and the
+ *    USSEG_* planner switches, each read from the environment once per process;
+ *  - one producer per destination between two flushes is NOT required: deferred finishes that share a
+ *    destination are issued as separate, stream-ordered launches (defer.hip);
  *  - all work is enqueued on the hipStream_t passed in (graph-capture safe);
  *  - return value: 0 on success, negative UssegStatus on error (usseg_last_error() has the text).
  *
@@ -337,8 +343,21 @@ typedef struct UssegLossDesc {
                            [B][H/2][W/2][16] that the 2x2-tap form of the stride-2 head produces, pixel (y,x) in slot
                            4*((y&1)*2+(x&1)) (ldl = lddl = 16, C <= 4).  probs and y_true are always [M][C]. */
 } UssegLossDesc;
+/* Reproducible scalar accumulators (loss of loss_kind 0, usseg_sumsq): the pointer names USSEG_ACC_FLOATS floats -
+ * [0] the running result, [1] a ticket counter (zero between calls), [2..] one partial per workgroup; the last workgroup to
+ * arrive adds the partials in workgroup order, so no float atomics and the same bits on every run.  Zero the whole buffer
+ * once; afterwards zeroing [0] is enough.  The loss map of loss_kind 1 is [HW] floats, each pixel owned by one thread. */
+#define USSEG_ACC_FLOATS 2050
 int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, const float* y_true, const float* scale,
                                float* probs, float* loss, void* dlogits, usseg_stream_t stream);
+/* The same two losses evaluated on PROBABILITIES, as the reference's public methods take them:
+ * loss_kind 0 = VisionTransformer.compute_loss(y_true, y_pred) (VisionTransformer.py:225-227: Keras normalises the
+ * probabilities by their class sum, clips to [clip_eps, 1-clip_eps], -sum_c y_smoothed*log p, summed / global batch into *loss);
+ * loss_kind 1 = ResNest.my_loss_cat(y_true, y_pred) (TBI_ResNest.py:234-248: loss map [HW] -= y*log(p+1e-7)*scale[hw][c]).
+ * probs, y_true fp32 [M][C]; only M, HW, C, loss_kind, label_smoothing, clip_eps, inv_global_batch of the descriptor are read.
+ * loss must be zeroed by the caller (it accumulates). */
+int usseg_loss_from_probs(const UssegLossDesc* d, const float* probs, const float* y_true, const float* scale, float* loss,
+                          usseg_stream_t stream);
 /* The <= 4-class head Conv2DTranspose(k x k, stride 2, 'same') (Decoder.py:120 k=3; TBI_ResNest.py:124 k=4) in "quad" form: a
  * stride-1 convolution at the INPUT resolution whose 16 output channels are (output parity class)*4 + n, run by
  * usseg_conv2d_fwd/dgrad/wgrad as a 3x3 conv (each parity uses <= 2x2 of the stencil taps, the rest are zero).  With
@@ -394,7 +413,8 @@ int usseg_augment(const UssegAugDesc* d, const UssegAugSample* samples_dev, cons
 int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, float* ws, usseg_stream_t stream);
 
 /* ---- optimiser: tf.clip_by_global_norm(1.0) + Adam (VisionTransformer.py:204,244-245; TBI_ResNest.py:28,46)
- * sumsq: *out += sum g^2 over n floats (zeroed by caller).
+ * sumsq: out[0] += sum g^2 over n floats.  `out` is a USSEG_ACC_FLOATS accumulator (zeroed by the caller once; see below),
+ *        so the sum - and with it the clip factor of every update - is bitwise reproducible from run to run.
  * adam:  scale = clip_norm > 0 ? clip_norm / max(sqrt(*sumsq), clip_norm) : 1;  g' = g*scale*grad_scale;
  *        Keras Adam with bias-corrected lr_t (host-computed from the device step counter is avoided: the caller
  *        passes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) through a device scalar so a captured graph can be replayed). */

@@ -187,7 +187,7 @@ def test_folded_batchnorm_matches_unfused():
             dh, df = net.decoder.backward(dl)
             net.transformer.backward(dh, df)
         torch.cuda.synchronize()
-        out.append((net._loss.item(), probs.clone(), net.flat.grad.clone()))
+        out.append((net._loss[0].item(), probs.clone(), net.flat.grad.clone()))
     D._FOLD_BN = R._FOLD_BN = False
     (l0, p0, g0), (l1, p1, g1) = out
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()

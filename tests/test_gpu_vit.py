@@ -93,3 +93,45 @@ def test_vit_block_alone():
     e_o, e_w, e_dx = rel(out.reshape(B, N, 512), out_r.detach()), rel(w, w_r.detach()), rel(dx.reshape(B, N, 512), xr.grad)
     print(f"block alone: out rel {e_o:.3e} weights rel {e_w:.3e} dx rel {e_dx:.3e}")
     assert e_o < 1e-2 and e_w < 2e-2 and e_dx < 3e-2
+
+
+def test_vit_block_parameter_gradients_with_split_k():
+    """B*N = 1024 rows: the Q/K/V projection's weight gradient is split over K and, inside the model's backward
+    (``ops.overlap_region``), its finishing reduction is DEFERRED - the three Dense kernels must still receive their
+    gradients (they were lost when the fused gradient went through a shared scratch buffer).  Every parameter gradient of
+    the block is compared with the oracle, tensor by tensor."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.flat import FlatParams
+    from ultrasound_modeling_amd.VisionTransformer import Block
+    gen = torch.Generator().manual_seed(6)
+    bld = O._Builder(6, torch.float64)
+    O.init_vit_params(bld, "", layers=1, perturb=True)
+    P = {k: v.to(torch.bfloat16).double() if k.endswith("kernel") else v.float().double() for k, v in bld.P.items()}
+    blk = Block()
+    fp = FlatParams(blk, DEV)
+    own = dict(blk.named_parameters())
+    for k, t in own.items():
+        t.data.copy_(P["Transformer_layers.0." + k].float().reshape(t.shape))
+    blk.attn.on_finalize(DEV)
+    for m in blk.modules():
+        if hasattr(m, "wp_f") and m.wp_f is not None:
+            m.repack()
+    B, N = 8, 128
+    x = (torch.randn(B, N, 512, generator=gen, dtype=torch.float64) * 0.7).to(torch.bfloat16).double()
+    dy = (torch.randn(B, N, 512, generator=gen, dtype=torch.float64) * 0.1).to(torch.bfloat16).double()
+    names = ["Transformer_layers.0." + k for k in own]
+    leaves = [P[n].clone().requires_grad_(True) for n in names]
+    Pl = dict(P)
+    Pl.update(zip(names, leaves))
+    out_r, _ = O.vit_block(x, Pl, "Transformer_layers.0.")
+    g_r = dict(zip(own, torch.autograd.grad((out_r * dy).sum(), leaves)))
+    fp.zero_grad()
+    blk.forward(x.to(torch.bfloat16).to(DEV).reshape(B, N, 1, 512))
+    with ops.overlap_region():
+        blk.backward(dy.to(torch.bfloat16).to(DEV).reshape(B, N, 1, 512))
+    torch.cuda.synchronize()
+    errs = {k: rel(own[k].grad.reshape(g_r[k].shape), g_r[k]) for k in own if not k.endswith("attn.key.bias")}
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    for k in ("attn.query.kernel", "attn.key.kernel", "attn.value.kernel", "attn.out.kernel", "ffn.fc1.kernel", "ffn.fc2.kernel"):
+        assert errs[k] < 2e-2, (k, errs[k])      # bf16 activations between the block's ten GEMMs; a dropped gradient is an error of 1.0
+    assert max(errs.values()) < 5e-2, max(errs.items(), key=lambda kv: kv[1])

@@ -26,6 +26,7 @@ from .flat import AdamClip, FlatParams
 from .layers import (KERAS_BN_EPS, KERAS_ELU_ALPHA, AveragePooling2D, BatchNormalization, Conv2D, Conv2DTranspose, QuadHead, QuadTConv,
                      _Workspace)
 from .ops import ACT_ELU, ACT_NONE, ACT_RELU, BF16, roundup
+from .step import TrainStepDriver
 
 
 def _span(t: torch.Tensor, n: int) -> torch.Tensor:
@@ -268,7 +269,8 @@ class _ResModel(nn.Module):
                 object.__setattr__(self, "_qt_" + name, QuadTConv(getattr(self, name + "_t_conv")))
                 self._qt[name] = getattr(self, "_qt_" + name)
         self._stages = None
-        self.dropout_seed = 0
+        self.dropout_seed = 0           # model-level seed of the always-on dropout masks
+        self._eval_salt = 0             # 0 inside training steps; the wrapper numbers evaluation calls
         self.injected_masks = None      # tests inject {0,1} keep masks to make the always-on dropout deterministic
 
     # grouped-kernel plumbing -----------------------------------------------------------------------------------
@@ -317,9 +319,11 @@ class _ResModel(nn.Module):
         if self.injected_masks is not None:
             m = self.injected_masks[i]
             return None if m is None else m
+        # tf.nn.dropout(out, 0.5), :216.  The mask is a pure function of (model seed, layer, the optimiser's DEVICE step counter,
+        # evaluation-call number): the eager step t and the HIP-graph replay of step t draw the same mask, successive steps and
+        # successive evaluation calls draw fresh ones
         mask = torch.empty_like(like)
-        self.dropout_seed += 1
-        return ops.dropout_mask(mask, self.dropout_seed * 7919 + i, 0.5, getattr(self, "step_dev", None))   # tf.nn.dropout(out, 0.5), :216
+        return ops.dropout_mask(mask, (self.dropout_seed * 1000003 + self._eval_salt) * 7919 + i, 0.5, getattr(self, "step_dev", None))
 
     def forward(self, x, return_logits=False):
         if x.dtype != BF16:
@@ -407,7 +411,7 @@ class _ResModel(nn.Module):
         return ops.tconv2d_dgrad(dy, layer.wp_d, layer.k, ops.new_act(B, H, W, layer.cin_p, dy.device))
 
 
-class ResNest:
+class ResNest(TrainStepDriver):
     """TBI_ResNest.py:15-55.  ``step(x, y, train)`` -> (loss map [H,W], accuracy, probabilities)."""
 
     def __init__(self, height, width, channel, num_class, ksize, radix=4, kpaths=4, learning_rate=1e-3, ckpt_dir="./Checkpoint", *,
@@ -431,6 +435,7 @@ class ResNest:
         self.grad_sync = None
         self._graph = None
         self.resModel.step_dev = self.optimizer.step_dev      # dropout masks follow the device step counter (graph replays)
+        object.__setattr__(self.resModel, "save", self.save_params)     # the driver calls neuralnet.resModel.save(path) (TBI_ResNest.py:472)
 
     # parameters in / out under the Keras layer names ------------------------------------------------------------------
     def load_params(self, params: dict):
@@ -462,96 +467,99 @@ class ResNest:
     def export_grads(self) -> dict:
         return {k: v.grad.detach().clone() for k, v in self.resModel.named_parameters()}
 
+    def save_params(self, path=None):
+        """TBI_ResNest.py:57-66 (a tf.train.CheckpointManager there, broken as committed): variables, BN statistics and the
+        optimiser state in one file."""
+        path = path or os.path.join(self.ckpt_dir, "usseg_arch_a.pt")
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        d = self.export_params()
+        d.update(self.optimizer.state_dict())
+        torch.save(d, path)
+        return path
+
+    def load_params_file(self, path=None):
+        """TBI_ResNest.py:68-78 ``load_params``: restore what ``save_params`` wrote."""
+        d = torch.load(path or os.path.join(self.ckpt_dir, "usseg_arch_a.pt"), map_location="cpu", weights_only=True)
+        self.optimizer.load_state_dict({k: d.pop(k) for k in list(d) if k.startswith("__adam_")})
+        self.load_params(d)
+
     def my_loss_cat(self, y_true, y_pred):
-        raise NotImplementedError("fused with the head softmax (usseg_softmax_loss_fwd_bwd, loss_kind=1); use step()")
+        """TBI_ResNest.py:234-248 on PROBABILITIES: per class c, scale[h,w] = 1/(sum_b y[b,h,w,c] + 1)/(H*W);
+        -sum_{b,c} y*log(p+1e-7)*scale -> the [H,W] loss map.  (step() uses the kernel fused with the head softmax.)"""
+        y_true, y_pred = self._prep_y(y_true), self._prep_y(y_pred)
+        B, H, W, Cc = y_pred.shape
+        scale = torch.empty(H * W * Cc, dtype=torch.float32, device=self.device)
+        loss = torch.empty(H * W, dtype=torch.float32, device=self.device)
+        ops.loss_cat_scale(y_true, scale)
+        ops.fill_f32(loss, 0.0)
+        ops.loss_from_probs(y_pred, y_true, loss, HW=H * W, C_classes=Cc, loss_kind=1, scale=scale)
+        return loss.reshape(H, W)
 
-    # ---- HIP-graph replay of the training step (as VisionTransformer.capture_graph): one graph, or two around the all-reduce
-    def _grad_body(self, x, y):
-        net = self.resModel
+    # ---- hooks of the shared step order (step.TrainStepDriver); the step is also capturable as HIP graph(s)
+    def _prep_x(self, x):
+        return torch.as_tensor(x).to(self.device).contiguous()
+
+    def _prep_y(self, y):
+        return torch.as_tensor(y).to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _zero_grad(self):
         self.flat.zero_grad()
-        logits = net.forward(x, return_logits=True)
-        B, (H, W), qw = logits.shape[0], net.out_hw, net.quad_w
-        probs = torch.empty((B, H, W, self.num_class), dtype=torch.float32, device=self.device)
-        dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device, zero=True) if qw else ops.new_act(B, H, W, 8, self.device)
-        ops.loss_cat_scale(y, self._scale)
-        ops.fill_f32(self._loss_map, 0.0)
-        ops.softmax_loss(logits, y, probs, self._loss_map, dlogits, HW=H * W, C_classes=self.num_class, loss_kind=1, scale=self._scale, quad_w=qw)
-        with ops.overlap_region():
-            net.backward(dlogits)
-        return probs
 
-    def _update_body(self):
-        self.optimizer.apply()
-        self.resModel.repack()
-
-    def capture_graph(self, x, y, warmup: int = 2):
-        x = torch.as_tensor(x).to(self.device).contiguous()
-        y = torch.as_tensor(y).to(device=self.device, dtype=torch.float32).contiguous()
-        self._gx, self._gy = x.clone(), y.clone()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                self._grad_body(self._gx, self._gy)
-                self._update_body()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        g1 = torch.cuda.CUDAGraph()
-        if self.grad_sync is None:
-            with torch.cuda.graph(g1):
-                self._gprobs = self._grad_body(self._gx, self._gy)
-                self._update_body()
-            self._graph = (g1, None)
-        else:
-            with torch.cuda.graph(g1):
-                self._gprobs = self._grad_body(self._gx, self._gy)
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                self._update_body()
-            self._graph = (g1, g2)
-
-    def _graph_step(self, x, y):
-        self._gx.copy_(x)
-        self._gy.copy_(y)
-        g1, g2 = self._graph
-        g1.replay()
-        if g2 is not None:
-            self.grad_sync(self.flat.grad)
-            g2.replay()
-        H, W = self.height, self.width
-        probs = self._gprobs
-        accuracy = (probs.argmax(dim=-1) == self._gy.argmax(dim=-1)).float().mean()
-        return self._loss_map.clone().reshape(H, W), accuracy, probs
-
-    def step(self, x, y, train=False):
-        """TBI_ResNest.py:35-55."""
-        x = torch.as_tensor(x).to(self.device).contiguous()
-        y = torch.as_tensor(y).to(device=self.device, dtype=torch.float32).contiguous()
-        if train and self._graph is not None:
-            return self._graph_step(x, y)
+    def _forward_loss(self, x, y, with_grad: bool):
         net = self.resModel
-        if train:
-            self.flat.zero_grad()
+        if with_grad:
+            net._eval_salt = 0
+        else:
+            self._eval_calls = getattr(self, "_eval_calls", 0) + 1
+            net._eval_salt = self._eval_calls
         logits = net.forward(x, return_logits=True)                                            # :40
         B, (H, W), qw = logits.shape[0], net.out_hw, net.quad_w
         probs = torch.empty((B, H, W, self.num_class), dtype=torch.float32, device=self.device)
         dlogits = None
-        if train:
+        if with_grad:
             dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device, zero=True) if qw else ops.new_act(B, H, W, 8, self.device)
         ops.loss_cat_scale(y, self._scale)                                                     # :240-241
         ops.fill_f32(self._loss_map, 0.0)
         ops.softmax_loss(logits, y, probs, self._loss_map, dlogits, HW=H * W, C_classes=self.num_class, loss_kind=1,
                          scale=self._scale, quad_w=qw)                                         # :125, :234-248
-        if train:
-            with ops.overlap_region():          # deferred / batched finishing reductions of the norm backward and bias sums
-                net.backward(dlogits)                                                          # :43 (gradient of the SUM of the map)
-            if self.grad_sync is not None:
-                self.grad_sync(self.flat.grad)
-            self.optimizer.apply()                                                             # :46
-            net.repack()
+        return probs, dlogits
+
+    def _forward_backward(self, x, y):
+        probs, dlogits = self._forward_loss(x, y, with_grad=True)
+        with ops.overlap_region():              # deferred / batched finishing reductions of the norm backward and bias sums
+            self.resModel.backward(dlogits)                                                    # :43 (gradient of the SUM of the map)
+        return probs
+
+    def _repack(self):
+        self.resModel.repack()
+
+    def _graph_state(self):
+        bn = [b for m in self.resModel.modules() if isinstance(m, BatchNormalization) for b in (m.moving_mean_p, m.moving_variance_p)]
+        return [self.flat.flat] + self.optimizer.state_tensors() + bn
+
+    def step(self, x, y, train=False):
+        """TBI_ResNest.py:35-55 -> (loss map [H,W], accuracy, probabilities)."""
+        x, y = self._prep_x(x), self._prep_y(y)
+        if not train:
+            probs, _ = self._forward_loss(x, y, with_grad=False)
+        elif self._graph is not None:
+            probs = self._graph_replay(x, y)
+        else:
+            probs = self._train_body(x, y)                                                     # :43-46 (no clipping: clip_norm None)
         pred = probs.argmax(dim=-1)                                                            # :48-51 (metric only)
         accuracy = (pred == y.argmax(dim=-1)).float().mean()
-        return self._loss_map.clone().reshape(H, W), accuracy, probs
+        return self._loss_map.clone().reshape(self.height, self.width), accuracy, probs
+
+    def modules(self):
+        return self.resModel.modules()
+
+    def repack(self):
+        self.resModel.repack()
+
+    def eval_step(self, x, y):
+        """MirroredTrainer-compatible evaluation: -> (sum of the loss map, probs)."""
+        loss_map, _, probs = self.step(x, y, train=False)
+        return loss_map.sum(), probs
 
     def train_step(self, x, y):
         """MirroredTrainer-compatible alias: -> (sum of the loss map, probs)."""

@@ -24,6 +24,7 @@ from .flat import AdamClip, FlatParams
 from .layers import BatchNormalization, Conv2D, LayerNormalization, _Workspace
 from .ResNest import ResNest, cardinal, residual_S
 from .ops import BF16, roundup
+from .step import TrainStepDriver
 
 input_size = (256, 80)   # VisionTransformer.py:7
 
@@ -115,6 +116,14 @@ class Attention(nn.Module):
             jobs.append(ops.pack_job(c.kernel.data, 0, hs, 1, 1, hs, hs, self.w_d, 3 * hs, 3 * hs, 0, i * hs))
         return jobs
 
+    def _qkv_map(self):
+        key = self.query.kernel.grad.data_ptr()
+        if getattr(self, "_qkv_map_key", None) != key:
+            hs = self.hidden_size
+            self._qkv_wmap = ops.wgrad_dst([(c.kernel.grad, 0, hs, 1, 0, i * hs, hs, hs) for i, c in enumerate((self.query, self.key, self.value))])
+            self._qkv_map_key = key
+        return self._qkv_wmap
+
     def forward(self, xn, residual):
         """xn, residual: [B,N,1,hidden] bf16 -> (attention output + residual, weights fp32 [B,heads,N,N])."""
         B, N, _, hs = xn.shape
@@ -154,12 +163,9 @@ class Attention(nn.Module):
         ops.gemm_tn_batched(dS, q, dK, N, dh, N, N, 3 * hs, B, nh, s_pp, s_qkv, s_hd)                       # dK = dS^T Q
         ops.cast_f32_to_bf16_batched(dK, N, dh, B, nh, dqkv[..., hs:2 * hs], 3 * hs, s_qkv)
         ops.cast_f32_to_bf16_batched(dV, N, dh, B, nh, dqkv[..., 2 * hs:], 3 * hs, s_qkv)
-        # fused projection backward
-        scratch = _Workspace.get(dev, hs * 3 * hs)
-        ops.fill_f32(scratch, 0.0)
-        ops.conv2d_wgrad(xn, dqkv, 1, 1, scratch)
-        for i, c in enumerate((self.query, self.key, self.value)):
-            ops.unpack_wgrad(scratch, hs, 3 * hs, 1, hs, hs, i * hs, 0, c.kernel.grad, 0, 1, hs)
+        # fused projection backward: the [hidden, 3*hidden] gradient is scattered straight into the three Dense kernels
+        # (one destination block each) - no shared scratch that a deferred split-K finish would still be filling
+        ops.conv2d_wgrad_mapped(xn, dqkv, 1, 1, self._qkv_map())
         ops.colsum(dqkv, self.db_qkv, 3 * hs)
         return ops.conv2d_dgrad(dqkv, self.w_d, 1, 1, ops.new_act(B, N, 1, hs, dev))
 
@@ -251,7 +257,7 @@ class Transformer(nn.Module):
         self.embeddings.backward(d_hidden, d_feats)
 
 
-class VisionTransformer(nn.Module):
+class VisionTransformer(TrainStepDriver, nn.Module):
     def __init__(self, batch_size, img_size=(256, 80), num_classes=3, learning_rate=1e-3, weight_decay=1e-4, *,
                  in_channels: int = 10, use_vit: bool = False, device: Optional[str] = None, seed: Optional[int] = 0):
         super().__init__()
@@ -272,7 +278,7 @@ class VisionTransformer(nn.Module):
         self.device = torch.device(dev)
         self.flat = FlatParams(self, self.device)
         self.optimizer = AdamClip(self.flat, lr=learning_rate, clip_norm=1.0)          # :204,:244
-        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._loss = torch.zeros(ops.ACC_FLOATS, dtype=torch.float32, device=self.device)   # [0] = the scalar loss
         self.grad_sync = None                   # set by the data-parallel wrapper: callable(flat_grad)
         self._graph = None
 
@@ -283,7 +289,15 @@ class VisionTransformer(nn.Module):
         return self
 
     def save(self, path):
-        torch.save(self.export_params(), path)
+        """model.save of a compiled Keras model (MainNumpy.py:177): variables, BN statistics AND the optimiser state."""
+        d = self.export_params()
+        d.update(self.optimizer.state_dict())
+        torch.save(d, path)
+
+    def load(self, path):
+        d = torch.load(path, map_location="cpu", weights_only=True)
+        self.optimizer.load_state_dict({k: d.pop(k) for k in list(d) if k.startswith("__adam_")})
+        self.load_params(d)
 
     @property
     def layers(self):
@@ -358,79 +372,45 @@ class VisionTransformer(nn.Module):
         return probs, dlogits
 
     def compute_loss(self, y_true, y_pred):
-        raise NotImplementedError("the loss is fused with the head softmax (usseg_softmax_loss_fwd_bwd); use step()/train_step()")
+        """VisionTransformer.py:225-227: CategoricalCrossentropy(label_smoothing=0.1, reduction NONE) on PROBABILITIES, summed
+        and divided by the global batch size -> scalar.  (train_step/step use the fused softmax+loss kernel instead.)"""
+        y_true, y_pred = self._prep_y(y_true), self._prep_y(y_pred)
+        H, W = y_pred.shape[1], y_pred.shape[2]
+        loss = torch.empty(ops.ACC_FLOATS, dtype=torch.float32, device=self.device)
+        ops.fill_f32(loss, 0.0)
+        ops.loss_from_probs(y_pred, y_true, loss, HW=H * W, C_classes=y_pred.shape[-1], loss_kind=0, label_smoothing=0.1, clip_eps=1e-7,
+                            inv_global_batch=1.0 / float(self.batch_size))
+        return loss[0].clone()
 
     def step(self, x, y):
         """Evaluation step (:248-254): -> (loss, probs)."""
         probs, _ = self._forward_loss(self._prep_x(x), self._prep_y(y), with_grad=False)
-        return self._loss.clone().reshape(()), probs
+        return self._loss[0].clone(), probs
 
-    def _grad_body(self, x, y):
-        """zero grads, forward, loss, backward (+ the per-replica clip when gradients are exchanged afterwards)."""
+    # ------------------------------------------------------------------ hooks of the shared step order (step.TrainStepDriver)
+    def _zero_grad(self):
         self.flat.zero_grad()
+
+    def _forward_backward(self, x, y):
         probs, dlogits = self._forward_loss(x, y, with_grad=True)                      # :240-241
-        with ops.overlap_region():              # weight gradients on the side stream, joined before the optimiser
+        with ops.overlap_region():              # finishing reductions deferred and batched until the optimiser needs them
             d_hidden, d_feats = self.decoder.backward(dlogits)                         # :243
             self.transformer.backward(d_hidden, d_feats)
-        if self.grad_sync is not None:
-            self.optimizer.clip_local()                                                # per-replica clip (:244) BEFORE the exchange
         return probs
 
-    def _update_body(self):
-        self.optimizer.apply(already_clipped=self.grad_sync is not None)               # (:244-)245 clip + Adam
+    def _repack(self):
         repack_all(self)
 
-    def _train_body(self, x, y):
-        probs = self._grad_body(x, y)
-        if self.grad_sync is not None:
-            self.grad_sync(self.flat.grad)                                             # SUM all-reduce inside apply_gradients
-        self._update_body()
-        return probs
+    def _graph_state(self):
+        bn = [b for m in self.modules() if isinstance(m, BatchNormalization) for b in (m.moving_mean_p, m.moving_variance_p)]
+        return [self.flat.flat] + self.optimizer.state_tensors() + bn
 
     def train_step(self, x, y):
-        """One optimisation step (:235-246): -> (loss, probs).  Loss = sum of per-pixel CCE / GLOBAL batch size."""
+        """One optimisation step (:235-246): -> (loss, probs).  Loss = sum of per-pixel CCE / GLOBAL batch size.
+        After ``capture_graph`` the returned probabilities are the captured step's static buffer: valid until the next call."""
         x, y = self._prep_x(x), self._prep_y(y)
-        if self._graph is not None:
-            return self._graph_step(x, y)
-        probs = self._train_body(x, y)
-        return self._loss.clone().reshape(()), probs
-
-    # ------------------------------------------------------------------ HIP-graph replay of the whole step
-    def capture_graph(self, x, y, warmup: int = 2):
-        """Capture ``train_step`` for inputs of this shape into HIP graphs (the step is ~400 launches of 5-70 us).
-        Single GPU: one graph.  Data parallel: two graphs (gradients, update) with the RCCL all-reduce between them."""
-        x, y = self._prep_x(x), self._prep_y(y)
-        self._gx, self._gy = x.clone(), y.clone()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                self._train_body(self._gx, self._gy)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        if self.grad_sync is None:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._gprobs = self._train_body(self._gx, self._gy)
-            self._graph = (g, None)
-        else:
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self._gprobs = self._grad_body(self._gx, self._gy)
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                self._update_body()
-            self._graph = (g1, g2)
-
-    def _graph_step(self, x, y):
-        self._gx.copy_(x)
-        self._gy.copy_(y)
-        g1, g2 = self._graph
-        g1.replay()
-        if g2 is not None:
-            self.grad_sync(self.flat.grad)
-            g2.replay()
-        return self._loss.clone().reshape(()), self._gprobs
+        probs = self._graph_replay(x, y) if self._graph is not None else self._train_body(x, y)
+        return self._loss[0].clone(), probs
 
     def __call__(self, x, *args, **kwargs):
         return self.forward(x)

@@ -464,80 +464,96 @@ extern "C" int usseg_splitattn_apply_bwd_dy(const UssegSplitAttnDesc* d, const v
 }
 
 // ------------------------------------------------------------------------------------------ head softmax + loss
+// One pixel: softmax, probabilities out, loss term (returned) and d(sum loss)/d logits.
+__device__ __forceinline__ float softmax_loss_pixel(const UssegLossDesc& d, int64_t m, const float* logits, const float* y_true,
+                                                    const float* scale, float* probs, bf16_t* dlogits) {
+  const int C = d.C;
+  float z[8], p[8], yt[8];
+  float mx = -INFINITY;
+  // quad (space-to-depth) layout of the head's output and its gradient: pixel (y, x) of the full-resolution map lives in
+  // slot 4*((y&1)*2 + (x&1)) of the 16-channel pixel (y/2, x/2) - what the 2x2-tap form of the stride-2 head produces
+  int64_t lbase = m * d.ldl, dbase = m * d.lddl;
+  if (d.quad_w) {
+    const int hw = (int)(m % d.HW);
+    const int64_t b = m / d.HW;
+    const int y = hw / d.quad_w, x = hw - y * d.quad_w;
+    const int64_t q = (b * (d.HW / d.quad_w / 2) + (y >> 1)) * (d.quad_w / 2) + (x >> 1);
+    const int slot = 4 * ((y & 1) * 2 + (x & 1));
+    lbase = q * d.ldl + slot;
+    dbase = q * d.lddl + slot;
+  }
+  for (int c = 0; c < C; ++c) { z[c] = logits[lbase + c]; mx = fmaxf(mx, z[c]); }
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) { p[c] = __expf(z[c] - mx); sum += p[c]; }
+  float inv = 1.f / sum;
+  for (int c = 0; c < C; ++c) { p[c] *= inv; probs[m * C + c] = p[c]; }
+  if (!y_true) return 0.f;
+  for (int c = 0; c < C; ++c) yt[c] = y_true[m * C + c];
+  float dLdp[8];
+  float l = 0.f;
+  if (d.loss_kind == 0) {
+    // CategoricalCrossentropy(label_smoothing) on probabilities (VisionTransformer.py:205)
+    float S = 0.f;
+    for (int c = 0; c < C; ++c) S += p[c];
+    float u[8], ubar = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float ys = yt[c] * (1.f - d.label_smoothing) + d.label_smoothing / (float)C;
+      float q = p[c] / S;
+      float qc = fminf(fmaxf(q, d.clip_eps), 1.f - d.clip_eps);
+      l -= ys * __logf(qc);
+      u[c] = (q > d.clip_eps && q < 1.f - d.clip_eps) ? -ys / qc : 0.f;
+      ubar += u[c] * q;
+    }
+    l *= d.inv_global_batch;
+    for (int c = 0; c < C; ++c) dLdp[c] = (u[c] - ubar) / S * d.inv_global_batch;
+  } else {
+    // my_loss_cat (TBI_ResNest.py:234-248): -sum_b y*log(p+1e-7)*scale[hw][c]; the [H,W] map is summed for the gradient
+    const int hw = (int)(m % d.HW);
+    for (int c = 0; c < C; ++c) {
+      float sc = scale[(int64_t)hw * C + c];
+      l -= yt[c] * __logf(p[c] + 1e-7f) * sc;
+      dLdp[c] = -yt[c] * sc / (p[c] + 1e-7f);
+    }
+  }
+  if (dlogits) {
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += dLdp[c] * p[c];
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (c < C) ? p[c] * (dLdp[c] - dot) : 0.f;
+    if (d.quad_w) {
+      uint2 v;
+      v.x = pack2bf(o[0], o[1]); v.y = pack2bf(o[2], o[3]);
+      *reinterpret_cast<uint2*>(dlogits + dbase) = v;
+    } else {
+      *reinterpret_cast<uint4*>(dlogits + dbase) = pack8(o);
+    }
+  }
+  return l;
+}
+
+// Reproducible reductions: loss_kind 0 sums the workgroup totals in workgroup order (grid_ordered_sum, loss = [USSEG_ACC_FLOATS]);
+// loss_kind 1 gives every pixel of the [H,W] map to ONE thread that walks the batch in order (no atomics on the map).
 __global__ __launch_bounds__(256) void softmax_loss_kernel(const UssegLossDesc d, const float* logits, const float* y_true, const float* scale,
                                                             float* probs, float* loss, bf16_t* dlogits) {
   __shared__ float red[4];
-  float lsum = 0.f;
-  const int C = d.C;
-  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < d.M; m += (int64_t)gridDim.x * 256) {
-    float z[8], p[8], yt[8];
-    float mx = -INFINITY;
-    // quad (space-to-depth) layout of the head's output and its gradient: pixel (y, x) of the full-resolution map lives in
-    // slot 4*((y&1)*2 + (x&1)) of the 16-channel pixel (y/2, x/2) - what the 2x2-tap form of the stride-2 head produces
-    int64_t lbase = m * d.ldl, dbase = m * d.lddl;
-    if (d.quad_w) {
-      const int hw = (int)(m % d.HW);
-      const int64_t b = m / d.HW;
-      const int y = hw / d.quad_w, x = hw - y * d.quad_w;
-      const int64_t q = (b * (d.HW / d.quad_w / 2) + (y >> 1)) * (d.quad_w / 2) + (x >> 1);
-      const int slot = 4 * ((y & 1) * 2 + (x & 1));
-      lbase = q * d.ldl + slot;
-      dbase = q * d.lddl + slot;
-    }
-    for (int c = 0; c < C; ++c) { z[c] = logits[lbase + c]; mx = fmaxf(mx, z[c]); }
-    float sum = 0.f;
-    for (int c = 0; c < C; ++c) { p[c] = __expf(z[c] - mx); sum += p[c]; }
-    float inv = 1.f / sum;
-    for (int c = 0; c < C; ++c) { p[c] *= inv; probs[m * C + c] = p[c]; }
-    if (!y_true) continue;
-    for (int c = 0; c < C; ++c) yt[c] = y_true[m * C + c];
-    float dLdp[8];
-    if (d.loss_kind == 0) {
-      // CategoricalCrossentropy(label_smoothing) on probabilities (VisionTransformer.py:205)
-      float S = 0.f;
-      for (int c = 0; c < C; ++c) S += p[c];
-      float u[8], ubar = 0.f, l = 0.f;
-      for (int c = 0; c < C; ++c) {
-        float ys = yt[c] * (1.f - d.label_smoothing) + d.label_smoothing / (float)C;
-        float q = p[c] / S;
-        float qc = fminf(fmaxf(q, d.clip_eps), 1.f - d.clip_eps);
-        l -= ys * __logf(qc);
-        u[c] = (q > d.clip_eps && q < 1.f - d.clip_eps) ? -ys / qc : 0.f;
-        ubar += u[c] * q;
-      }
-      lsum += l * d.inv_global_batch;
-      for (int c = 0; c < C; ++c) dLdp[c] = (u[c] - ubar) / S * d.inv_global_batch;
-    } else {
-      // my_loss_cat (TBI_ResNest.py:234-248): -sum_b y*log(p+1e-7)*scale[hw][c]; the [H,W] map is summed for the gradient
-      int hw = (int)(m % d.HW);
+  if (d.loss_kind == 1 && y_true) {
+    const int nb = (int)(d.M / d.HW);
+    for (int64_t hw = (int64_t)blockIdx.x * 256 + threadIdx.x; hw < d.HW; hw += (int64_t)gridDim.x * 256) {
       float l = 0.f;
-      for (int c = 0; c < C; ++c) {
-        float sc = scale[(int64_t)hw * C + c];
-        l -= yt[c] * __logf(p[c] + 1e-7f) * sc;
-        dLdp[c] = -yt[c] * sc / (p[c] + 1e-7f);
-      }
-      atomicAdd(loss + hw, l);
+      for (int b = 0; b < nb; ++b) l += softmax_loss_pixel(d, (int64_t)b * d.HW + hw, logits, y_true, scale, probs, dlogits);
+      loss[hw] += l;
     }
-    if (dlogits) {
-      float dot = 0.f;
-      for (int c = 0; c < C; ++c) dot += dLdp[c] * p[c];
-      float o[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] = (c < C) ? p[c] * (dLdp[c] - dot) : 0.f;
-      if (d.quad_w) {
-        uint2 v;
-        v.x = pack2bf(o[0], o[1]); v.y = pack2bf(o[2], o[3]);
-        *reinterpret_cast<uint2*>(dlogits + dbase) = v;
-      } else {
-        *reinterpret_cast<uint4*>(dlogits + dbase) = pack8(o);
-      }
-    }
+    return;
   }
-  if (y_true && d.loss_kind == 0) {
+  float lsum = 0.f;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < d.M; m += (int64_t)gridDim.x * 256)
+    lsum += softmax_loss_pixel(d, m, logits, y_true, scale, probs, dlogits);
+  if (y_true) {
     for (int msk = 32; msk >= 1; msk >>= 1) lsum += __shfl_xor(lsum, msk, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+    grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), loss, gridDim.x);
   }
 }
 
@@ -551,11 +567,65 @@ extern "C" int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* l
   USSEG_CHECK_ARG(!dlogits || (d->lddl == (d->quad_w ? 16 : 8)), "dlogits stride must be 8 (16 in the quad layout)");
   USSEG_CHECK_ARG(d->loss_kind == 0 || (d->loss_kind == 1 && scale), "loss_kind 1 needs scale");
   if (d->M <= 0) return USSEG_OK;
-  int64_t g = cdiv64(d->M, 256 * 4);
+  USSEG_CHECK_ARG(d->HW > 0 && d->M % d->HW == 0, "softmax_loss: M must be a multiple of HW");
+  int64_t g = (y_true && d->loss_kind == 1) ? cdiv64(d->HW, 256) : cdiv64(d->M, 256 * 4);
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(softmax_loss_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *d, logits, y_true, scale, probs, loss,
                      (bf16_t*)dlogits);
   return usseg_check_launch("softmax_loss");
+}
+
+// compute_loss / my_loss_cat on probabilities (the reference's public loss methods): same arithmetic as the fused kernel above
+__device__ __forceinline__ float loss_from_probs_pixel(const UssegLossDesc& d, int64_t m, const float* probs, const float* y_true,
+                                                       const float* scale) {
+  const int C = d.C;
+  float p[8], yt[8], l = 0.f;
+  for (int c = 0; c < C; ++c) { p[c] = probs[m * C + c]; yt[c] = y_true[m * C + c]; }
+  if (d.loss_kind == 0) {
+    float S = 0.f;
+    for (int c = 0; c < C; ++c) S += p[c];
+    for (int c = 0; c < C; ++c) {
+      float ys = yt[c] * (1.f - d.label_smoothing) + d.label_smoothing / (float)C;
+      float qc = fminf(fmaxf(p[c] / S, d.clip_eps), 1.f - d.clip_eps);
+      l -= ys * __logf(qc);
+    }
+    return l * d.inv_global_batch;
+  }
+  const int hw = (int)(m % d.HW);
+  for (int c = 0; c < C; ++c) l -= yt[c] * __logf(p[c] + 1e-7f) * scale[(int64_t)hw * C + c];
+  return l;
+}
+__global__ __launch_bounds__(256) void loss_from_probs_kernel(const UssegLossDesc d, const float* probs, const float* y_true, const float* scale,
+                                                               float* loss) {
+  __shared__ float red[4];
+  if (d.loss_kind == 1) {
+    const int nb = (int)(d.M / d.HW);
+    for (int64_t hw = (int64_t)blockIdx.x * 256 + threadIdx.x; hw < d.HW; hw += (int64_t)gridDim.x * 256) {
+      float l = 0.f;
+      for (int b = 0; b < nb; ++b) l += loss_from_probs_pixel(d, (int64_t)b * d.HW + hw, probs, y_true, scale);
+      loss[hw] += l;
+    }
+    return;
+  }
+  float lsum = 0.f;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < d.M; m += (int64_t)gridDim.x * 256)
+    lsum += loss_from_probs_pixel(d, m, probs, y_true, scale);
+  for (int msk = 32; msk >= 1; msk >>= 1) lsum += __shfl_xor(lsum, msk, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), loss, gridDim.x);
+}
+extern "C" int usseg_loss_from_probs(const UssegLossDesc* d, const float* probs, const float* y_true, const float* scale, float* loss,
+                                     usseg_stream_t stream) {
+  USSEG_CHECK_ARG(d && probs && y_true && loss, "loss_from_probs: null pointer");
+  USSEG_CHECK_ARG(d->C >= 1 && d->C <= 8 && d->HW > 0, "loss_from_probs: 1 <= C <= 8");
+  USSEG_CHECK_ARG(d->loss_kind == 0 || (d->loss_kind == 1 && scale), "loss_kind 1 needs scale");
+  if (d->M <= 0) return USSEG_OK;
+  USSEG_CHECK_ARG(d->M % d->HW == 0, "loss_from_probs: M must be a multiple of HW");
+  int64_t g = d->loss_kind == 1 ? cdiv64(d->HW, 256) : cdiv64(d->M, 256 * 4);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(loss_from_probs_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *d, probs, y_true, scale, loss);
+  return usseg_check_launch("loss_from_probs");
 }
 
 __global__ __launch_bounds__(256) void loss_cat_scale_kernel(const float* y, int B, int HW, int C, float* scale) {
@@ -599,7 +669,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, f
   for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), out, gridDim.x);   // reproducible: the clip factor scales every update
 }
 extern "C" int usseg_sumsq(const float* g, int64_t n, float* out, usseg_stream_t stream) {
   USSEG_CHECK_ARG(g && out && n >= 0 && ((uintptr_t)g % 16) == 0, "sumsq: bad args (g must be 16-byte aligned)");

@@ -51,6 +51,34 @@ __device__ __forceinline__ float act_grad(float v, int act, float alpha) {
   }
 }
 
+// ---- bitwise reproducible grid-wide sum (no float atomics: their arrival order changes the rounding from run to run) ----------------
+// acc[0] accumulates the result, acc[1] is a ticket counter (zero before and after the call), acc[2 + b] holds workgroup b's
+// total.  Every workgroup (256 threads) stores its total; the LAST one to arrive adds all of them in workgroup order with a
+// fixed tree.  Partials are moved with agent-scope atomic loads / stores and fenced, so the eight XCD L2s agree on them.
+/* USSEG_ACC_FLOATS (usseg.h) = 2 + the largest grid of the kernels that use it */
+__device__ __forceinline__ void grid_ordered_sum(float block_total /* thread 0 */, float* acc, int nblocks) {
+  __shared__ int s_last;
+  __shared__ float s_w[4];
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(acc + 2 + blockIdx.x, block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(acc + 1), 1u);
+    s_last = (t == (unsigned)nblocks - 1u);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += __hip_atomic_load(acc + 2 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    acc[0] += (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(acc + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- shared epilogue of the conv kernels (16x16 MFMA layout: a lane holds Y[pixel = lane&15][n = nbase + 16*bt + j]) ----------------
 // vmcnt retires in issue order and counts stores, so a load issued after a store waits for that store's write latency
 // (about 1k cycles): the per-tile "load bias, add, store" loop these kernels started with serialized 2*NT store latencies

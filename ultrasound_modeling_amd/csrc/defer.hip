@@ -68,13 +68,15 @@ __global__ __launch_bounds__(256) void reduce_finish_batched_kernel(const RBatch
 
 // ------------------------------------------------------------------------------------------ split-K slabs of a weight gradient
 // out (identity) or the mapped variables += sum_s ws[s][i]  (n floats per slab, n % 4 == 0)
-// Workgroup = 64 float4 outputs x 4 slab slices; gy splits the slabs further when the output is small, and those
-// partial sums meet in the destination through a handful of atomics per element.
+// Workgroup = (256 / SL) float4 outputs x SL slab slices, SL in {4, 16, 64}: a small output with many slabs gets more
+// slices per output instead of more workgroups per output, so every output element is finished by ONE workgroup in a fixed
+// order - no atomics, bitwise reproducible (the earlier form split the slab axis over workgroups that met through float
+// atomics: the stem's weight gradients changed in the last bits from run to run).
 struct WJob {
   const float* ws;
   float* out;
   int64_t n4;
-  int32_t splits, Ma, Nb, gx, gy, pad;
+  int32_t splits, Ma, Nb, gx, sl_log2, pad;
   WgMap map;
 };
 struct WBatch {
@@ -83,34 +85,36 @@ struct WBatch {
   WJob job[14];
 };
 
-__device__ __forceinline__ void wgrad_finish_body(const WJob& q, int bx, int by) {
-  __shared__ float4 s_part[4][64];
+__device__ __forceinline__ void wgrad_finish_body(const WJob& q, int bx) {
+  __shared__ float4 s_part[256];
   const float4* w4 = reinterpret_cast<const float4*>(q.ws);
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int per_y = (q.splits + q.gy - 1) / q.gy;
-  const int s0 = by * per_y;
-  int s1 = s0 + per_y;
-  if (s1 > q.splits) s1 = q.splits;
-  for (int64_t base = (int64_t)bx * 64; base < q.n4; base += (int64_t)q.gx * 64) {
+  const int SL = 1 << q.sl_log2, O = 256 >> q.sl_log2;
+  const int o = threadIdx.x & (O - 1), sl = threadIdx.x >> (8 - q.sl_log2);
+  for (int64_t base = (int64_t)bx * O; base < q.n4; base += (int64_t)q.gx * O) {
     const int64_t i = base + o;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < q.n4) {
 #pragma unroll 4
-      for (int s = s0 + sl; s < s1; s += 4) {
+      for (int s = sl; s < q.splits; s += SL) {
         float4 v = w4[(int64_t)s * q.n4 + i];
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
       }
     }
-    s_part[sl][o] = a;
+    s_part[threadIdx.x] = a;
     __syncthreads();
+    for (int h = SL >> 1; h >= 1; h >>= 1) {          // fixed tree over the slices
+      if (sl < h) {
+        float4 u = s_part[threadIdx.x], w = s_part[threadIdx.x + h * O];
+        u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
+        s_part[threadIdx.x] = u;
+      }
+      __syncthreads();
+    }
     if (sl == 0 && i < q.n4) {
-      float4 t = s_part[0][o];
-#pragma unroll
-      for (int r = 1; r < 4; ++r) { t.x += s_part[r][o].x; t.y += s_part[r][o].y; t.z += s_part[r][o].z; t.w += s_part[r][o].w; }
+      const float4 t = s_part[o];
       if (q.map.nblocks == 0) {
         float* d = q.out + i * 4;
-        if (q.gy == 1) { d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
-        else { atomicAdd(d, t.x); atomicAdd(d + 1, t.y); atomicAdd(d + 2, t.z); atomicAdd(d + 3, t.w); }
+        d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w;
       } else {   // scatter into the framework's variables (logical channels, Keras strides); the four elements share (tap, ci)
         const int64_t e = i * 4;
         const int tap = (int)(e / ((int64_t)q.Ma * q.Nb));
@@ -120,23 +124,18 @@ __device__ __forceinline__ void wgrad_finish_body(const WJob& q, int bx, int by)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float* d = wg_map_dst(q.map, nullptr, 0, tap, mi, n + r);
-          if (d) {
-            if (q.gy == 1) *d += v[r];
-            else atomicAdd(d, v[r]);
-          }
+          if (d) *d += v[r];
         }
       }
     }
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WJob q) { wgrad_finish_body(q, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WJob q) { wgrad_finish_body(q, blockIdx.x); }
 __global__ __launch_bounds__(256) void wgrad_finish_batched_kernel(const WBatch b) {
   int j = 0;
   while (j + 1 < b.njobs && (int)blockIdx.x >= b.start[j + 1]) ++j;
-  const WJob& q = b.job[j];
-  const int local = blockIdx.x - b.start[j];
-  wgrad_finish_body(q, local % q.gx, local / q.gx);
+  wgrad_finish_body(b.job[j], blockIdx.x - b.start[j]);
 }
 
 // ------------------------------------------------------------------------------------------ deferral context (host)
@@ -155,14 +154,39 @@ static DeferCtx* find_ctx(hipStream_t s) {
   return nullptr;
 }
 
+// The batched kernels read-modify-write their destinations without atomics and the jobs of one launch run concurrently, so
+// two jobs that share a destination (a gradient variable produced twice before the flush) must not share a launch: a
+// batch is closed in front of the first job that repeats a destination and the next launch is stream-ordered behind it.
+static bool rjob_shares_dst(const RBatch& b, const RJob& q) {
+  for (int j = 0; j < b.njobs; ++j) {
+    const float* have[3] = {b.job[j].d0, b.job[j].d1, b.job[j].d2};
+    const float* want[3] = {q.d0, q.d1, q.d2};
+    for (const float* h : have)
+      for (const float* w : want)
+        if (h && h == w) return true;
+  }
+  return false;
+}
+static const float* wjob_dst(const WJob& q, int b) { return q.map.nblocks == 0 ? (b == 0 ? q.out : nullptr) : (b < q.map.nblocks ? q.map.blk[b].dst : nullptr); }
+static bool wjob_shares_dst(const WBatch& b, const WJob& q) {
+  for (int j = 0; j < b.njobs; ++j)
+    for (int x = 0; x < 4; ++x)
+      for (int y = 0; y < 4; ++y) {
+        const float* h = wjob_dst(b.job[j], x);
+        if (h && h == wjob_dst(q, y)) return true;
+      }
+  return false;
+}
+
 static void flush_reduce(DeferCtx& c) {
-  for (size_t i = 0; i < c.rj.size(); i += 48) {
+  size_t i = 0;
+  while (i < c.rj.size()) {
     RBatch b = {};
     int gx = 1;
-    b.njobs = (int)(c.rj.size() - i < 48 ? c.rj.size() - i : 48);
-    for (int j = 0; j < b.njobs; ++j) {
-      b.job[j] = c.rj[i + j];
-      if (b.job[j].nblocks > gx) gx = b.job[j].nblocks;
+    while (i < c.rj.size() && b.njobs < 48 && !rjob_shares_dst(b, c.rj[i])) {
+      b.job[b.njobs] = c.rj[i++];
+      if (b.job[b.njobs].nblocks > gx) gx = b.job[b.njobs].nblocks;
+      ++b.njobs;
     }
     hipLaunchKernelGGL(reduce_finish_batched_kernel, dim3(gx, b.njobs), dim3(256), 0, c.s, b);
   }
@@ -170,14 +194,15 @@ static void flush_reduce(DeferCtx& c) {
   c.rused = 0;
 }
 static void flush_wgrad(DeferCtx& c) {
-  for (size_t i = 0; i < c.wj.size(); i += 14) {
+  size_t i = 0;
+  while (i < c.wj.size()) {
     WBatch b = {};
     int total = 0;
-    b.njobs = (int)(c.wj.size() - i < 14 ? c.wj.size() - i : 14);
-    for (int j = 0; j < b.njobs; ++j) {
-      b.job[j] = c.wj[i + j];
-      b.start[j] = total;
-      total += b.job[j].gx * b.job[j].gy;
+    while (i < c.wj.size() && b.njobs < 14 && !wjob_shares_dst(b, c.wj[i])) {
+      b.job[b.njobs] = c.wj[i++];
+      b.start[b.njobs] = total;
+      total += b.job[b.njobs].gx;
+      ++b.njobs;
     }
     b.start[b.njobs] = total;
     const int slot = usseg_prof_start(2, c.s);     // counted with the weight-gradient kernels it finishes
@@ -226,18 +251,20 @@ float* usseg_defer_wgrad_ws(hipStream_t s, float* caller_ws, int64_t caller_floa
 void usseg_launch_wgrad_finish(const float* ws, int splits, int64_t slab_floats, float* out, const WgMap& map, int Ma, int Nb, hipStream_t s) {
   WJob q = {};
   q.ws = ws; q.out = out; q.n4 = slab_floats / 4; q.splits = splits; q.Ma = Ma; q.Nb = Nb; q.map = map;
-  int gx = (int)((q.n4 + 63) / 64);
+  // slices per output: 4, or 16 / 64 while that still leaves fewer than 256 workgroups and >= 2 slabs per slice
+  int sl_log2 = 2;
+  while (sl_log2 < 6 && (q.n4 + (256 >> sl_log2) - 1) / (256 >> sl_log2) < 256 && splits >= (2 << (sl_log2 + 2))) sl_log2 += 2;
+  const int O = 256 >> sl_log2;
+  int gx = (int)((q.n4 + O - 1) / O);
   if (gx > 2048) gx = 2048;
-  int gy = 1;  // small outputs: also split the slab axis so a few hundred workgroups share the walk
-  while (gx * gy < 256 && splits / (gy * 2) >= 8) gy *= 2;
-  q.gx = gx; q.gy = gy;
+  q.gx = gx; q.sl_log2 = sl_log2;
   DeferCtx* c = find_ctx(s);
   if (c && c->wws && ws >= c->wws && ws < c->wws + c->wcap) {
     c->wused = (ws - c->wws) + (((int64_t)splits * slab_floats + 63) & ~(int64_t)63);   // commit the slabs this producer wrote
     c->wj.push_back(q);
     return;
   }
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(gx, gy), dim3(256), 0, s, q);
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(gx), dim3(256), 0, s, q);
 }
 
 extern "C" int usseg_defer_begin(usseg_stream_t stream, float* reduce_ws, int64_t reduce_floats, float* wgrad_ws, int64_t wgrad_floats) {

@@ -96,7 +96,7 @@ class AdamClip:
         self.v = torch.zeros_like(flat.flat)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.lr_t_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(ops.ACC_FLOATS, dtype=torch.float32, device=dev)   # [0] = squared global norm (reproducible accumulator)
 
     def global_norm_sq(self):
         ops.fill_f32(self.sumsq, 0.0)
@@ -109,11 +109,34 @@ class AdamClip:
             self.global_norm_sq()
             ops.scale_by_clip(self.flat.grad, self.sumsq, float(self.clip_norm))
 
-    def apply(self, already_clipped: bool = False):
+    def advance(self):
+        """step += 1 and the bias-corrected learning rate of that step (device side: replayable from a HIP graph)."""
         ops.adam_advance(self.step_dev, self.lr_t_dev, self.lr, self.b1, self.b2)
+
+    def apply_range(self, lo: int, hi: int, clip: float = 0.0):
+        """Adam update of flat[lo:hi] (elementwise, so any partition of the buffer gives the same result as one launch)."""
+        f = self.flat
+        ops.adam_clip_step(f.flat[lo:hi], f.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.sumsq, clip, self.lr_t_dev, self.b1, self.b2,
+                           self.eps)
+
+    def apply(self, already_clipped: bool = False):
+        self.advance()
         clip = 0.0
         if self.clip_norm is not None and not already_clipped:
             self.global_norm_sq()
             clip = float(self.clip_norm)
-        ops.adam_clip_step(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq, clip, self.lr_t_dev, self.b1, self.b2,
-                           self.eps)
+        self.apply_range(0, self.flat.total, clip)
+
+    def state_tensors(self):
+        return [self.m, self.v, self.step_dev, self.lr_t_dev]
+
+    def state_dict(self):
+        """Adam moments in the flat layout + the step counter (what Keras saves with a compiled model)."""
+        return {"__adam_m__": self.m.detach().clone(), "__adam_v__": self.v.detach().clone(), "__adam_step__": self.step_dev.detach().clone()}
+
+    def load_state_dict(self, d):
+        if not d:
+            return
+        self.m.copy_(d["__adam_m__"].to(self.m.device))
+        self.v.copy_(d["__adam_v__"].to(self.v.device))
+        self.step_dev.copy_(d["__adam_step__"].to(self.step_dev.device))

@@ -20,6 +20,7 @@ from ._lib import (ACCUMULATE, ACT_ELU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU,
                    SplitAttnDesc, SplitAttnGrads, SplitAttnParams)
 
 BF16 = torch.bfloat16
+ACC_FLOATS = 2050   # USSEG_ACC_FLOATS: a reproducible scalar accumulator ([0] result, [1] ticket, [2..] per-workgroup partials)
 
 
 def roundup(a: int, b: int) -> int:
@@ -526,6 +527,7 @@ def fill_f32(t: torch.Tensor, value: float = 0.0):
 
 
 def sumsq(g: torch.Tensor, out: torch.Tensor):
+    assert out.numel() >= ACC_FLOATS, "sumsq accumulates through a USSEG_ACC_FLOATS buffer"
     L.check(L.load().usseg_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "sumsq")
 
 
@@ -592,9 +594,20 @@ def softmax_loss(logits, y_true, probs, loss, dlogits, *, HW, C_classes, loss_ki
     ``quad_w`` = full-resolution width when logits / dlogits are in the head's space-to-depth layout [B,H/2,W/2,16]."""
     M = probs.numel() // C_classes
     ldl = logits.shape[-1]
+    assert loss is None or loss_kind == 1 or loss.numel() >= ACC_FLOATS, "the scalar loss accumulates through a USSEG_ACC_FLOATS buffer"
     d = LossDesc(M, HW, C_classes, ldl, 16 if quad_w else 8, loss_kind, label_smoothing, clip_eps, inv_global_batch, quad_w)
     L.check(L.load().usseg_softmax_loss_fwd_bwd(C.byref(d), logits.data_ptr(), _ptr(y_true), _ptr(scale), probs.data_ptr(), _ptr(loss),
                                                 _ptr(dlogits), _stream()), "softmax_loss")
+
+
+def loss_from_probs(probs, y_true, loss, *, HW, C_classes, loss_kind=0, label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=1.0, scale=None):
+    """The reference's public loss methods on PROBABILITIES (compute_loss / my_loss_cat); ``loss`` (pre-zeroed) accumulates."""
+    assert probs.dtype == torch.float32 and y_true.dtype == torch.float32 and probs.is_contiguous() and y_true.is_contiguous()
+    M = probs.numel() // C_classes
+    assert loss_kind == 1 or loss.numel() >= ACC_FLOATS
+    d = LossDesc(M, HW, C_classes, C_classes, 8, loss_kind, label_smoothing, clip_eps, inv_global_batch, 0)
+    L.check(L.load().usseg_loss_from_probs(C.byref(d), probs.data_ptr(), y_true.data_ptr(), _ptr(scale), loss.data_ptr(), _stream()),
+            "loss_from_probs")
 
 
 def quad_bias_expand(bias, C_logical, out):
