@@ -318,8 +318,11 @@ int usseg_splitattn_apply_fwd(const UssegSplitAttnDesc* d, const void* y, const 
  * (3) dy = mult*s*dout + dg*mult/HW */
 int usseg_splitattn_apply_bwd_reduce(const UssegSplitAttnDesc* d, const void* y, const void* dout, int32_t lddo,
                                      float* ds, float* ws, usseg_stream_t stream);
+/* grad_ws: usseg_splitattn_mlp_bwd_ws_floats(d) floats - one row of parameter-gradient partials per (path, image); the rows
+ * are added into the variables in image order by a finishing reduction (no float atomics: bitwise reproducible). */
+int64_t usseg_splitattn_mlp_bwd_ws_floats(const UssegSplitAttnDesc* d);
 int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, const float* s,
-                            const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads,
+                            const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads, float* grad_ws,
                             usseg_stream_t stream);
 int usseg_splitattn_apply_bwd_dy(const UssegSplitAttnDesc* d, const void* dout, int32_t lddo, const float* s,
                                  const float* dg, void* dy, int32_t lddy, usseg_stream_t stream);

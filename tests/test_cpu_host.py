@@ -93,43 +93,98 @@ def test_shard_batch_is_contiguous_split():
 
 
 # ------------------------------------------------------------------------------------------------ world_size-2 gloo
-class _FakeFlat:
+class _CpuFlat:
     def __init__(self, n):
         self.flat = torch.zeros(n)
         self.grad = torch.zeros(n)
+        self.total = n
 
 
-class _FakeNet:
-    """Stands in for the GPU model: same attributes MirroredTrainer touches, oracle arithmetic inside."""
+class _CpuAdamClip:
+    """flat.AdamClip's interface (clip_local / advance / apply / apply_range) in fp32 torch-CPU arithmetic: the GPU kernels
+    cannot run here, the ORDER in which step.TrainStepDriver calls them is what this test drives."""
 
-    def __init__(self, P, global_batch):
-        self.P, self.names = P, O.trainable_names(P)
-        self.sizes = [P[n].numel() for n in self.names]
-        self.flat = _FakeFlat(sum(self.sizes))
-        self.flat.flat.copy_(torch.cat([P[n].reshape(-1) for n in self.names]).float())
-        self.grad_sync, self.global_batch, self.opt = None, global_batch, {}
-        self._buffers = {k: v for k, v in P.items() if k not in self.names}     # BN moving statistics
+    def __init__(self, flat, lr=1e-3, clip_norm=1.0):
+        self.flat, self.lr, self.clip_norm = flat, lr, clip_norm
+        self.m, self.v, self.step, self.lr_t = torch.zeros_like(flat.flat), torch.zeros_like(flat.flat), 0, 0.0
+        self.calls = []
 
-    def modules(self):
-        return [self]
+    def _scale(self):
+        gn = float(self.flat.grad.double().norm())
+        return self.clip_norm / max(gn, self.clip_norm)
 
-    def _sync(self, grads):
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self.flat.grad.copy_(flat.float())
-        if self.grad_sync is not None:
-            self.grad_sync(self.flat.grad)
-        out, o = [], 0
-        for g, n in zip(grads, self.sizes):
-            out.append(self.flat.grad[o:o + n].reshape(g.shape).double())
-            o += n
-        return out
+    def clip_local(self):
+        self.calls.append("clip_local")
+        self.flat.grad.mul_(self._scale())
 
-    def train_step(self, x, y):
-        loss, probs, _, _ = O.train_step(x, y, self.P, self.opt, self.global_batch, grad_allreduce=self._sync)
-        return loss.float(), probs
+    def advance(self):
+        self.calls.append("advance")
+        self.step += 1
+        self.lr_t = self.lr * (1 - 0.999 ** self.step) ** 0.5 / (1 - 0.9 ** self.step)
+
+    def apply_range(self, lo, hi, clip=0.0):
+        self.calls.append(("adam", lo, hi))
+        g = self.flat.grad[lo:hi] * (self._scale() if clip > 0 else 1.0)
+        m, v = self.m[lo:hi], self.v[lo:hi]
+        m.mul_(0.9).add_(g, alpha=0.1)
+        v.mul_(0.999).addcmul_(g, g, value=0.001)
+        self.flat.flat[lo:hi].sub_(self.lr_t * m / (v.sqrt() + 1e-7))
+
+    def apply(self, already_clipped=False):
+        self.advance()
+        self.apply_range(0, self.flat.total, 0.0 if already_clipped else self.clip_norm)
 
 
-def _dp_worker(rank, world, port, tmp):
+def _make_cpu_net():
+    from ultrasound_modeling_amd.step import TrainStepDriver
+
+    class _CpuNet(TrainStepDriver):
+        """The PRODUCT's step driver (step.TrainStepDriver: _grad_body / _sync_and_update / _update_body / _train_body) with
+        the oracle's forward / backward in the hooks and a torch-CPU Adam: what runs under gloo is the shipped ordering logic."""
+
+        def __init__(self, P, global_batch):
+            self.P, self.names = P, O.trainable_names(P)
+            self.sizes = [P[n].numel() for n in self.names]
+            self.flat = _CpuFlat(sum(self.sizes))
+            self.flat.flat.copy_(torch.cat([P[n].reshape(-1) for n in self.names]).float())
+            self.optimizer = _CpuAdamClip(self.flat)
+            self.grad_sync, self.global_batch = None, global_batch
+            self._buffers = {k: v for k, v in P.items() if k not in self.names}     # BN moving statistics
+            self.repacks = 0
+
+        def modules(self):
+            return [self]
+
+        def _views(self, buf):
+            out, o = [], 0
+            for n, sz in zip(self.names, self.sizes):
+                out.append(buf[o:o + sz].reshape(self.P[n].shape))
+                o += sz
+            return out
+
+        def _zero_grad(self):
+            self.flat.grad.zero_()
+
+        def _forward_backward(self, x, y):
+            leaves = [t.double().clone().requires_grad_(True) for t in self._views(self.flat.flat)]
+            Pl = dict(self.P)
+            Pl.update(zip(self.names, leaves))
+            probs = O.vision_transformer_forward(x, Pl, 3, 3, as_executed=False)
+            self.loss = O.compute_loss(y, probs, self.global_batch)
+            for dst, g in zip(self._views(self.flat.grad), torch.autograd.grad(self.loss, leaves)):
+                dst.add_(g.float())
+            return probs.detach()
+
+        def _repack(self):
+            self.repacks += 1
+
+        def train_step(self, x, y):
+            probs = self._train_body(x, y)
+            return self.loss.detach().float(), probs
+    return _CpuNet
+
+
+def _dp_worker(rank, world, port, tmp, chunks):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
     from ultrasound_modeling_amd.MainParallel import MirroredTrainer, init_distributed, shard_batch
@@ -137,29 +192,33 @@ def _dp_worker(rank, world, port, tmp):
     assert (r, w) == (rank, world)
     torch.set_num_threads(2)
     P = O.init_vision_transformer_params(channel=1, seed=1 + rank, perturb=True)       # ranks start DIFFERENT ...
-    net = _FakeNet(P, global_batch=4)
-    tr = MirroredTrainer(net)                                                           # ... and rank 0's weights are mirrored
-    o = 0
-    for n, sz in zip(net.names, net.sizes):
-        net.P[n] = net.flat.flat[o:o + sz].reshape(net.P[n].shape).double()
-        o += sz
+    net = _make_cpu_net()(P, global_batch=4)
+    tr = MirroredTrainer(net, chunks=chunks)                                            # ... and rank 0's weights are mirrored
+    assert (getattr(net.grad_sync, "chunks", None) is not None) == (chunks > 1)
     x, y = O.synthetic_batch(4, 32, 32, 1, seed=9)
     xs, ys = shard_batch(x, y, rank, world)
     loss, _ = tr.train_step(xs, ys)
-    torch.save({"loss": loss, "P": {k: v.clone() for k, v in net.P.items()}}, os.path.join(tmp, f"r{rank}.pt"))
+    calls = net.optimizer.calls
+    # the shipped order: per-replica clip BEFORE the exchange, then the already-clipped Adam (whole buffer or chunk by chunk)
+    assert calls[0] == "clip_local" and calls[1] == "advance" and all(c[0] == "adam" for c in calls[2:]), calls
+    assert [c[1] for c in calls[2:]] == sorted(c[1] for c in calls[2:]) and calls[2][1] == 0 and calls[-1][2] == net.flat.total
+    assert len(calls) - 2 == (chunks if chunks > 1 else 1) and net.repacks == 1
+    torch.save({"loss": loss, "P": {n: t.clone() for n, t in zip(net.names, net._views(net.flat.flat))}}, os.path.join(tmp, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_mirrored_step_world2_gloo(tmp_path):
-    """Two replicas: weights mirrored from rank 0, batch split contiguously, loss / GLOBAL batch, per-replica clip,
-    SUM all-reduce, identical Adam update everywhere (MainParallel.py:117-146,209-210; VisionTransformer.py:227,244-245)."""
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_mirrored_step_world2_gloo(tmp_path, chunks):
+    """Two replicas driving the PRODUCT's step order (step.TrainStepDriver + MainParallel.MirroredTrainer / GradSync): weights
+    mirrored from rank 0, batch split contiguously, loss / GLOBAL batch, per-replica clip, SUM all-reduce (one collective, or
+    three pipelined chunks), identical Adam update everywhere (MainParallel.py:117-146,209-210; VisionTransformer.py:227,244-245)."""
+    port = 29500 + (os.getpid() % 2000) + chunks
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), chunks), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     for k in r0["P"]:
         assert torch.equal(r0["P"][k], r1["P"][k]), k                       # replicas stay in lock step
-    # single-process emulation of the same semantics
+    # single-process emulation of the same semantics with the oracle's own clip / Adam
     P = {k: v.float().double() for k, v in O.init_vision_transformer_params(channel=1, seed=1, perturb=True).items()}
     x, y = O.synthetic_batch(4, 32, 32, 1, seed=9)
     names = O.trainable_names(P)
@@ -178,4 +237,4 @@ def test_mirrored_step_world2_gloo(tmp_path):
     O.adam_step(new, summed, [torch.zeros_like(t) for t in new], [torch.zeros_like(t) for t in new], 1, 1e-3)
     assert abs(r0["loss"].item() - sum(losses)) < 1e-4 * abs(sum(losses))    # scalar SUM-reduce (MainParallel.py:131)
     for n, t in zip(names, new):
-        assert torch.allclose(r0["P"][n], t, rtol=1e-6, atol=2e-6), n   # first Adam step ~ lr*sign(g): entries with |g| near fp32 noise may differ
+        assert torch.allclose(r0["P"][n].double(), t, rtol=1e-6, atol=2e-6), n   # first Adam step ~ lr*sign(g): entries with |g| near fp32 noise may differ

@@ -133,6 +133,8 @@ struct SaMlp {
   UssegSplitAttnParams p;
   UssegSplitAttnGrads gr;
   const float* g; float* s; float* ws; const float* ds; float* dg;
+  float* gws;      // backward: per-(path, image) rows of parameter-gradient partials [w1 | b1 | gamma | beta | w2 | b2] (no atomics)
+  int32_t Ctot;
 };
 
 extern "C" int64_t usseg_splitattn_ws_floats(const UssegSplitAttnDesc* d) {
@@ -162,6 +164,10 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
   const float* w1 = a.p.w1 + (int64_t)p * Cg * Hd;
   const float* w2 = a.p.w2 + (int64_t)p * R * Hd * Cg;
   const float gscale = d.mult / (float)d.HW;
+  // backward: this (path, image)'s row of parameter-gradient partials; usseg_launch_reduce_finish adds the rows of a path over
+  // the images in a fixed order (float atomics made these gradients differ in the last bits from run to run at B > 2)
+  float* grow = BWD ? a.gws + ((int64_t)p * d.B + b) * a.Ctot : nullptr;
+  float* g_w1 = grow, *g_b1 = g_w1 + Cg * Hd, *g_gamma = g_b1 + Hd, *g_beta = g_gamma + Hd, *g_w2 = g_beta + Hd, *g_b2 = g_w2 + R * Hd * Cg;
 
   // gin[c] = mult/HW * sum_r g[b][(p*R+r)*Cg + c]     (ResNest.py:173-180)
   for (int c = tid; c < Cg; c += 128) {
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
       for (int c = tid; c < Cg; c += 128) {
         float v = d.use_sigmoid ? dsv[c] * sv[c] * (1.f - sv[c]) : sv[c] * (dsv[c] - red[2]);
         dz[r * 128 + c] = v;
-        atomicAdd(a.gr.b2 + (p * R + r) * Cg + c, v);
+        g_b2[r * Cg + c] = v;
       }
       __syncthreads();
     }
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
       int c = idx % Cg;
       int j = (idx / Cg) % Hd;
       int r = idx / (Cg * Hd);
-      atomicAdd(a.gr.w2 + (int64_t)p * R * Hd * Cg + idx, av[j] * dz[r * 128 + c]);
+      g_w2[idx] = av[j] * dz[r * 128 + c];
     }
     for (int j = tid; j < Hd; j += 128) {
       float v = 0.f;
@@ -262,8 +268,8 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
       float ga = a.p.gamma[p * Hd + j];
       float pre = ga * xh[j] + a.p.beta[p * Hd + j];
       float dpre = da[j] * act_grad(pre, d.act, d.alpha);
-      atomicAdd(a.gr.gamma + p * Hd + j, dpre * xh[j]);
-      atomicAdd(a.gr.beta + p * Hd + j, dpre);
+      g_gamma[j] = dpre * xh[j];
+      g_beta[j] = dpre;
       dh[j] = dpre * ga;  // d xhat
     }
     __syncthreads();
@@ -279,10 +285,10 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
       for (int j = tid; j < Hd; j += 128) dh[j] = dh[j] * rsqrtf(a.p.var[p * Hd + j] + d.eps);
     }
     __syncthreads();
-    for (int j = tid; j < Hd; j += 128) atomicAdd(a.gr.b1 + p * Hd + j, dh[j]);
+    for (int j = tid; j < Hd; j += 128) g_b1[j] = dh[j];
     for (int idx = tid; idx < Cg * Hd; idx += 128) {
       int j = idx % Hd, c = idx / Hd;
-      atomicAdd(a.gr.w1 + (int64_t)p * Cg * Hd + idx, gin[c] * dh[j]);
+      g_w1[idx] = gin[c] * dh[j];
     }
     // d g_sum[b][(p*R+r)*Cg + c] = mult/HW * sum_j w1[c][j] dh[j]
     for (int c = tid; c < Cg; c += 128) {
@@ -307,16 +313,32 @@ extern "C" int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float*
   return usseg_check_launch("splitattn_mlp_fwd");
 }
 
+extern "C" int64_t usseg_splitattn_mlp_bwd_ws_floats(const UssegSplitAttnDesc* d) {
+  if (!d) return 0;
+  return (int64_t)d->B * d->P * (d->Cg * d->Hd + 3 * d->Hd + d->R * d->Hd * d->Cg + d->R * d->Cg);
+}
+
 extern "C" int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, const float* s,
-                                       const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads,
+                                       const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads, float* grad_ws,
                                        usseg_stream_t stream) {
   int rc = sa_check(d);
   if (rc) return rc;
-  USSEG_CHECK_ARG(g && p && s && ds && dg && grads, "null pointer");
+  USSEG_CHECK_ARG(g && p && s && ds && dg && grads && grad_ws, "null pointer");
   USSEG_CHECK_ARG(grads->w1 && grads->b1 && grads->gamma && grads->beta && grads->w2 && grads->b2, "null grad pointer");
   SaMlp a = {};
   a.d = *d; a.p = *p; a.gr = *grads; a.g = g; a.s = const_cast<float*>(s); a.ws = const_cast<float*>(ws); a.ds = ds; a.dg = dg;
+  const int Cg = d->Cg, Hd = d->Hd, R = d->R;
+  a.Ctot = Cg * Hd + 3 * Hd + R * Hd * Cg + R * Cg;
+  a.gws = usseg_defer_reduce_ws((hipStream_t)stream, grad_ws, (int64_t)d->B * d->P * a.Ctot);   // a private region while finishes are deferred
   hipLaunchKernelGGL(sa_mlp_kernel<true>, dim3(d->B * d->P), dim3(128), 0, (hipStream_t)stream, a);
+  // per parameter: rows (path, image) of Ctot floats -> the path's variable (per-path variables are adjacent: [P][numel])
+  const int sizes[6] = {Cg * Hd, Hd, Hd, Hd, R * Hd * Cg, R * Cg};
+  float* dst[6] = {grads->w1, grads->b1, grads->gamma, grads->beta, grads->w2, grads->b2};
+  int off = 0;
+  for (int i = 0; i < 6; ++i) {
+    usseg_launch_reduce_finish(a.gws + off, d->P, d->B, 1, a.Ctot, sizes[i], 1.f, dst[i], nullptr, nullptr, (hipStream_t)stream);
+    off += sizes[i];
+  }
   return usseg_check_launch("splitattn_mlp_bwd");
 }
 

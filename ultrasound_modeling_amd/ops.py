@@ -569,7 +569,7 @@ def splitattn_fwd(d: SplitAttnDesc, y, params, out):
 
 
 def splitattn_bwd(d: SplitAttnDesc, y, dout, params, grads, g, s, ws, dy):
-    """grads = (dw1,db1,dgamma,dbeta,dw2,db2) accumulated with atomics.  Writes dy (stride of dy tensor)."""
+    """grads = (dw1,db1,dgamma,dbeta,dw2,db2) accumulate (per-image partial rows + an ordered finishing reduction).  Writes dy."""
     dev = y.device
     Cy = d.P * d.R * d.Cg
     ds = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)     # overwritten by usseg_splitattn_apply_bwd_reduce
@@ -580,8 +580,9 @@ def splitattn_bwd(d: SplitAttnDesc, y, dout, params, grads, g, s, ws, dy):
                                                  reduce_ws(dev).data_ptr(), _stream()), "splitattn_apply_bwd_reduce")
     sp = _sa_params(*params)
     sg = SplitAttnGrads(*[_ptr(t) for t in grads])
+    gws = torch.empty(int(lib.usseg_splitattn_mlp_bwd_ws_floats(C.byref(d))), dtype=torch.float32, device=dev)
     L.check(lib.usseg_splitattn_mlp_bwd(C.byref(d), g.data_ptr(), C.byref(sp), s.data_ptr(), ws.data_ptr(), ds.data_ptr(), dg.data_ptr(),
-                                        C.byref(sg), _stream()), "splitattn_mlp_bwd")
+                                        C.byref(sg), gws.data_ptr(), _stream()), "splitattn_mlp_bwd")
     L.check(lib.usseg_splitattn_apply_bwd_dy(C.byref(d), dout.data_ptr(), lddo, s.data_ptr(), dg.data_ptr(), dy.data_ptr(), geom(dy)[4],
                                              _stream()), "splitattn_apply_bwd_dy")
     return dy
