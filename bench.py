@@ -2,9 +2,13 @@
 """Headline benchmark: segmentation TRAINING images/sec at 256x256 on N MI355X (BASELINE.json metric).
 
 A "step" is one full training step (forward + backward + per-replica clip + gradient all-reduce + Adam + operand
-repack) of the Arch B network of BASELINE config 2 (ResNest.py r=3,k=3 encoder + patch embedding + Decoder.py
-DecoderCup, no ViT) on a synthetic batch of 16 256x256x1 tiles PER GPU that is already resident in HBM.
-Weak scaling: the per-GPU batch is fixed, the global batch (which divides the loss) is 16*N.
+repack) on a synthetic batch of 256x256x1 tiles that is already resident in HBM.
+
+  --arch B (default)  BASELINE configs[1]: Arch B (ResNest.py r=3,k=3 encoder + patch embedding + Decoder.py DecoderCup,
+                      no ViT), 16 images per GPU - the configuration the metric is quoted on.
+  --arch A            BASELINE configs[2]: Arch A (TBI_ResNest.py model, r=3,k=4, my_loss_cat, Adam 5e-3), 32 images per GPU.
+  --scaling weak (default)  the per-GPU batch is fixed, the global batch (which divides Arch B's loss) is batch*N;
+  --scaling strong          the GLOBAL batch is fixed at 16 (B) / 32 (A) and split over the N replicas (MainParallel.py:127-128).
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
@@ -32,7 +36,7 @@ import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
 HBM_BYTES_PER_S = 8.0e12     # HBM3E peak, MI355X_MICROARCH.md
-B_PER_GPU = 16
+BASE_BATCH = {"B": 16, "A": 32}   # images per GPU at N=1 (BASELINE configs[1] / configs[2])
 H = W = 256
 C_IN = 1
 
@@ -53,11 +57,10 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def algorithmic_flops(net):
-    """Algorithmic FLOPs (2*MACs, logical channel counts, radix branches de-duplicated) of the conv / tconv layers
-    for the batch of the last forward pass: (forward, igemm family = fwd + dgrad actually run, wgrad)."""
+def algorithmic_flops(net, arch):
+    """Algorithmic FLOPs (2*MACs, logical channel counts; Arch B's radix branches de-duplicated, Arch A's are distinct layers)
+    of the conv / tconv layers for the batch of the last forward pass: (forward, igemm family = fwd + dgrad actually run, wgrad)."""
     from ultrasound_modeling_amd.layers import Conv2D
-    from ultrasound_modeling_amd.ResNest import residual_S
     from ultrasound_modeling_amd import ops
     fwd = igemm = 0.0
     attain = [0.0]      # seconds the fwd + dgrad launches would take on their own rooflines: max(FLOPs / MFMA peak, min bytes / HBM)
@@ -65,21 +68,36 @@ def algorithmic_flops(net):
     def roof(f, M, cin, cout, passes):
         attain[0] += passes * max(f / (PEAK_BF16_TFLOPS * 1e12), 2.0 * M * (cin + cout) / HBM_BYTES_PER_S)
     managed = set()
-    for m in net.modules():
-        if isinstance(m, residual_S):
-            g = m._group
-            x = g._saved[0]
-            Bx, Hx, Wx, _, _ = ops.geom(x)
-            M = Bx * Hx * Wx
-            f = 2.0 * M * g.P * (g.cin * g.cv11 + g.k * g.k * g.cv11 * g.cvkk)
-            fwd += f
-            igemm += 2 * f
-            roof(2.0 * M * g.P * g.cin * g.cv11, M, g.cin, g.P * g.cv11, 2)
-            roof(2.0 * M * g.P * g.k * g.k * g.cv11 * g.cvkk, M, g.P * g.cv11, g.P * g.cvkk, 2)
-            for c in g.cards:
-                managed.update((id(c.conv1), id(c.conv2), id(c.split.dense1), id(c.split.dense2)))
-    first = net.transformer.embeddings.hybrid_model.conv1
-    for m in net.modules():
+    groups = []         # (saved input, [(1x1 conv, kxk conv), ...]) of every grouped split-attention launch pair
+    if arch == "B":
+        from ultrasound_modeling_amd.ResNest import residual_S
+        root = net
+        first = net.transformer.embeddings.hybrid_model.conv1
+        for m in net.modules():
+            if isinstance(m, residual_S):
+                groups.append((m._group._saved[0], [(c.conv1, c.conv2) for c in m._group.cards]))
+                for c in m._group.cards:
+                    managed.update((id(c.split.dense1), id(c.split.dense2)))
+    else:
+        root = net.resModel
+        first = root.Conv1
+        for st in root._build():
+            for sl in st.slabs:
+                groups.append((sl._saved[0], [(b[0], b[2]) for b in sl.br]))
+                for a1, _, a2s in sl.att:
+                    managed.update([id(a1)] + [id(c) for c in a2s])
+    for x, pairs in groups:
+        Bx, Hx, Wx, _, _ = ops.geom(x)
+        M = Bx * Hx * Wx
+        f1 = sum(2.0 * M * c1.cin * c1.cout for c1, _ in pairs)
+        f2 = sum(2.0 * M * c2.k * c2.k * c2.cin * c2.cout for _, c2 in pairs)
+        fwd += f1 + f2
+        igemm += 2 * (f1 + f2)
+        roof(f1, M, pairs[0][0].cin, sum(c1.cout for c1, _ in pairs), 2)
+        roof(f2, M, sum(c2.cin for _, c2 in pairs), sum(c2.cout for _, c2 in pairs), 2)
+        for c1, c2 in pairs:
+            managed.update((id(c1), id(c2)))
+    for m in root.modules():
         if isinstance(m, Conv2D) and id(m) not in managed:
             Bx, Hx, Wx, _, _ = ops.geom(m._x)
             f = 2.0 * Bx * Hx * Wx * m.k * m.k * m.cin * m.cout
@@ -91,18 +109,27 @@ def algorithmic_flops(net):
     return fwd, igemm, fwd
 
 
-def pmc_traffic(launches_per_step):
+def pmc_traffic(arch, per_gpu_batch, launches_per_step):
     """HBM bytes per launch of the conv kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is; tools/pmc_traffic.py made the file), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-        if d.get("per_gpu_batch") != B_PER_GPU or d.get("hw") != H:
-            return None
-        return {"bytes_per_launch": d["conv_family_bytes_per_step"] / max(d["conv_family_launches_per_step"], 1),
-                "bytes_per_step": d["conv_family_bytes_per_step"], "source": "profiles/r01_pmc_traffic.json"}
-    except Exception:
-        return None
+    MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is; tools/pmc_traffic.py made the file from the same build as the
+    kernel statistics, tools/profile_round.sh), or None.  The file is REJECTED when it does not describe the step that was just
+    profiled live: other architecture / batch / image size, or another number of conv-family launches per step."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_arch{arch}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("per_gpu_batch") != per_gpu_batch or d.get("hw") != H or d.get("arch") != arch:
+                continue
+            if abs(d["conv_family_launches_per_step"] - launches_per_step) > 0.01:
+                log(f"pmc_traffic: {os.path.basename(path)} has {d['conv_family_launches_per_step']} conv launches per step, this build "
+                    f"runs {launches_per_step}: stale, ignored")
+                continue
+            return {"bytes_per_launch": d["conv_family_bytes_per_step"] / max(d["conv_family_launches_per_step"], 1),
+                    "bytes_per_step": d["conv_family_bytes_per_step"], "total_bytes_per_step_all_kernels": d.get("total_bytes_per_step"),
+                    "source": "profiles/" + os.path.basename(path)}
+        except Exception:
+            continue
+    return None
 
 
 def layer_probe(dev):
@@ -162,7 +189,7 @@ def layer_probe(dev):
     return out
 
 
-def cpu_baseline(seconds_budget: float = 25.0):
+def cpu_baseline(arch, seconds_budget: float = 25.0):
     """Time the CPU oracle (fp32, all host cores) on a bounded sample: full train steps at B=2, 256x256x1."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import usseg_oracle as O
@@ -170,20 +197,41 @@ def cpu_baseline(seconds_budget: float = 25.0):
     torch.set_num_threads(cores)
     log(f"cpu_baseline: timing the CPU oracle on {cores} threads")
     Bc = 2
-    P = O.init_vision_transformer_params(channel=C_IN, seed=0, dtype=torch.float32)
     x, y = O.synthetic_batch(Bc, H, W, C_IN, seed=0, dtype=torch.float32)
-    st = {}
-    O.train_step(x, y, P, st, Bc)            # warm-up
+    if arch == "B":
+        P = O.init_vision_transformer_params(channel=C_IN, seed=0, dtype=torch.float32)
+        st = {}
+        step = lambda: O.train_step(x, y, P, st, Bc)
+    else:
+        P = O.init_archA_params(channel=C_IN, radix=3, kpaths=4, seed=0, dtype=torch.float32)
+        names = O.trainable_names(P)
+        m, v, it = [torch.zeros_like(P[n]) for n in names], [torch.zeros_like(P[n]) for n in names], [0]
+        gen = torch.Generator().manual_seed(0)
+
+        def step():      # TBI_ResNest.py:35-55: forward, my_loss_cat map, gradient of its sum, plain Adam(5e-3)
+            leaves = [P[n].detach().clone().requires_grad_(True) for n in names]
+            Pl = dict(P)
+            Pl.update(zip(names, leaves))
+            masks = [(torch.rand(Bc, H // 64 * 2 ** (i + 1), W // 64 * 2 ** (i + 1), 512, generator=gen) > 0.5).float() for i in range(3)]
+            probs = O.archA_forward(x, Pl, 3, 4, dropout_masks=masks)
+            grads = torch.autograd.grad(O.my_loss_cat(y, probs, H, W).sum(), leaves)
+            it[0] += 1
+            with torch.no_grad():
+                new = [l.detach().clone() for l in leaves]
+                O.adam_step(new, grads, m, v, it[0], 5e-3)
+                for n, t in zip(names, new):
+                    P[n] = t
+    step()            # warm-up
     t0 = time.perf_counter()
     n = 0
     while True:
-        O.train_step(x, y, P, st, Bc)
+        step()
         n += 1
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 8:
             break
     return {"value": round(Bc * n / el, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} full train steps (fwd+bwd+clip+Adam) of the Arch B oracle, fp32 PyTorch-CPU, B={Bc}, 256x256x1, "
+            "sample": f"{n} full train steps (fwd+bwd+{'clip+' if arch == 'B' else ''}Adam) of the Arch {arch} oracle, fp32 PyTorch-CPU, B={Bc}, 256x256x1, "
                       f"{torch.get_num_threads()} threads; TensorFlow (the reference) is not installable here"}
 
 
@@ -192,9 +240,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", choices=["B", "A"], default="B", help="B: ResNest.py+Decoder.py (configs[1], default); A: TBI_ResNest.py (configs[2])")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: fixed per-GPU batch; strong: fixed global batch split over the replicas")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path (RCCL all-reduce, 2 graphs) even at N=1")
+    ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path (RCCL all-reduce around the update) even at N=1")
+    ap.add_argument("--dp-chunks", type=int, default=0, help="pieces the gradient exchange is pipelined in (0 = automatic)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra eager steps with per-launch HIP events (roofline leg)")
     args = ap.parse_args()
 
@@ -203,26 +254,38 @@ def main():
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    arch = args.arch
+    base = BASE_BATCH[arch]
+    if args.scaling == "strong":
+        assert base % world == 0, f"strong scaling: the global batch {base} must divide over {world} replicas"
+        per_gpu = base // world
+    else:
+        per_gpu = base
+    global_batch = per_gpu * world
 
     from ultrasound_modeling_amd import _lib
-    from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
-    net = VisionTransformer(batch_size=B_PER_GPU * world, img_size=(H, W), in_channels=C_IN, device=str(dev), seed=0)
+    if arch == "B":
+        from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
+        net = VisionTransformer(batch_size=global_batch, img_size=(H, W), in_channels=C_IN, device=str(dev), seed=0)
+    else:
+        from ultrasound_modeling_amd.TBI_ResNest import ResNest
+        net = ResNest(H, W, C_IN, 3, ksize=3, radix=3, kpaths=4, learning_rate=5e-3, device=str(dev), seed=0)
     if args.force_dist and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
-    trainer = MirroredTrainer(net, force=args.force_dist)
+    trainer = MirroredTrainer(net, force=args.force_dist, chunks=args.dp_chunks or None)
 
     g = torch.Generator().manual_seed(rank)
-    x = torch.randn(B_PER_GPU, H, W, C_IN, generator=g).clamp_(-1, 1).to(dev)
-    lab = torch.rand(B_PER_GPU, H // 16, W // 16, generator=g)
+    x = torch.randn(per_gpu, H, W, C_IN, generator=g).clamp_(-1, 1).to(dev)
+    lab = torch.rand(per_gpu, H // 16, W // 16, generator=g)
     lab = (lab > 0.70).float() + (lab > 0.95).float()
     lab = (lab + 0.9 * torch.rand(lab.shape, generator=g) * (lab >= 1)).repeat_interleave(16, 1).repeat_interleave(16, 2)
     c2 = torch.where(lab >= 1.05, (lab - 1).clamp(0, 1), torch.zeros_like(lab))
     y = torch.stack([(lab <= 0.95).float(), torch.where(lab > 0.95, 1 - c2, torch.zeros_like(lab)), c2], dim=-1).to(dev)
 
-    use_graph = not args.no_graph                    # N > 1: two graphs with the RCCL all-reduce between them
-    log(f"rank {rank}/{world}: model built ({net.flat.n_trainable} params), warming up (graph={use_graph})")
+    use_graph = not args.no_graph                    # N > 1: the step up to the per-replica clip is one graph, then the RCCL exchange, then the update
+    log(f"rank {rank}/{world}: Arch {arch} built ({net.flat.n_trainable} params), {per_gpu} images per GPU, warming up (graph={use_graph})")
     for _ in range(max(args.warmup, 1) if not use_graph else 1):
         trainer.train_step(x, y)
     if use_graph:
@@ -258,9 +321,10 @@ def main():
         P = args.profile_steps
         from ultrasound_modeling_amd import ops as _ops
         side_saved, _ops._Side.enabled = _ops._Side.enabled, False   # per-kernel durations: no weight-gradient launches running beside them
+        xp, yp = net._prep_x(x), net._prep_y(y)
         _lib.check(lib.usseg_prof_enable(3, 4096 * P), "prof_enable")
         for _ in range(P):
-            net._train_body(x, y)
+            net._train_body(xp, yp)
         torch.cuda.synchronize()
         _ops._Side.enabled = side_saved
         ms, n = ctypes.c_double(), ctypes.c_int64()
@@ -269,7 +333,7 @@ def main():
         _lib.check(lib.usseg_prof_read(2, ctypes.byref(ms), ctypes.byref(n)), "prof_read")
         wg_ms, wg_n = ms.value / P, n.value // P
         lib.usseg_prof_disable()
-        fwd_f, ig_f, wg_f = algorithmic_flops(net)
+        fwd_f, ig_f, wg_f = algorithmic_flops(net, arch)
         net._graph, net.grad_sync = net._graph_saved, sync_saved
         achieved = ig_f / (ig_ms * 1e-3) / 1e12
         roofline = {"kernel": "conv family: conv_stream_kernel / conv_big_kernel / igemm_dma_kernel / igemm_kernel / conv_halo_kernel (every conv + "
@@ -279,26 +343,28 @@ def main():
                     "algorithmic_gflop_per_step": round(ig_f / 1e9, 2), "kernel_ms_per_step": round(ig_ms, 3),
                     "wgrad": {"launches_per_step": wg_n, "kernel_ms_per_step": round(wg_ms, 3),
                               "achieved": round(wg_f / (wg_ms * 1e-3) / 1e12, 2), "algorithmic_gflop_per_step": round(wg_f / 1e9, 2)},
-                    "fwd_gflop_per_image": round(fwd_f / B_PER_GPU / 1e9, 3),
+                    "fwd_gflop_per_image": round(fwd_f / per_gpu / 1e9, 3),
                     # time-weighted: what the same launches would take if each ran on its own roofline (HBM-bound stem /
                     # stage-1 layers priced on bytes, the deep ones on FLOPs) over what they took
                     "attainable_ms_per_step": round(algorithmic_flops.attainable_s * 1e3, 3),
                     "frac_of_attainable": round(algorithmic_flops.attainable_s * 1e3 / max(ig_ms, 1e-9), 4)}
-        roofline["traffic"] = pmc_traffic(ig_n)
+        roofline["traffic"] = pmc_traffic(arch, per_gpu, ig_n)
         roofline["layers"] = layer_probe(dev)
 
     if rank == 0:
-        out = {"metric": "segmentation training images/sec at 256x256", "value": round(B_PER_GPU * world * args.steps / el, 2),
+        names = {"B": "BASELINE configs[1]: Arch B (ResNest.py r=3,k=3 + Decoder.py, no ViT) train step",
+                 "A": "BASELINE configs[2]: Arch A (TBI_ResNest.py model r=3,k=4, my_loss_cat, Adam 5e-3) train step"}
+        out = {"metric": "segmentation training images/sec at 256x256", "value": round(global_batch * args.steps / el, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: Arch B (ResNest.py r=3,k=3 + Decoder.py, no ViT) train step, 256x256x1, "
-                                      "16 images per GPU, bf16 MFMA / fp32 accumulate, fp32 master weights + Adam",
-                          "per_gpu_batch": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
-                          "hip_graph": bool(use_graph), "final_loss": round(loss_val, 4)},
+               "config": {"workload": f"{names[arch]}, 256x256x1, {per_gpu} images per GPU, bf16 MFMA / fp32 accumulate, fp32 master weights + Adam",
+                          "arch": arch, "per_gpu_batch": per_gpu, "global_batch": global_batch, "parallelism": f"dp{world}",
+                          "hip_graph": bool(use_graph), "dp_exchange_chunks": getattr(net.grad_sync, "nchunks", 0) if net.grad_sync is not None else 0,
+                          "final_loss": round(loss_val, 4)},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(arch)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -1,8 +1,9 @@
-"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --no-graph` into profiles/r01_pmc_traffic.json.
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --no-graph` into profiles/rNN_pmc_traffic_arch{B,A}.json.
 
-usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <steps in the run> <out.json>
-gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads, so the
-read side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB."""
+usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <steps in the run> <out.json> [arch] [per-GPU batch]
+`steps in the run` = every train step the profiled process executed (bench.py --no-graph: warmup + steps, with
+--profile-steps 0).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request for wide coalesced
+reads, so the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB."""
 import csv, json, sys, collections
 
 def load(path, counter):
@@ -17,8 +18,10 @@ def load(path, counter):
 fetch, nf = load(sys.argv[1], "FETCH_SIZE")
 write, nw = load(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3])
+arch = sys.argv[5] if len(sys.argv) > 5 else "B"
+batch = int(sys.argv[6]) if len(sys.argv) > 6 else {"B": 16, "A": 32}[arch]
 fam = lambda k: k.startswith("igemm") or k.startswith("conv_halo") or k.startswith("conv_big") or k.startswith("conv_stream")
-out = {"per_gpu_batch": 16, "hw": 256, "steps_profiled": steps, "kernels": {}}
+out = {"arch": arch, "per_gpu_batch": batch, "hw": 256, "steps_profiled": steps, "kernels": {}}
 cb = cl = 0.0
 for k in sorted(set(fetch) | set(write)):
     rd = 2.0 * fetch[k] * 1024 / steps      # gfx950: FETCH_SIZE reads exactly half of a wide coalesced stream

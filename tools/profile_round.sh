@@ -1,13 +1,18 @@
 #!/bin/bash
-# Regenerates the round's committed evidence on a GPU box: kernel stats, PMC traffic, bench JSON.  usage: bash tools/profile_round.sh <tag>
+# Regenerates the round's committed evidence on a GPU box FROM ONE BUILD: kernel statistics + step timeline (graph replay under
+# the rocprofv3 kernel trace), PMC traffic (two separate --pmc passes, eager), and the bench JSON that reads that traffic file.
+# usage: bash tools/profile_round.sh <round tag, e.g. r02> <version tag, e.g. v3> [arch B|A]
 set -e
-TAG=${1:-r01_v13}
+R=${1:-r02}; V=${2:-v1}; ARCH=${3:-B}
+TAG=${R}_${V}_arch${ARCH}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats -d gpurun_out/stats_$TAG -o r --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > gpurun_out/stats_$TAG.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f_$TAG -o r --output-format csv -- python3 bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_f_$TAG.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w_$TAG -o r --output-format csv -- python3 bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_w_$TAG.log 2>&1
-python3 tools/pmc_traffic.py gpurun_out/pmc_f_$TAG/r_counter_collection.csv gpurun_out/pmc_w_$TAG/r_counter_collection.csv 4 gpurun_out/pmc_traffic_$TAG.json
-cp gpurun_out/pmc_traffic_$TAG.json profiles/r01_pmc_traffic.json
-python3 bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
-tail -2 gpurun_out/bench_$TAG.err; ls gpurun_out/stats_$TAG
+mkdir -p gpurun_out profiles
+rocprofv3 --kernel-trace --stats -d gpurun_out/stats_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > gpurun_out/stats_$TAG.log 2>&1
+cp gpurun_out/stats_$TAG/r_kernel_stats.csv profiles/${R}_kernel_stats_${V}_arch${ARCH}.csv
+python3 tools/step_timeline.py gpurun_out/stats_$TAG/r_kernel_trace.csv profiles/${R}_step_timeline_${V}_arch${ARCH}.txt
+# eager run (--no-graph): 1 warm-up + 3 timed = 4 steps in the process
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_f_$TAG.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_w_$TAG.log 2>&1
+python3 tools/pmc_traffic.py gpurun_out/pmc_f_$TAG/r_counter_collection.csv gpurun_out/pmc_w_$TAG/r_counter_collection.csv 4 profiles/${R}_pmc_traffic_arch${ARCH}.json $ARCH
+python3 bench.py --arch $ARCH > profiles/${R}_bench_${V}_arch${ARCH}.json 2> gpurun_out/bench_$TAG.err
+tail -3 gpurun_out/bench_$TAG.err; tail -6 profiles/${R}_step_timeline_${V}_arch${ARCH}.txt
