@@ -330,9 +330,9 @@ int usseg_splitattn_apply_bwd_dy(const UssegSplitAttnDesc* d, const void* dout, 
 /* ---- head softmax + loss ---------------------------------------------------------------------
  * logits fp32 [M][ldl] (C classes) -> probs fp32 [M][C] (Decoder.py:121; TBI_ResNest.py:125).
  * loss_kind 0: CategoricalCrossentropy(label_smoothing, reduction NONE) summed and divided by the GLOBAL batch
- *              (VisionTransformer.py:205,225-227); *loss accumulates the scalar.
+ *              (VisionTransformer.py:205,225-227); loss[0] receives the scalar.
  * loss_kind 1: my_loss_cat (TBI_ResNest.py:234-248) with precomputed per-pixel-per-class scale[HW][C];
- *              loss_map [HW] accumulates (atomics).
+ *              loss_map [HW] is overwritten.
  * dlogits (bf16 [M][lddl], may be NULL) = d(sum loss)/d logits. */
 typedef struct UssegLossDesc {
   int64_t M;            /* B*H*W pixels */
@@ -347,9 +347,10 @@ typedef struct UssegLossDesc {
                            4*((y&1)*2+(x&1)) (ldl = lddl = 16, C <= 4).  probs and y_true are always [M][C]. */
 } UssegLossDesc;
 /* Reproducible scalar accumulators (loss of loss_kind 0, usseg_sumsq): the pointer names USSEG_ACC_FLOATS floats -
- * [0] the running result, [1] a ticket counter (zero between calls), [2..] one partial per workgroup; the last workgroup to
- * arrive adds the partials in workgroup order, so no float atomics and the same bits on every run.  Zero the whole buffer
- * once; afterwards zeroing [0] is enough.  The loss map of loss_kind 1 is [HW] floats, each pixel owned by one thread. */
+ * [0] the result (OVERWRITTEN by every call), [1] a ticket counter (zero between calls), [2..] one partial per workgroup; the
+ * last workgroup to arrive adds the partials in workgroup order, so no float atomics and the same bits on every run.  Zero the
+ * whole buffer once at allocation; no per-call zeroing.  The loss map of loss_kind 1 is [HW] floats, each pixel owned by one
+ * thread and OVERWRITTEN. */
 #define USSEG_ACC_FLOATS 2050
 int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, const float* y_true, const float* scale,
                                float* probs, float* loss, void* dlogits, usseg_stream_t stream);
@@ -358,7 +359,7 @@ int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, cons
  * probabilities by their class sum, clips to [clip_eps, 1-clip_eps], -sum_c y_smoothed*log p, summed / global batch into *loss);
  * loss_kind 1 = ResNest.my_loss_cat(y_true, y_pred) (TBI_ResNest.py:234-248: loss map [HW] -= y*log(p+1e-7)*scale[hw][c]).
  * probs, y_true fp32 [M][C]; only M, HW, C, loss_kind, label_smoothing, clip_eps, inv_global_batch of the descriptor are read.
- * loss must be zeroed by the caller (it accumulates). */
+ * loss is overwritten (loss_kind 0: a USSEG_ACC_FLOATS accumulator, [0] = the scalar). */
 int usseg_loss_from_probs(const UssegLossDesc* d, const float* probs, const float* y_true, const float* scale, float* loss,
                           usseg_stream_t stream);
 /* The <= 4-class head Conv2DTranspose(k x k, stride 2, 'same') (Decoder.py:120 k=3; TBI_ResNest.py:124 k=4) in "quad" form: a
@@ -412,16 +413,26 @@ typedef struct UssegAugDesc {
 int usseg_augment(const UssegAugDesc* d, const UssegAugSample* samples_dev, const void* x, int32_t x_is_f64, const float* y,
                   const float* noise, void* x_out_bf16, float* x_out_f32, float* y_out, float* y_vec, usseg_stream_t stream);
 
+/* ---- Decoder.py:140-141: the hidden state [B][N][hidden] is re-injected at every decoder scale through a RAW row-major
+ * reshape to [B][gh*s][gw*s][c0_i] and concatenated behind the block output.  bufs[i] = first element of scale i's channel
+ * slice (pixel stride ld[i], c0[i] channels, c0 % 8 == 0), n <= 4 scales in one launch.
+ * backward == 0: scatter `hidden` into the n slices; backward == 1: hidden = sum_i slice_i (fp32 sum, one rounding). */
+int usseg_reinject_hidden(void* hidden, int64_t numel, int32_t n, void* const* bufs, const int32_t* c0, const int32_t* ld,
+                          int32_t backward, usseg_stream_t stream);
+
 /* ---- bias gradient: db[c] += sum_pixels dy[m][c] --------------------------------------------- */
 int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, float* ws, usseg_stream_t stream);
 
 /* ---- optimiser: tf.clip_by_global_norm(1.0) + Adam (VisionTransformer.py:204,244-245; TBI_ResNest.py:28,46)
- * sumsq: out[0] += sum g^2 over n floats.  `out` is a USSEG_ACC_FLOATS accumulator (zeroed by the caller once; see below),
+ * sumsq: out[0] = sum g^2 over n floats (OVERWRITTEN).  `out` is a USSEG_ACC_FLOATS accumulator (zeroed by the caller once; see below),
  *        so the sum - and with it the clip factor of every update - is bitwise reproducible from run to run.
  * adam:  scale = clip_norm > 0 ? clip_norm / max(sqrt(*sumsq), clip_norm) : 1;  g' = g*scale*grad_scale;
  *        Keras Adam with bias-corrected lr_t (host-computed from the device step counter is avoided: the caller
  *        passes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) through a device scalar so a captured graph can be replayed). */
 int usseg_sumsq(const float* g, int64_t n, float* out, usseg_stream_t stream);
+/* the same launch also advances the optimiser's device step counter (usseg_adam_advance) in its last workgroup */
+int usseg_sumsq_advance(const float* g, int64_t n, float* out, int32_t* step, float* lr_t_dev, float lr, float beta1, float beta2,
+                        usseg_stream_t stream);
 int usseg_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
                          const float* lr_t_dev, float beta1, float beta2, float eps, usseg_stream_t stream);
 /* device-side step counter: *step += 1; *lr_t = lr*sqrt(1-b2^step)/(1-b1^step) */

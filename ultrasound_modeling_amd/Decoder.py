@@ -157,6 +157,12 @@ class DecoderBlock(nn.Module):
             for j in range(4):
                 ops.conv2d_dgrad(dys[j], convs[j].wp_d, convs[j].k, convs[j].dil, dx, None, j > 0)
 
+    def skip_slot(self, B, H, W, device):
+        """Allocate this block's concat buffer [B,2H,2W,oc+skip] ahead of time and return its skip slice: a producer that
+        writes the skip tensor THERE makes ``tf.concat([x, skip])`` (Decoder.py:66) free."""
+        self._cat = ops.new_act(B, 2 * H, 2 * W, self.out_channels + self.skip_channels, device)
+        return self._cat[..., self.out_channels:]
+
     def forward(self, x, skip=None, out=None):
         """x [B,h,w,in]; skip [B,2h,2w,skip] or None; ``out``: optional [B,2h,2w,oc] slice to write the result into."""
         B, H, W, _, _ = ops.geom(x)
@@ -165,12 +171,16 @@ class DecoderBlock(nn.Module):
         has_skip = skip is not None
         c1 = oc + (self.skip_channels if has_skip else 0)
         assert has_skip or self.skip_channels == 0, "block was built for a skip connection"
-        cat = ops.new_act(B, 2 * H, 2 * W, c1, dev)
+        pre = getattr(self, "_cat", None)
+        in_place = (has_skip and pre is not None and tuple(pre.shape) == (B, 2 * H, 2 * W, c1)
+                    and skip.data_ptr() == pre[..., oc:].data_ptr() and ops.geom(skip)[4] == c1)
+        cat = pre if in_place else ops.new_act(B, 2 * H, 2 * W, c1, dev)
+        self._cat = None
         if self._qup is not None:
             self._qup.forward(x, out=cat[..., :oc])
         else:
             self.up.forward(x, out=cat[..., :oc])                                     # :63
-        if has_skip:
+        if has_skip and not in_place:
             ops.copy_channels(skip, cat[..., oc:])                                    # :66
         self._fold = _FOLD_BN and not any(getattr(self, f"bn{st}_{j}").training_mode for st in ("1", "2") for j in range(4))
         out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, oc, dev)
@@ -249,6 +259,12 @@ class DecoderCup(nn.Module):
     def _head_backward(self, dl4):
         return self._quad.backward(dl4)
 
+    def prepare(self, B, device):
+        """Allocate the blocks' concat buffers ahead of the encoder and return the destinations [x_3, x_2, x_1] for its stage
+        outputs (``ResNest.forward(x, outs=...)``): the skip connections then need no copy (Decoder.py:66)."""
+        gh, gw = self.grid
+        return [blk.skip_slot(B, gh * 2 ** i, gw * 2 ** i, device) for i, blk in enumerate(self.blocks)]
+
     def forward(self, hidden_states, features: Optional[List[torch.Tensor]] = None, return_logits=False):
         assert features is not None, "this implementation is built for the skip-connected configuration the drivers use"
         B = hidden_states.shape[0]
@@ -257,16 +273,18 @@ class DecoderCup(nn.Module):
         dev = hidden_states.device
         y = hidden_states.reshape(B, gh, gw, hs)                                      # :128 (a view: same memory)
         self._hidden_shape = hidden_states.shape
+        # the hidden state re-injected at every scale by a raw row-major reshape (:140-141): all three scales in one launch
+        cats, slots = [], []
+        for i, blk in enumerate(self.blocks):
+            s, c0 = 2 ** (i + 1), hs // (4 ** (i + 1))
+            cats.append(ops.new_act(B, gh * s, gw * s, blk.out_channels + c0, dev))
+            slots.append(cats[i][..., blk.out_channels:])
+        ops.reinject_hidden(y if y.is_contiguous() else y.contiguous(), slots, backward=False)
         x = self.conv_more.forward(y)                                                 # :129
         x = self.bn1.forward(x, ACT_LRELU, KERAS_LRELU_ALPHA)                         # :130-131
         for i, blk in enumerate(self.blocks):                                         # :132
-            s = 2 ** (i + 1)
-            c0 = hs // (4 ** (i + 1))
-            cat = ops.new_act(B, gh * s, gw * s, blk.out_channels + c0, dev)
-            blk.forward(x, features[i], out=cat[..., :blk.out_channels])              # :137
-            x0 = y.reshape(B, gh * s, gw * s, c0)                                     # :140 raw row-major reinterpretation
-            ops.copy_channels(x0, cat[..., blk.out_channels:])                        # :141
-            x = cat
+            blk.forward(x, features[i], out=cats[i][..., :blk.out_channels])          # :137 (x0 already sits behind it, :140-141)
+            x = cats[i]
         Ho, Wo = 2 * x.shape[1], 2 * x.shape[2]
         self.out_hw = (Ho, Wo)
         # :142; logits fp32: [B,Ho,Wo,4] or, in quad form, [B,Ho/2,Wo/2,16] (softmax_loss indexes it through quad_w)
@@ -291,14 +309,12 @@ class DecoderCup(nn.Module):
         d = self._head_backward(dlogits) if self.quad_head else self.head.backward(dlogits)
         d_hidden = ops.new_act(B, gh, gw, hs, dev)
         dfeats = [None, None, None]
-        first = True
+        reinj = []                                   # gradient slices of the three re-injections (views keep their buffers alive)
         for i in reversed(range(3)):
             blk = self.blocks[i]
-            s = 2 ** (i + 1)
-            c0 = hs // (4 ** (i + 1))
-            ops.copy_channels(d[..., blk.out_channels:], d_hidden.reshape(B, gh * s, gw * s, c0), accumulate=not first)
-            first = False
+            reinj.append(d[..., blk.out_channels:])
             d, dfeats[i] = blk.backward(d[..., :blk.out_channels])
+        ops.reinject_hidden(d_hidden, reinj, backward=True)                           # d_hidden = sum of the three, one launch
         d = self.bn1.backward(d, dbias=self.conv_more.bias.grad)
         self.conv_more.backward(d, dx=d_hidden, accumulate_dx=True, skip_bias=True)
         return d_hidden.reshape(self._hidden_shape), dfeats

@@ -293,8 +293,10 @@ class ResNest(nn.Module):
         self.conv_3 = residual_S(ksize, 256, radix, kpaths, wDecay=wDecay, in_channels=128)
         self.conv_4 = residual_S(ksize, 512, radix, kpaths, wDecay=wDecay, in_channels=256)
 
-    def forward(self, x):
-        """x: NHWC float32/float64 [B,H,W,channel] (cast to bf16 here, ResNest.py:39) or an already-cast bf16 tensor."""
+    def forward(self, x, outs=None):
+        """x: NHWC float32/float64 [B,H,W,channel] (cast to bf16 here, ResNest.py:39) or an already-cast bf16 tensor.
+        ``outs``: optional destinations [x_3, x_2, x_1] (channel-slice views allowed) the stage outputs are written into."""
+        o3, o2, o1 = outs if outs is not None else (None, None, None)
         if x.dtype != BF16:
             x = ops.cast_input(x.contiguous(), roundup(self.channel, 8))
         a = KERAS_LRELU_ALPHA
@@ -310,9 +312,9 @@ class ResNest(nn.Module):
             t = self.convtmp_2.forward(t)                                                        # :44
             t = self.convtmp_2bn.forward(t, ACT_LRELU, a)                                        # :45-46
         t = self.conv1_pool.forward(t)                                                           # :47
-        x_1 = self.conv_1.forward(t)                                                             # :48
-        x_2 = self.conv_2.forward(self.conv2_pool.forward(x_1))                                  # :49-50
-        x_3 = self.conv_3.forward(self.conv3_pool.forward(x_2))                                  # :51-52
+        x_1 = self.conv_1.forward(t, out=o1)                                                     # :48
+        x_2 = self.conv_2.forward(self.conv2_pool.forward(x_1), out=o2)                          # :49-50
+        x_3 = self.conv_3.forward(self.conv3_pool.forward(x_2), out=o3)                          # :51-52
         x_4 = self.conv_4.forward(self.conv4_pool.forward(x_3))                                  # :53-54
         return x_4, [x_3, x_2, x_1]                                                              # :55
 

@@ -491,7 +491,6 @@ class ResNest(TrainStepDriver):
         scale = torch.empty(H * W * Cc, dtype=torch.float32, device=self.device)
         loss = torch.empty(H * W, dtype=torch.float32, device=self.device)
         ops.loss_cat_scale(y_true, scale)
-        ops.fill_f32(loss, 0.0)
         ops.loss_from_probs(y_pred, y_true, loss, HW=H * W, C_classes=Cc, loss_kind=1, scale=scale)
         return loss.reshape(H, W)
 
@@ -517,9 +516,8 @@ class ResNest(TrainStepDriver):
         probs = torch.empty((B, H, W, self.num_class), dtype=torch.float32, device=self.device)
         dlogits = None
         if with_grad:
-            dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device, zero=True) if qw else ops.new_act(B, H, W, 8, self.device)
-        ops.loss_cat_scale(y, self._scale)                                                     # :240-241
-        ops.fill_f32(self._loss_map, 0.0)
+            dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device) if qw else ops.new_act(B, H, W, 8, self.device)
+        ops.loss_cat_scale(y, self._scale)                                                     # :240-241 (the loss map is overwritten)
         ops.softmax_loss(logits, y, probs, self._loss_map, dlogits, HW=H * W, C_classes=self.num_class, loss_kind=1,
                          scale=self._scale, quad_w=qw)                                         # :125, :234-248
         return probs, dlogits

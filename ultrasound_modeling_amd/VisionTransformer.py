@@ -19,6 +19,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import Decoder as _DEC
+from . import ResNest as _ENC
 from .Decoder import DecoderBlock, DecoderCup
 from .flat import AdamClip, FlatParams
 from .layers import BatchNormalization, Conv2D, LayerNormalization, _Workspace
@@ -53,8 +55,8 @@ def repack_all(root: nn.Module):
         table = (ops.make_pack_table(jobs, dev), len(jobs), ops.make_bn_fold_table(folds, dev) if folds else None, len(folds))
         object.__setattr__(root, "_pack_table", table)
     ops.pack_weights_batched(table[0], table[1])
-    if table[3]:
-        ops.bn_fold_batched(table[2], table[3])     # folded inference BatchNorm constants of the conv epilogues
+    if table[3] and (_DEC._FOLD_BN or _ENC._FOLD_BN):
+        ops.bn_fold_batched(table[2], table[3])     # folded inference BatchNorm constants of the conv epilogues (USSEG_FOLD_BN=1 only)
 
 
 class Embeddings(nn.Module):
@@ -68,8 +70,10 @@ class Embeddings(nn.Module):
         self.hybrid_model = ResNest(img_size[0], img_size[1], in_channels, radix=3, ksize=3, kpaths=3)   # :100
         self.patch_embeddings = Conv2D(512, hidden_size, 1, init="glorot")                                # :106
 
-    def forward(self, x):
-        x4, features = self.hybrid_model.forward(x)                                   # :113
+    def forward(self, x, feature_slots=None):
+        """``feature_slots``: optional [x_3, x_2, x_1] destinations (the skip slices of the decoder's concat buffers): the
+        encoder stages write their outputs there, so ``tf.concat([x, skip])`` (Decoder.py:66) costs no copy."""
+        x4, features = self.hybrid_model.forward(x, outs=feature_slots)               # :113
         e = self.patch_embeddings.forward(x4)                                         # :114
         B = e.shape[0]
         return e.reshape(B, self.seq_len, self.hidden_size), features                 # :116 (+ zeros, :118; dropout 0)
@@ -242,8 +246,8 @@ class Transformer(nn.Module):
         self.embeddings = Embeddings(img_size=img_size, in_channels=in_channels)
         self.encoder = Encoder(img_size[0], img_size[1], wDecay=wDecay) if use_vit else None
 
-    def forward(self, input_ids):
-        embedding_output, features = self.embeddings.forward(input_ids)
+    def forward(self, input_ids, feature_slots=None):
+        embedding_output, features = self.embeddings.forward(input_ids, feature_slots)
         if self.encoder is None:
             return embedding_output, [], features
         B, N, hs = embedding_output.shape
@@ -353,20 +357,20 @@ class VisionTransformer(TrainStepDriver, nn.Module):
 
     def forward(self, x):
         """-> (probs fp32 [B,H,W,classes], attn_weights) (:220-223)."""
-        hidden, attn_weights, features = self.transformer.forward(self._prep_x(x))
+        x = self._prep_x(x)
+        hidden, attn_weights, features = self.transformer.forward(x, feature_slots=self.decoder.prepare(x.shape[0], self.device))
         return self.decoder.forward(hidden, features), attn_weights
 
     def _forward_loss(self, x, y, with_grad: bool):
-        hidden, _, features = self.transformer.forward(x)
+        hidden, _, features = self.transformer.forward(x, feature_slots=self.decoder.prepare(x.shape[0], self.device))
         logits = self.decoder.forward(hidden, features, return_logits=True)
         B = logits.shape[0]
         H, W = self.decoder.out_hw
         qw = self.decoder.quad_w                 # head in quad form: logits / dlogits are [B,H/2,W/2,16]
         probs = torch.empty((B, H, W, self.num_classes), dtype=torch.float32, device=self.device)
         dlogits = None
-        if with_grad:
-            dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device, zero=True) if qw else ops.new_act(B, H, W, 8, self.device)
-        ops.fill_f32(self._loss, 0.0)
+        if with_grad:   # quad layout: the four pixels of a 2x2 block fill all 16 channels of their quad pixel, so no zero-fill
+            dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device) if qw else ops.new_act(B, H, W, 8, self.device)
         ops.softmax_loss(logits, y, probs, self._loss, dlogits, HW=H * W, C_classes=self.num_classes, loss_kind=0,
                          label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=1.0 / float(self.batch_size), quad_w=qw)   # :205,:227
         return probs, dlogits

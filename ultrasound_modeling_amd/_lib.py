@@ -149,6 +149,8 @@ _PROTOS = {
     "usseg_loss_cat_scale": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "usseg_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "usseg_sumsq": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "usseg_sumsq_advance": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),
+    "usseg_reinject_hidden": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "usseg_adam_clip_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_f32, c_f32, c_f32, c_vp]),
     "usseg_adam_advance": (C.c_int, [c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),
     "usseg_fill_f32": (C.c_int, [c_vp, c_i64, c_f32, c_vp]),

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const UssegLossDesc d
     for (int64_t hw = (int64_t)blockIdx.x * 256 + threadIdx.x; hw < d.HW; hw += (int64_t)gridDim.x * 256) {
       float l = 0.f;
       for (int b = 0; b < nb; ++b) l += softmax_loss_pixel(d, (int64_t)b * d.HW + hw, logits, y_true, scale, probs, dlogits);
-      loss[hw] += l;
+      loss[hw] = l;
     }
     return;
   }
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void loss_from_probs_kernel(const UssegLossDes
     for (int64_t hw = (int64_t)blockIdx.x * 256 + threadIdx.x; hw < d.HW; hw += (int64_t)gridDim.x * 256) {
       float l = 0.f;
       for (int b = 0; b < nb; ++b) l += loss_from_probs_pixel(d, (int64_t)b * d.HW + hw, probs, y_true, scale);
-      loss[hw] += l;
+      loss[hw] = l;
     }
     return;
   }
@@ -667,7 +667,7 @@ extern "C" int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, 
 }
 
 // ------------------------------------------------------------------------------------------ optimiser
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, float* out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, float* out, int32_t* step, float* lr_t, float lr, float b1, float b2) {
   __shared__ float red[4];
   float s = 0.f;
   int64_t n4 = n >> 2;
@@ -691,15 +691,27 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, f
   for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), out, gridDim.x);   // reproducible: the clip factor scales every update
+  const bool last = grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), out, gridDim.x);   // reproducible: the clip factor scales every update
+  if (last && step && threadIdx.x == 0) {   // usseg_sumsq_advance: the optimiser's step counter moves on in the same launch
+    const int t = *step + 1;
+    *step = t;
+    *lr_t = lr * sqrtf(1.f - powf(b2, (float)t)) / (1.f - powf(b1, (float)t));
+  }
+}
+static int sumsq_launch(const float* g, int64_t n, float* out, int32_t* step, float* lr_t, float lr, float b1, float b2, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(g && out && n > 0 && ((uintptr_t)g % 16) == 0, "sumsq: bad args (g must be 16-byte aligned, n > 0)");   // out[0] is OVERWRITTEN
+  int64_t grid = cdiv64(n, 256 * 16);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, out, step, lr_t, lr, b1, b2);
+  return usseg_check_launch("sumsq");
 }
 extern "C" int usseg_sumsq(const float* g, int64_t n, float* out, usseg_stream_t stream) {
-  USSEG_CHECK_ARG(g && out && n >= 0 && ((uintptr_t)g % 16) == 0, "sumsq: bad args (g must be 16-byte aligned)");
-  if (n == 0) return USSEG_OK;
-  int64_t grid = cdiv64(n, 256 * 16);
-  if (grid > 256) grid = 256;          // one same-address atomic per workgroup at the end: keep them few
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
-  return usseg_check_launch("sumsq");
+  return sumsq_launch(g, n, out, nullptr, nullptr, 0.f, 0.f, 0.f, stream);
+}
+extern "C" int usseg_sumsq_advance(const float* g, int64_t n, float* out, int32_t* step, float* lr_t_dev, float lr, float beta1, float beta2,
+                                   usseg_stream_t stream) {
+  USSEG_CHECK_ARG(step && lr_t_dev, "sumsq_advance: null pointer");
+  return sumsq_launch(g, n, out, step, lr_t_dev, lr, beta1, beta2, stream);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,

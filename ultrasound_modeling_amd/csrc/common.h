@@ -52,32 +52,37 @@ __device__ __forceinline__ float act_grad(float v, int act, float alpha) {
 }
 
 // ---- bitwise reproducible grid-wide sum (no float atomics: their arrival order changes the rounding from run to run) ----------------
-// acc[0] accumulates the result, acc[1] is a ticket counter (zero before and after the call), acc[2 + b] holds workgroup b's
-// total.  Every workgroup (256 threads) stores its total; the LAST one to arrive adds all of them in workgroup order with a
-// fixed tree.  Partials are moved with agent-scope atomic loads / stores and fenced, so the eight XCD L2s agree on them.
+// acc[0] receives the result (overwritten), acc[1] is a ticket counter (zero before and after the call), acc[2 + b] holds workgroup b's
+// total.  Every workgroup (256 threads) publishes its total; the LAST one to arrive adds all of them in workgroup order with a
+// fixed tree.  No __threadfence(): an agent-scope release writes back the XCD's dirty L2 lines, which costs a kernel that also
+// streams tens of MB of stores (the fused softmax + loss kernel went from 36 to 74 us with it).  Ordering comes from data flow
+// instead: the partial is published with a RETURNING agent-scope atomic exchange (executed at the memory side), the ticket
+// increment consumes that return value, and the last workgroup reads the partials with agent-scope atomic loads.
 /* USSEG_ACC_FLOATS (usseg.h) = 2 + the largest grid of the kernels that use it */
-__device__ __forceinline__ void grid_ordered_sum(float block_total /* thread 0 */, float* acc, int nblocks) {
+__device__ __forceinline__ bool grid_ordered_sum(float block_total /* thread 0 */, float* acc, int nblocks) {
   __shared__ int s_last;
   __shared__ float s_w[4];
   if (threadIdx.x == 0) {
-    __hip_atomic_store(acc + 2 + blockIdx.x, block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(acc + 1), 1u);
+    const float old = __hip_atomic_exchange(acc + 2 + blockIdx.x, block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned zero = 0u;
+    asm volatile("; ticket after the partial is at the memory side" : "+v"(zero) : "v"(old));
+    const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(acc + 1), 1u + zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == (unsigned)nblocks - 1u);
   }
   __syncthreads();
-  if (!s_last) return;
-  __threadfence();
+  if (!s_last) return false;
   float s = 0.f;
   for (int b = threadIdx.x; b < nblocks; b += 256) s += __hip_atomic_load(acc + 2 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 64);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    acc[0] += (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    acc[0] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);     // OVERWRITES: no zero-fill launch in front of the kernel
     __hip_atomic_store(reinterpret_cast<unsigned*>(acc + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  return true;
 }
+// (returns true in the workgroup that performed the final addition: for work that must follow the sum)
 
 // ---- shared epilogue of the conv kernels (16x16 MFMA layout: a lane holds Y[pixel = lane&15][n = nbase + 16*bt + j]) ----------------
 // vmcnt retires in issue order and counts stores, so a load issued after a store waits for that store's write latency

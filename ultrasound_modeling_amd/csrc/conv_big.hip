@@ -404,9 +404,15 @@ static void big_launch(BigParams& P, int njobs, int nt, int PX, hipStream_t s, i
     if (p.gy > gy) gy = p.gy;
     if (p.npa > npa) npa = p.npa;
   }
-  // one LDS stage with two or more workgroups per CU measured 1.3-1.4x faster than a double-buffered single workgroup
-  static const int stages_env = getenv("USSEG_BIG_STAGES") ? atoi(getenv("USSEG_BIG_STAGES")) : 1;
-  const int nstages = stages_env == 2 ? 2 : 1;
+  // One LDS stage with several co-resident workgroups per CU measured 1.3-1.4x faster than a double-buffered single workgroup -
+  // but when the launch has at most two workgroups per CU there is nobody to overlap with, and the second stage (the next
+  // chunk's DMA in flight under this chunk's MFMAs) wins: -10...-15 % on concats_2 256->512 @16x16, conv_more and the decoder's
+  // 512->64 branches at batch 16 and 32 (tools/bench_conv.py, round 2), +15...+30 % when forced on the 1024-workgroup launches.
+  // USSEG_BIG_STAGES: 0 = this rule (default), 1 / 2 = forced.
+  static const int stages_env = getenv("USSEG_BIG_STAGES") ? atoi(getenv("USSEG_BIG_STAGES")) : 0;
+  int64_t total_wg = 0;
+  for (int j = 0; j < njobs; ++j) total_wg += (int64_t)P.job[j].gx * P.job[j].gy;
+  const int nstages = stages_env == 2 ? 2 : (stages_env == 1 ? 1 : (total_wg <= 512 ? 2 : 1));
   for (int j = 0; j < njobs; ++j) { P.job[j].npa = npa; P.job[j].nstages = nstages; }   // one stage layout for the whole launch
   const size_t dyn = nstages * ((size_t)npa * 1024 + (size_t)9 * 16 * nt * 64);
   const dim3 grid(gx, gy, njobs);

@@ -536,6 +536,51 @@ extern "C" int usseg_copy_channels(const void* src, int64_t M, int32_t C, int32_
   return usseg_check_launch("copy_channels");
 }
 
+// The decoder re-injects the hidden state at every scale through a RAW row-major reshape (Decoder.py:140-141):
+// hidden [B][N][hidden] seen as [B][gh*s][gw*s][c0] is concatenated behind the block output, c0 = hidden / 4^(i+1).  All three
+// scales in ONE launch: forward scatters each 8-element vector of the hidden state into its three destinations, backward
+// gathers the three gradient slices, adds them in fp32 and writes d_hidden once (three copy launches each way before).
+struct ReinjectParams {
+  bf16_t* buf[4];
+  int32_t c0[4], ld[4];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void reinject_hidden_kernel(bf16_t* hidden, int64_t nvec, const ReinjectParams q, int backward) {
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    const int64_t e = v * 8;
+    if (!backward) {
+      const uint4 val = *reinterpret_cast<const uint4*>(hidden + e);
+      for (int i = 0; i < q.n; ++i) {
+        const int64_t pix = e / q.c0[i];
+        *reinterpret_cast<uint4*>(q.buf[i] + pix * q.ld[i] + (int)(e - pix * q.c0[i])) = val;
+      }
+    } else {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, t[8];
+      for (int i = 0; i < q.n; ++i) {
+        const int64_t pix = e / q.c0[i];
+        unpack8(*reinterpret_cast<const uint4*>(q.buf[i] + pix * q.ld[i] + (int)(e - pix * q.c0[i])), t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += t[j];
+      }
+      *reinterpret_cast<uint4*>(hidden + e) = pack8(acc);
+    }
+  }
+}
+extern "C" int usseg_reinject_hidden(void* hidden, int64_t numel, int32_t n, void* const* bufs, const int32_t* c0, const int32_t* ld,
+                                     int32_t backward, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(hidden && bufs && c0 && ld && n >= 1 && n <= 4 && numel % 8 == 0, "reinject_hidden: bad args");
+  ReinjectParams q = {};
+  q.n = n;
+  for (int i = 0; i < n; ++i) {
+    USSEG_CHECK_ARG(bufs[i] && c0[i] >= 8 && c0[i] % 8 == 0 && ld[i] % 8 == 0 && ld[i] >= c0[i] && numel % c0[i] == 0, "reinject_hidden: bad view");
+    q.buf[i] = (bf16_t*)bufs[i]; q.c0[i] = c0[i]; q.ld[i] = ld[i];
+  }
+  if (numel <= 0) return USSEG_OK;
+  hipLaunchKernelGGL(reinject_hidden_kernel, dim3(grid_for(numel / 8, 256 * 2, 4096)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)hidden, numel / 8, q,
+                     backward);
+  return usseg_check_launch("reinject_hidden");
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cast_input_kernel(const T* src, int64_t M, int C, bf16_t* dst, int Cphys) {
   const int CH = Cphys / 8;

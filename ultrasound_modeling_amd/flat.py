@@ -99,8 +99,7 @@ class AdamClip:
         self.sumsq = torch.zeros(ops.ACC_FLOATS, dtype=torch.float32, device=dev)   # [0] = squared global norm (reproducible accumulator)
 
     def global_norm_sq(self):
-        ops.fill_f32(self.sumsq, 0.0)
-        ops.sumsq(self.flat.grad, self.sumsq)
+        ops.sumsq(self.flat.grad, self.sumsq)        # sumsq[0] is overwritten: no zero-fill launch
         return self.sumsq
 
     def clip_local(self):
@@ -120,11 +119,13 @@ class AdamClip:
                            self.eps)
 
     def apply(self, already_clipped: bool = False):
-        self.advance()
         clip = 0.0
         if self.clip_norm is not None and not already_clipped:
-            self.global_norm_sq()
+            # squared global norm and the step counter in one launch
+            ops.sumsq_advance(self.flat.grad, self.sumsq, self.step_dev, self.lr_t_dev, self.lr, self.b1, self.b2)
             clip = float(self.clip_norm)
+        else:
+            self.advance()
         self.apply_range(0, self.flat.total, clip)
 
     def state_tensors(self):

@@ -244,8 +244,8 @@ class QuadHead:
         self.wq_f = torch.zeros((16, 9 * cin_p), dtype=BF16, device=device)
         self.wq_d = torch.zeros((roundup(cin_p, 16), 9 * 16), dtype=BF16, device=device)
         self.bias16 = torch.zeros(16, dtype=torch.float32, device=device)
-        self.d16 = torch.zeros(16, dtype=torch.float32, device=device)
-        self.dq = torch.zeros(9 * cin_p * 16, dtype=torch.float32, device=device)
+        self._dq16 = torch.zeros(9 * cin_p * 16 + 16, dtype=torch.float32, device=device)      # one buffer: one zero-fill launch
+        self.dq, self.d16 = self._dq16[:9 * cin_p * 16], self._dq16[9 * cin_p * 16:]
         jobs = self.pack_jobs()
         ops.pack_weights_batched(ops.make_pack_table(jobs, device), len(jobs))
 
@@ -276,13 +276,14 @@ class QuadHead:
         """dl4: bf16 [B,h,w,16] gradient of the quad-form logits -> dx [B,h,w,cin]."""
         h, x = self.head, self._x
         with ops.side_stream(x, dl4):
-            ops.fill_f32(self.dq, 0.0)
-            ops.fill_f32(self.d16, 0.0)
+            ops.fill_f32(self._dq16, 0.0)
             ops.conv2d_wgrad(x, dl4, 3, 1, self.dq)
             ops.colsum(dl4, self.d16, 16)
-            ops.defer_flush()                                      # dq / d16 are read right away
-            ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, 4, h.k, h.kernel.grad)
-            ops.quad_bias_fold(self.d16, h.cout, h.bias.grad)
+
+            def fold():     # dq / d16 are complete once the deferred finishing reductions have run: fold them into the Keras variables then
+                ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, 4, h.k, h.kernel.grad)
+                ops.quad_bias_fold(self.d16, h.cout, h.bias.grad)
+            ops.after_flush(fold)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)

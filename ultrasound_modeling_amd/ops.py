@@ -56,6 +56,7 @@ class _Side:
     keep = []
     dirty = False
     deferring = set()      # stream handles with an open deferral context
+    post = []              # callbacks that run after the region's final flush (ops.after_flush)
     bufs = {}
 
 
@@ -93,6 +94,17 @@ def defer_flush():
         L.check(L.load().usseg_defer_flush(_stream()), "defer_flush")
 
 
+def after_flush(fn):
+    """Run ``fn`` once the finishing reductions queued so far have executed: at the end of the enclosing ``overlap_region``
+    (after its final flush - no extra finishing launches in the middle of the backward pass), or right away when nothing is
+    being deferred."""
+    if _Side.depth > 0 and _stream() in _Side.deferring and not (_Side.enabled and _Side.stream is not None and torch.cuda.current_stream() == _Side.stream):
+        _Side.post.append(fn)
+    else:
+        defer_flush()
+        fn()
+
+
 @contextlib.contextmanager
 def overlap_region():
     _Side.depth += 1
@@ -105,6 +117,9 @@ def overlap_region():
         if _Side.depth == 0:
             side_join()
             _defer_end()
+            post, _Side.post = _Side.post, []
+            for fn in post:
+                fn()
 
 
 @contextlib.contextmanager
@@ -529,6 +544,26 @@ def fill_f32(t: torch.Tensor, value: float = 0.0):
 def sumsq(g: torch.Tensor, out: torch.Tensor):
     assert out.numel() >= ACC_FLOATS, "sumsq accumulates through a USSEG_ACC_FLOATS buffer"
     L.check(L.load().usseg_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "sumsq")
+
+
+def sumsq_advance(g: torch.Tensor, out: torch.Tensor, step_dev, lr_t_dev, lr, b1, b2):
+    """sumsq + adam_advance in ONE launch (the last workgroup of the ordered sum moves the step counter on)."""
+    assert out.numel() >= ACC_FLOATS
+    L.check(L.load().usseg_sumsq_advance(g.data_ptr(), g.numel(), out.data_ptr(), step_dev.data_ptr(), lr_t_dev.data_ptr(), lr, b1, b2, _stream()),
+            "sumsq_advance")
+
+
+def reinject_hidden(hidden: torch.Tensor, views, backward: bool):
+    """Decoder.py:140-141 for all scales at once.  ``hidden``: contiguous bf16 tensor; ``views``: channel-slice views
+    [B,h_i,w_i,c0_i] of the concat buffers (forward: written; backward: their gradients, summed into ``hidden``)."""
+    assert hidden.is_contiguous() and hidden.dtype == BF16 and 1 <= len(views) <= 4
+    n = len(views)
+    bufs = (C.c_void_p * n)(*[v.data_ptr() for v in views])
+    c0 = (C.c_int32 * n)(*[v.shape[3] for v in views])
+    ld = (C.c_int32 * n)(*[geom(v)[4] for v in views])
+    for v in views:
+        assert v.numel() == hidden.numel()
+    L.check(L.load().usseg_reinject_hidden(hidden.data_ptr(), hidden.numel(), n, bufs, c0, ld, 1 if backward else 0, _stream()), "reinject_hidden")
 
 
 def scale_by_clip(g: torch.Tensor, sumsq_t: torch.Tensor, clip_norm: float):
