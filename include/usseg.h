@@ -239,6 +239,18 @@ int usseg_dropout_mask_step(void* mask, int64_t M, int32_t C, int32_t ld, uint64
 int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma, const float* beta,
                        const float* mean, const float* var, const void* mask, int32_t ldm, void* dx, float* dgamma,
                        float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
+/* The split attention of a residual_S stage (ResNest.py:171-199) folded into the norms on either side of it:
+ *  - usseg_norm_act_fwd_gap: the norm + activation that produces the cardinal output ALSO writes, per image and workgroup, the
+ *    partial sums of its (bf16) output over the pixels: gap_rows [B][nb][Cphys] - the global average pool of ResNest.py:179
+ *    without a pass over the tensor (usseg_splitattn_mlp_fwd adds the nb rows);
+ *  - usseg_norm_act_bwd_sa: the norm backward whose incoming gradient is the re-weighting's backward
+ *    dy = sa_mult * sa_s[b][c] * dout + sa_dg[b][c]  (identical radix branches: R == 1 in the descriptor), formed in registers
+ *    (replaces usseg_splitattn_apply_bwd_dy + the tensor it wrote).  d->M must be B * pixels-per-image. */
+int usseg_norm_act_fwd_gap(const UssegNormDesc* d, const void* x, const float* gamma, const float* beta, const float* mean,
+                           const float* var, void* y, int32_t B, int32_t nb, float* gap_rows, usseg_stream_t stream);
+int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, const void* dout, const float* gamma, const float* beta,
+                          const float* mean, const float* var, int32_t B, const float* sa_s, const float* sa_dg, float sa_mult,
+                          void* dx, float* dgamma, float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
 /* Every per-channel reduction (norm backward, colsum, channel_stats, split-attention reductions) writes one partial
  * row per workgroup into the caller's fp32 workspace `ws` (at least usseg_reduce_ws_floats() floats) and a finishing
  * kernel ADDS the column sums to the destination: no atomics, bitwise reproducible.
@@ -310,8 +322,10 @@ typedef struct UssegSplitAttnGrads {
 int usseg_splitattn_gap(const UssegSplitAttnDesc* d, const void* y, float* g, float* ws, usseg_stream_t stream);
 /* ws: fp32 workspace of usseg_splitattn_ws_floats(d) floats holding the saved MLP intermediates */
 int64_t usseg_splitattn_ws_floats(const UssegSplitAttnDesc* d);
-int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, float* s,
-                            float* ws, usseg_stream_t stream);
+/* g = pooled sums as [B][g_rows][g_stride] partial rows which the kernel adds up: (1, Cy) for the vector usseg_splitattn_gap
+ * wrote, or the rows usseg_norm_act_fwd_gap produced (g_rows = its nb, g_stride = Cphys) - no pooling pass, no finishing launch */
+int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float* g, int32_t g_rows, int32_t g_stride,
+                            const UssegSplitAttnParams* p, float* s, float* ws, usseg_stream_t stream);
 int usseg_splitattn_apply_fwd(const UssegSplitAttnDesc* d, const void* y, const float* s, void* out,
                               usseg_stream_t stream);
 /* backward: (1) ds[b][p][r][c] = sum_hw mult*y*dout (ds is OVERWRITTEN) (2) MLP backward -> dg, param grads
@@ -321,9 +335,9 @@ int usseg_splitattn_apply_bwd_reduce(const UssegSplitAttnDesc* d, const void* y,
 /* grad_ws: usseg_splitattn_mlp_bwd_ws_floats(d) floats - one row of parameter-gradient partials per (path, image); the rows
  * are added into the variables in image order by a finishing reduction (no float atomics: bitwise reproducible). */
 int64_t usseg_splitattn_mlp_bwd_ws_floats(const UssegSplitAttnDesc* d);
-int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, const float* s,
-                            const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads, float* grad_ws,
-                            usseg_stream_t stream);
+int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, int32_t g_rows, int32_t g_stride,
+                            const UssegSplitAttnParams* p, const float* s, const float* ws, const float* ds, float* dg,
+                            const UssegSplitAttnGrads* grads, float* grad_ws, usseg_stream_t stream);
 int usseg_splitattn_apply_bwd_dy(const UssegSplitAttnDesc* d, const void* dout, int32_t lddo, const float* s,
                                  const float* dg, void* dy, int32_t lddy, usseg_stream_t stream);
 

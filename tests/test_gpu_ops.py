@@ -430,6 +430,64 @@ def test_split_attention_shared_branches(gen, B, H, W, P, Cg, radix):
         assert rel(got, want) < 2e-3, (got.shape,)
 
 
+@pytest.mark.parametrize("B,H,W,P,Cg,radix", [(2, 8, 8, 3, 10, 3), (3, 16, 8, 3, 21, 3), (2, 4, 4, 3, 85, 3), (2, 32, 32, 3, 42, 3)])
+def test_split_attention_folded_into_its_norms(gen, B, H, W, P, Cg, radix):
+    """The residual_S chain LayerNorm+LeakyReLU -> split attention (ResNest.py:143-147,171-199) as the model runs it: the norm
+    launch also emits the pooled partial rows (no pooling pass), and the norm BACKWARD forms the re-weighting's backward
+    radix*s*dout + dg in registers (no apply pass, no dy tensor) - against the oracle chain, forward and every gradient."""
+    from ultrasound_modeling_amd import ops
+    Hd, V = Cg // 2, P * Cg
+    Vp = (V + 7) // 8 * 8
+    v_raw = bf(rnd(gen, B, H, W, V) * 1.5 + 0.2)
+    f = lambda *s, sc=1.0: (torch.randn(*s, generator=gen, dtype=torch.float64) * sc).float().double()
+    g2, be2 = 1 + f(V, sc=0.2), f(V, sc=0.1)
+    w1, b1 = f(P, Cg, Hd, sc=1 / math.sqrt(Cg)), f(P, Hd, sc=0.1)
+    ga, be = 1 + f(P, Hd, sc=0.2), f(P, Hd, sc=0.1)
+    w2, b2 = f(P, Hd, Cg, sc=1 / math.sqrt(Hd)), f(P, Cg, sc=0.1)
+    dout = rnd(gen, B, H, W, V)
+    leaves = [t.clone().requires_grad_(True) for t in (v_raw, g2, be2, w1, b1, ga, be, w2, b2)]
+    vr, g2_, be2_, w1_, b1_, ga_, be_, w2_, b2_ = leaves
+    outs, ys = [], []
+    for p in range(P):
+        sl = slice(p * Cg, (p + 1) * Cg)
+        yp = O.leaky_relu(O.layer_norm(vr[..., sl], g2_[sl], be2_[sl]))
+        ys.append(yp)
+        Pd = {"dense1.kernel": w1_[p].reshape(1, 1, Cg, Hd), "dense1.bias": b1_[p], "dense1_bn.gamma": ga_[p], "dense1_bn.beta": be_[p],
+              "dense2.kernel": w2_[p].reshape(1, 1, Hd, Cg), "dense2.bias": b2_[p]}
+        outs.append(O.split_attention([bf(yp.detach()) + (yp - yp.detach())] * radix, Pd, "", radix))   # the pool sees the STORED (bf16) y
+    ref = torch.cat(outs, -1)
+    (ref * dout).sum().backward()
+
+    dev = lambda t: t.float().contiguous().to(DEV)
+    pad = lambda t: torch.cat([t.float(), torch.zeros(Vp - V)]).to(DEV)
+    params = (dev(w1), dev(b1), dev(ga), dev(be), None, None, dev(w2), dev(b2))
+    xd = to_dev_padded(v_raw)
+    gam, bet = pad(g2), pad(be2)
+    y, gap = ops.norm_act_fwd_gap(xd, V, gam, bet, torch.empty_like(xd), 0, P, 1e-3, ops.ACT_LRELU, 0.3)
+    y_plain = ops.norm_act_fwd(xd, V, gam, bet, torch.empty_like(xd), 0, P, 1e-3, ops.ACT_LRELU, 0.3)
+    assert torch.equal(y, y_plain)                                   # same values as the plain launch, bit for bit
+    pooled = gap[0].sum(dim=1)[:, :V] / (H * W)
+    assert rel(pooled, y[..., :V].float().mean(dim=(1, 2))) < 1e-5
+    d = ops.splitattn_desc(B, H * W, P, 1, Cg, Hd, Vp, Vp, Vp, Vp, float(radix), 0, 1e-3, ops.ACT_LRELU, 0.3, radix == 1)
+    out, g, s, ws = ops.splitattn_fwd(d, y, params, ops.new_act(B, H, W, Vp, DEV), gap=gap)
+    assert rel(out[..., :V], bf(ref)) < REL_BF16
+    out2, *_ = ops.splitattn_fwd(d, y, params, ops.new_act(B, H, W, Vp, DEV))       # the pooling-pass form agrees
+    assert rel(out, out2) < 1e-3
+    grads = tuple(torch.zeros_like(t) for t in (params[0], params[1], params[2], params[3], params[6], params[7]))
+    doutd = to_dev_padded(dout)
+    sa_s, sa_dg = ops.splitattn_bwd(d, y, doutd, params, grads, g, s, ws, None)
+    dgam, dbet, dbias = torch.zeros(Vp, device=DEV), torch.zeros(Vp, device=DEV), torch.zeros(Vp, device=DEV)
+    dv = ops.norm_act_bwd_sa(xd, doutd, V, gam, bet, torch.empty_like(xd), dgam, dbet, 0, P, 1e-3, ops.ACT_LRELU, 0.3, sa_s, sa_dg, float(radix),
+                             dbias=dbias)
+    torch.cuda.synchronize()
+    assert rel(dv[..., :V], bf(vr.grad)) < 2 * REL_BF16
+    assert Vp == V or dv[..., V:].abs().max().item() == 0
+    assert rel(dgam[:V], g2_.grad) < 2e-3 and rel(dbet[:V], be2_.grad) < 2e-3
+    assert rel(dbias[:V], vr.grad.sum(dim=(0, 1, 2))) < 2e-3
+    for got, want in zip(grads, (w1_.grad, b1_.grad, ga_.grad, be_.grad, w2_.grad, b2_.grad)):
+        assert rel(got, want) < 2e-3, (got.shape,)
+
+
 # ------------------------------------------------------------------------------------------------ loss / optimiser
 def test_softmax_cce_loss_fwd_bwd(gen):
     from ultrasound_modeling_amd import ops

@@ -194,11 +194,12 @@ class _CardinalGroup:
         u_raw = ops.conv2d_fwd(x, self.w1_f, self.b1, 1, 1, ops.new_act(B, H, W, self.Up, dev))                 # :139
         u = ops.norm_act_fwd(u_raw, self.U, self.g1, self.be1, torch.empty_like(u_raw), 0, self.P, KERAS_LN_EPS, ACT_LRELU, a)  # :140-141
         v_raw = ops.conv2d_fwd(u, self.w2_f, self.b2, self.k, self.dil, ops.new_act(B, H, W, self.Vp, dev))    # :142
-        y = ops.norm_act_fwd(v_raw, self.V, self.g2, self.be2, torch.empty_like(v_raw), 0, self.P, KERAS_LN_EPS, ACT_LRELU, a)  # :143-144
+        # :143-144; the same launch emits the partial rows of the global average pool the split attention starts with (:179)
+        y, gap = ops.norm_act_fwd_gap(v_raw, self.V, self.g2, self.be2, torch.empty_like(v_raw), 0, self.P, KERAS_LN_EPS, ACT_LRELU, a)
         out = out if out is not None else ops.new_act(B, H, W, self.Vp, dev)
         d = self._sa_desc(B, H * W)
         params = self.mlp_p[:4] + (None, None) + self.mlp_p[4:]
-        _, g, s, ws = ops.splitattn_fwd(d, y, params, out)                                                        # :171-199
+        _, g, s, ws = ops.splitattn_fwd(d, y, params, out, gap=gap)                                               # :171-199
         self._saved = (x, u_raw, u, v_raw, y, g, s, ws)
         return out
 
@@ -210,9 +211,10 @@ class _CardinalGroup:
         T = self.k * self.k
         d = self._sa_desc(B, H * W)
         params = self.mlp_p[:4] + (None, None) + self.mlp_p[4:]
-        dy = ops.splitattn_bwd(d, y, dout, params, self.mlp_g, g, s, ws, torch.empty_like(y))
-        dv = ops.norm_act_bwd(v_raw, dy, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, 0, self.P,
-                              KERAS_LN_EPS, ACT_LRELU, a, dbias=self.db2)
+        # the re-weighting's backward (dy = radix*s*dout + dg) is formed inside the norm backward: no dy tensor, no apply pass
+        sa_s, sa_dg = ops.splitattn_bwd(d, y, dout, params, self.mlp_g, g, s, ws, None)
+        dv = ops.norm_act_bwd_sa(v_raw, dout, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, 0, self.P,
+                                 KERAS_LN_EPS, ACT_LRELU, a, sa_s, sa_dg, float(self.radix), dbias=self.db2)
         # grouped 3x3: dense wgrad into scratch, keep the diagonal blocks
         # grouped 3x3: the dense [T][Up][Vp] gradient is never materialised - only the diagonal blocks are scattered
         with ops.side_stream(u, dv):

@@ -128,9 +128,9 @@ class _SlabA:
         u_raw = ops.conv2d_fwd(x, self.w1_f, self.b1, 1, 1, ops.new_act(B, H, W, self.Up, dev))                      # :162
         u = ops.norm_act_fwd(u_raw, self.U, self.g1, self.be1, torch.empty_like(u_raw), 1, 1, e, ACT_ELU, 1.0, self.m1, self.v1)   # :164-165
         v_raw = ops.conv2d_fwd(u, self.w2_f, self.b2, self.k, 1, ops.new_act(B, H, W, self.Vp, dev))               # :167
-        y = ops.norm_act_fwd(v_raw, self.V, self.g2, self.be2, torch.empty_like(v_raw), 1, 1, e, ACT_ELU, 1.0, self.m2, self.v2)   # :169-170
+        y, gap = ops.norm_act_fwd_gap(v_raw, self.V, self.g2, self.be2, torch.empty_like(v_raw), 1, 1, e, ACT_ELU, 1.0, self.m2, self.v2)   # :169-170 (+ pooled partial rows)
         d = self._sa_desc(B, H * W, out)
-        _, g, s, ws = ops.splitattn_fwd(d, y, self.mlp_p, out)                                                        # :175-207
+        _, g, s, ws = ops.splitattn_fwd(d, y, self.mlp_p, out, gap=gap)                                               # :175-207
         self._saved = (x, u_raw, u, v_raw, y, g, s, ws)
         return out
 

@@ -128,11 +128,13 @@ _PROTOS = {
     "usseg_cast_bf16_to_f32": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "usseg_splitattn_gap": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp, c_vp]),
     "usseg_splitattn_ws_floats": (c_i64, [P(SplitAttnDesc)]),
-    "usseg_splitattn_mlp_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, P(SplitAttnParams), c_vp, c_vp, c_vp]),
+    "usseg_splitattn_mlp_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_i32, P(SplitAttnParams), c_vp, c_vp, c_vp]),
+    "usseg_norm_act_fwd_gap": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_norm_act_bwd_sa": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_splitattn_apply_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp, c_vp]),
     "usseg_splitattn_apply_bwd_reduce": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "usseg_splitattn_mlp_bwd_ws_floats": (c_i64, [P(SplitAttnDesc)]),
-    "usseg_splitattn_mlp_bwd": (C.c_int, [P(SplitAttnDesc), c_vp, P(SplitAttnParams), c_vp, c_vp, c_vp, c_vp,
+    "usseg_splitattn_mlp_bwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_i32, P(SplitAttnParams), c_vp, c_vp, c_vp, c_vp,
                                           P(SplitAttnGrads), c_vp, c_vp]),
     "usseg_splitattn_apply_bwd_dy": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "usseg_softmax_loss_fwd_bwd": (C.c_int, [P(LossDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

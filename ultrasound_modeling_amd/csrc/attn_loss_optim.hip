@@ -133,6 +133,7 @@ struct SaMlp {
   UssegSplitAttnParams p;
   UssegSplitAttnGrads gr;
   const float* g; float* s; float* ws; const float* ds; float* dg;
+  int32_t g_rows, g_stride;   // g = [B][g_rows][g_stride] partial rows of the pooled sums (1 row of Cy floats: already summed)
   float* gws;      // backward: per-(path, image) rows of parameter-gradient partials [w1 | b1 | gamma | beta | w2 | b2] (no atomics)
   int32_t Ctot;
 };
@@ -172,7 +173,14 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
   // gin[c] = mult/HW * sum_r g[b][(p*R+r)*Cg + c]     (ResNest.py:173-180)
   for (int c = tid; c < Cg; c += 128) {
     float v = 0.f;
-    for (int r = 0; r < R; ++r) v += a.g[(int64_t)b * Cy + (p * R + r) * Cg + c];
+    for (int r = 0; r < R; ++r) {
+      const float* gp = a.g + (int64_t)b * a.g_rows * a.g_stride + (p * R + r) * Cg + c;
+      float v0 = 0.f, v1 = 0.f;          // the rows are independent loads: two chains keep them in flight
+      int j = 0;
+      for (; j + 1 < a.g_rows; j += 2) { v0 += gp[(int64_t)j * a.g_stride]; v1 += gp[(int64_t)(j + 1) * a.g_stride]; }
+      if (j < a.g_rows) v0 += gp[(int64_t)j * a.g_stride];
+      v += v0 + v1;
+    }
     gin[c] = v * gscale;
   }
   __syncthreads();
@@ -301,14 +309,15 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
   }
 }
 
-extern "C" int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, float* s, float* ws,
-                                       usseg_stream_t stream) {
+extern "C" int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float* g, int32_t g_rows, int32_t g_stride, const UssegSplitAttnParams* p,
+                                       float* s, float* ws, usseg_stream_t stream) {
   int rc = sa_check(d);
   if (rc) return rc;
   USSEG_CHECK_ARG(g && p && s && ws && p->w1 && p->b1 && p->gamma && p->beta && p->w2 && p->b2, "null pointer");
   USSEG_CHECK_ARG(d->norm_mode == 0 || (p->mean && p->var), "affine norm needs mean/var");
+  USSEG_CHECK_ARG(g_rows >= 1 && g_stride >= d->P * d->R * d->Cg, "splitattn_mlp: bad pooled-row layout");
   SaMlp a = {};
-  a.d = *d; a.p = *p; a.g = g; a.s = s; a.ws = ws;
+  a.d = *d; a.p = *p; a.g = g; a.s = s; a.ws = ws; a.g_rows = g_rows; a.g_stride = g_stride;
   hipLaunchKernelGGL(sa_mlp_kernel<false>, dim3(d->B * d->P), dim3(128), 0, (hipStream_t)stream, a);
   return usseg_check_launch("splitattn_mlp_fwd");
 }
@@ -318,15 +327,17 @@ extern "C" int64_t usseg_splitattn_mlp_bwd_ws_floats(const UssegSplitAttnDesc* d
   return (int64_t)d->B * d->P * (d->Cg * d->Hd + 3 * d->Hd + d->R * d->Hd * d->Cg + d->R * d->Cg);
 }
 
-extern "C" int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, const UssegSplitAttnParams* p, const float* s,
-                                       const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads, float* grad_ws,
-                                       usseg_stream_t stream) {
+extern "C" int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, int32_t g_rows, int32_t g_stride, const UssegSplitAttnParams* p,
+                                       const float* s, const float* ws, const float* ds, float* dg, const UssegSplitAttnGrads* grads,
+                                       float* grad_ws, usseg_stream_t stream) {
   int rc = sa_check(d);
   if (rc) return rc;
   USSEG_CHECK_ARG(g && p && s && ds && dg && grads && grad_ws, "null pointer");
+  USSEG_CHECK_ARG(g_rows >= 1 && g_stride >= d->P * d->R * d->Cg, "splitattn_mlp: bad pooled-row layout");
   USSEG_CHECK_ARG(grads->w1 && grads->b1 && grads->gamma && grads->beta && grads->w2 && grads->b2, "null grad pointer");
   SaMlp a = {};
   a.d = *d; a.p = *p; a.gr = *grads; a.g = g; a.s = const_cast<float*>(s); a.ws = const_cast<float*>(ws); a.ds = ds; a.dg = dg;
+  a.g_rows = g_rows; a.g_stride = g_stride;
   const int Cg = d->Cg, Hd = d->Hd, R = d->R;
   a.Ctot = Cg * Hd + 3 * Hd + R * Hd * Cg + R * Cg;
   a.gws = usseg_defer_reduce_ws((hipStream_t)stream, grad_ws, (int64_t)d->B * d->P * a.Ctot);   // a private region while finishes are deferred

@@ -55,13 +55,23 @@ struct NormParams {
   int64_t M;
   int32_t C, Cphys, ldx, ldy, lddy, lddx, G, Cg, mode, act, LPP;
   float eps, alpha;
+  // FUSE (split attention, ResNest.py:171-199, folded into the norm that feeds / follows it; grid = (blocks per image, images)):
+  //   forward:  gap_ws[(b*gridDim.x + block)*Cphys + c] = this block's sum over its pixels of the (bf16-rounded) activated output
+  //             - the partial rows of the global average pool (ResNest.py:179), summed by the split-attention MLP kernel;
+  //   backward: the incoming gradient is dout*sa_s[b][c] + sa_dg[b][c] (the re-weighting's backward, ResNest.py:194-197 with
+  //             identical radix branches), formed in registers instead of by a separate pass over the tensor.
+  int64_t HW;
+  float* gap_ws;
+  const float *sa_s, *sa_dg;
+  int32_t sa_cy;
+  float sa_mult;
 };
 
 // MODE 0: per-pixel LayerNormalization over NG groups of channels; MODE 1: per-channel affine with given statistics.
 // NG = 1 is the plain LayerNormalization (no group bookkeeping at all); NG = 4 handles up to four groups with 0/1
 // membership masks folded into FMAs (the cardinal paths' LN: 3 groups of 3..85 channels, not aligned to the 8-channel
 // chunks - per-element compare/select chains made that form VALU bound at ~1 TB/s).
-template <bool BWD, int MODE, int NG>
+template <bool BWD, int MODE, int NG, bool FUSE = false>
 __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int LPP = p.LPP, ppw = 64 / LPP;
@@ -104,16 +114,27 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
       }
     }
   }
-  __shared__ float s_red[BWD ? 4 * 512 : 1];
+  __shared__ float s_red[(BWD || FUSE) ? 4 * 512 : 1];
   float dga[8], dbe[8], dbi[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { dga[j] = 0.f; dbe[j] = 0.f; dbi[j] = 0.f; }
   const float inv_cg = 1.f / (float)p.Cg;
+  float sa_sv[8], sa_dgv[8];        // FUSE backward: this image's re-weighting (times mult) and pooled-path gradient per channel
+  if (FUSE && BWD) {
+    const int cl = chunk_ok ? c0 : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cl + j < p.sa_cy ? cl + j : p.sa_cy - 1;       // clamped, unconditional loads
+      sa_sv[j] = okf[j] * p.sa_mult * p.sa_s[(int64_t)blockIdx.y * p.sa_cy + c];
+      sa_dgv[j] = okf[j] * p.sa_dg[(int64_t)blockIdx.y * p.sa_cy + c];
+    }
+  }
 
   const int64_t ppb = 4 * ppw;
-  for (int64_t base = (int64_t)blockIdx.x * ppb; base < p.M; base += (int64_t)gridDim.x * ppb) {
+  const int64_t m_lo = FUSE ? (int64_t)blockIdx.y * p.HW : 0, m_hi = FUSE ? m_lo + p.HW : p.M;
+  for (int64_t base = m_lo + (int64_t)blockIdx.x * ppb; base < m_hi; base += (int64_t)gridDim.x * ppb) {
     const int64_t m = base + wv * ppw + slot;
-    const bool valid = chunk_ok && m < p.M;
+    const bool valid = chunk_ok && m < m_hi;
     float xv[8], dyv[8];
     uint4 rawx = make_uint4(0, 0, 0, 0), rawd = make_uint4(0, 0, 0, 0);
     if (valid) {
@@ -122,6 +143,10 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
     }
     unpack8(rawx, xv);
     if (BWD) unpack8(rawd, dyv);
+    if (FUSE && BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dyv[j] = valid ? fmaf(dyv[j], sa_sv[j], sa_dgv[j]) : 0.f;
+    }
     float xh[8];        // normalised value
     float rstd_j[8];    // 1/sigma of each element's group (MODE 0)
     if (MODE == 0) {
@@ -210,7 +235,14 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] *= mk[j];
       }
-      if (valid) *reinterpret_cast<uint4*>(p.y + m * p.ldy + c0) = pack8(o);
+      const uint4 packed = pack8(o);
+      if (valid) *reinterpret_cast<uint4*>(p.y + m * p.ldy + c0) = packed;
+      if (FUSE && valid) {          // global-average-pool partial of the STORED (bf16) values, as a pass over y would read them
+        float r8[8];
+        unpack8(packed, r8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dga[j] += r8[j];
+      }
     } else {
       if (p.mask && valid) {
         float mk[8];
@@ -268,21 +300,24 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
       if (valid) *reinterpret_cast<uint4*>(p.dx + m * p.lddx + c0) = pack8(o);
     }
   }
+  if (FUSE && !BWD) {
+    block_chunk_partial(dga, LPP, chunk, chunk_ok, p.gap_ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * p.Cphys, p.Cphys, s_red);
+  }
   if (BWD) {
-    float* row = p.ws + (int64_t)blockIdx.x * 3 * p.Cphys;
+    float* row = p.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 * p.Cphys;
     block_chunk_partial(dga, LPP, chunk, chunk_ok, row, p.Cphys, s_red);
     block_chunk_partial(dbe, LPP, chunk, chunk_ok, row + p.Cphys, p.Cphys, s_red);
     block_chunk_partial(dbi, LPP, chunk, chunk_ok, row + 2 * p.Cphys, p.Cphys, s_red);
   }
 }
 
-template <bool BWD>
-static void norm_launch(const NormParams& p, unsigned grid, hipStream_t s) {
-  if (p.mode == 2) hipLaunchKernelGGL((norm_act_kernel<true, 2, 1>), dim3(grid), dim3(256), 0, s, p);
-  else if (p.mode == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 1, 1>), dim3(grid), dim3(256), 0, s, p);
-  else if (p.G == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 1>), dim3(grid), dim3(256), 0, s, p);
-  else if (p.G <= 3) hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 3>), dim3(grid), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 4>), dim3(grid), dim3(256), 0, s, p);
+template <bool BWD, bool FUSE = false>
+static void norm_launch(const NormParams& p, dim3 grid, hipStream_t s) {
+  if (p.mode == 2) hipLaunchKernelGGL((norm_act_kernel<true, 2, 1>), grid, dim3(256), 0, s, p);
+  else if (p.mode == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 1, 1, FUSE>), grid, dim3(256), 0, s, p);
+  else if (p.G == 1) hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 1, FUSE>), grid, dim3(256), 0, s, p);
+  else if (p.G <= 3) hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 3, FUSE>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((norm_act_kernel<BWD, 0, 4, FUSE>), grid, dim3(256), 0, s, p);
 }
 
 static int norm_common(const UssegNormDesc* d, NormParams& p) {
@@ -313,7 +348,7 @@ extern "C" int usseg_norm_act_fwd(const UssegNormDesc* d, const void* x, const f
   p.ldx = d->ldx; p.ldy = d->ldy;
   if (p.M <= 0) return USSEG_OK;
   int ppb = 4 * (64 / p.LPP);
-  norm_launch<false>(p, grid_for(p.M, ppb * 4), (hipStream_t)stream);
+  norm_launch<false>(p, dim3(grid_for(p.M, ppb * 4)), (hipStream_t)stream);
   return usseg_check_launch("norm_act_fwd");
 }
 
@@ -337,9 +372,47 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   // small tensors are latency bound (each loop trip is a dependent load -> store): spread them over many workgroups
   unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
   p.ws = ws = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * 3 * p.Cphys);
-  norm_launch<true>(p, grid, (hipStream_t)stream);
+  norm_launch<true>(p, dim3(grid), (hipStream_t)stream);
   usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
   return usseg_check_launch("norm_act_bwd");
+}
+
+// ---- split-attention fusions (see NormParams) ---------------------------------------------------------------------------------
+extern "C" int usseg_norm_act_fwd_gap(const UssegNormDesc* d, const void* x, const float* gamma, const float* beta, const float* mean,
+                                      const float* var, void* y, int32_t B, int32_t nb, float* gap_rows, usseg_stream_t stream) {
+  NormParams p = {};
+  int rc = norm_common(d, p);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(x && y && gamma && beta && gap_rows && (d->mode == 0 || (mean && var)), "norm fwd gap: null pointer");
+  USSEG_CHECK_ARG(d->mode != 2 && B > 0 && nb > 0 && nb <= 1024 && d->M % B == 0, "norm fwd gap: bad arguments");
+  USSEG_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0, "norm: unaligned channel vectors");
+  p.x = (const bf16_t*)x; p.y = (bf16_t*)y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
+  p.ldx = d->ldx; p.ldy = d->ldy; p.HW = d->M / B; p.gap_ws = gap_rows;
+  norm_launch<false, true>(p, dim3(nb, B), (hipStream_t)stream);
+  return usseg_check_launch("norm_act_fwd_gap");
+}
+
+extern "C" int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, const void* dout, const float* gamma, const float* beta,
+                                     const float* mean, const float* var, int32_t B, const float* sa_s, const float* sa_dg, float sa_mult,
+                                     void* dx, float* dgamma, float* dbeta, float* dbias, float* ws, usseg_stream_t stream) {
+  NormParams p = {};
+  int rc = norm_common(d, p);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(x && dout && dx && gamma && beta && dgamma && dbeta && ws && sa_s && sa_dg && (d->mode == 0 || (mean && var)), "norm bwd sa: null pointer");
+  USSEG_CHECK_ARG(d->mode != 2 && B > 0 && d->M % B == 0, "norm bwd sa: bad arguments");
+  USSEG_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0, "norm: unaligned channel vectors");
+  p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dout; p.dx = (bf16_t*)dx; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
+  p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
+  p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->lddx > 0 ? d->lddx : d->ldx;
+  p.HW = d->M / B; p.sa_s = sa_s; p.sa_dg = sa_dg; p.sa_cy = d->C; p.sa_mult = sa_mult;
+  USSEG_CHECK_ARG(p.lddx % 8 == 0 && p.lddx >= d->Cphys, "norm bwd: bad dx stride");
+  const int ppb = 4 * (64 / p.LPP);
+  int nb = (int)grid_for(p.HW, ppb * 2, USSEG_REDUCE_MAX_BLOCKS / B > 0 ? USSEG_REDUCE_MAX_BLOCKS / B : 1);
+  const int64_t grid = (int64_t)nb * B;
+  p.ws = ws = usseg_defer_reduce_ws((hipStream_t)stream, ws, grid * 3 * p.Cphys);
+  norm_launch<true, true>(p, dim3(nb, B), (hipStream_t)stream);
+  usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
+  return usseg_check_launch("norm_act_bwd_sa");
 }
 
 // ------------------------------------------------------------------------------------------ column sums

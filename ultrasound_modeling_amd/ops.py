@@ -436,6 +436,30 @@ def norm_act_fwd(x, C_logical, gamma, beta, out, mode, G=1, eps=1e-3, act=ACT_NO
     return out
 
 
+def norm_act_fwd_gap(x, C_logical, gamma, beta, out, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None, var=None):
+    """norm + activation that also emits the partial rows of the global average pool of its output (split attention,
+    ResNest.py:179): -> (out, (rows [B,nb,Cphys] fp32, nb, Cphys)) for ``splitattn_fwd(..., gap=...)``."""
+    B, H, W, Cphys, _ = geom(x)
+    d = _norm_desc(x, C_logical, geom(out)[4], G, mode, eps, act, alpha)
+    nb = max(1, min(32, (H * W) // 32))
+    rows = torch.empty((B, nb, Cphys), dtype=torch.float32, device=x.device)
+    L.check(L.load().usseg_norm_act_fwd_gap(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean), _ptr(var), out.data_ptr(),
+                                            B, nb, rows.data_ptr(), _stream()), "norm_act_fwd_gap")
+    return out, (rows, nb, Cphys)
+
+
+def norm_act_bwd_sa(x, dout, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G, eps, act, alpha, sa_s, sa_dg, sa_mult, mean=None, var=None,
+                    dbias=None):
+    """Norm backward whose incoming gradient is the split attention re-weighting's backward mult*s[b][c]*dout + dg[b][c]
+    (formed in registers: no usseg_splitattn_apply_bwd_dy pass, no dy tensor)."""
+    B, H, W, Cphys, ldx = geom(x)
+    d = NormDesc(B * H * W, C_logical, Cphys, ldx, geom(dout)[4], G, mode, eps, act, alpha, geom(dx)[4])
+    L.check(L.load().usseg_norm_act_bwd_sa(C.byref(d), x.data_ptr(), dout.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean), _ptr(var), B,
+                                           sa_s.data_ptr(), sa_dg.data_ptr(), sa_mult, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                           _ptr(dbias), reduce_ws(x.device).data_ptr(), _stream()), "norm_act_bwd_sa")
+    return dx
+
+
 def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None,
                  var=None, dbias=None, mask=None):
     B, H, W, Cphys, ldx = geom(x)
@@ -588,36 +612,48 @@ def _sa_params(w1, b1, gamma, beta, mean, var, w2, b2) -> SplitAttnParams:
     return SplitAttnParams(_ptr(w1), _ptr(b1), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), _ptr(w2), _ptr(b2))
 
 
-def splitattn_fwd(d: SplitAttnDesc, y, params, out):
-    """params = (w1,b1,gamma,beta,mean,var,w2,b2) fp32 tensors laid out per path.  Returns (out, g, s, ws)."""
+def splitattn_fwd(d: SplitAttnDesc, y, params, out, gap=None):
+    """params = (w1,b1,gamma,beta,mean,var,w2,b2) fp32 tensors laid out per path.  ``gap``: the pooled partial rows
+    (tensor [B,nb,Cphys], nb, Cphys) that ``norm_act_fwd_gap`` produced together with y - without it the pooling pass over y
+    runs here.  Returns (out, g, s, ws); g = (tensor, rows, stride) is what ``splitattn_bwd`` takes back."""
     dev = y.device
     Cy = d.P * d.R * d.Cg
-    g = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)      # overwritten by usseg_splitattn_gap
     s = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
     ws = torch.empty(d.B * d.P * (d.Cg + 2 * d.Hd), dtype=torch.float32, device=dev)
     lib = L.load()
-    L.check(lib.usseg_splitattn_gap(C.byref(d), y.data_ptr(), g.data_ptr(), reduce_ws(dev).data_ptr(), _stream()), "splitattn_gap")
+    if gap is None:
+        g = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)      # overwritten by usseg_splitattn_gap
+        L.check(lib.usseg_splitattn_gap(C.byref(d), y.data_ptr(), g.data_ptr(), reduce_ws(dev).data_ptr(), _stream()), "splitattn_gap")
+        gap = (g, 1, Cy)
     sp = _sa_params(*params)
-    L.check(lib.usseg_splitattn_mlp_fwd(C.byref(d), g.data_ptr(), C.byref(sp), s.data_ptr(), ws.data_ptr(), _stream()), "splitattn_mlp_fwd")
+    L.check(lib.usseg_splitattn_mlp_fwd(C.byref(d), gap[0].data_ptr(), gap[1], gap[2], C.byref(sp), s.data_ptr(), ws.data_ptr(), _stream()),
+            "splitattn_mlp_fwd")
     L.check(lib.usseg_splitattn_apply_fwd(C.byref(d), y.data_ptr(), s.data_ptr(), out.data_ptr(), _stream()), "splitattn_apply_fwd")
-    return out, g, s, ws
+    return out, gap, s, ws
 
 
 def splitattn_bwd(d: SplitAttnDesc, y, dout, params, grads, g, s, ws, dy):
-    """grads = (dw1,db1,dgamma,dbeta,dw2,db2) accumulate (per-image partial rows + an ordered finishing reduction).  Writes dy."""
+    """grads = (dw1,db1,dgamma,dbeta,dw2,db2) accumulate (per-image partial rows + an ordered finishing reduction).
+    ``dy`` tensor: written (dy = mult*s*dout + dg).  ``dy=None``: the re-weighting's backward is left to the caller's
+    ``norm_act_bwd_sa`` (R == 1 only) and (s, dg) are returned for it."""
     dev = y.device
     Cy = d.P * d.R * d.Cg
     ds = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)     # overwritten by usseg_splitattn_apply_bwd_reduce
     dg = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
     lib = L.load()
     lddo = geom(dout)[4]
+    if not isinstance(g, tuple):
+        g = (g, 1, Cy)
     L.check(lib.usseg_splitattn_apply_bwd_reduce(C.byref(d), y.data_ptr(), dout.data_ptr(), lddo, ds.data_ptr(),
                                                  reduce_ws(dev).data_ptr(), _stream()), "splitattn_apply_bwd_reduce")
     sp = _sa_params(*params)
     sg = SplitAttnGrads(*[_ptr(t) for t in grads])
     gws = torch.empty(int(lib.usseg_splitattn_mlp_bwd_ws_floats(C.byref(d))), dtype=torch.float32, device=dev)
-    L.check(lib.usseg_splitattn_mlp_bwd(C.byref(d), g.data_ptr(), C.byref(sp), s.data_ptr(), ws.data_ptr(), ds.data_ptr(), dg.data_ptr(),
-                                        C.byref(sg), gws.data_ptr(), _stream()), "splitattn_mlp_bwd")
+    L.check(lib.usseg_splitattn_mlp_bwd(C.byref(d), g[0].data_ptr(), g[1], g[2], C.byref(sp), s.data_ptr(), ws.data_ptr(), ds.data_ptr(),
+                                        dg.data_ptr(), C.byref(sg), gws.data_ptr(), _stream()), "splitattn_mlp_bwd")
+    if dy is None:
+        assert d.R == 1, "the fused re-weighting backward needs identical radix branches (R == 1)"
+        return s, dg
     L.check(lib.usseg_splitattn_apply_bwd_dy(C.byref(d), dout.data_ptr(), lddo, s.data_ptr(), dg.data_ptr(), dy.data_ptr(), geom(dy)[4],
                                              _stream()), "splitattn_apply_bwd_dy")
     return dy
