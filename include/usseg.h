@@ -251,6 +251,18 @@ int usseg_norm_act_fwd_gap(const UssegNormDesc* d, const void* x, const float* g
 int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, const void* dout, const float* gamma, const float* beta,
                           const float* mean, const float* var, int32_t B, const float* sa_s, const float* sa_dg, float sa_mult,
                           void* dx, float* dgamma, float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
+/* Inference BatchNormalization + activation + AveragePooling2D(2,2) in one pass - the stem's convtmp_2bn -> LeakyReLU ->
+ * conv1_pool (ResNest.py:45-47) and conv2_1_2bn -> ELU -> pool_1 (TBI_ResNest.py:90-92): the activated full-resolution tensor
+ * feeds the pool only, so it is never written.  x [B,H,W,Cphys] pre-norm; y / dy [B,H/2,W/2,Cphys]; dx [B,H,W,Cphys] is the
+ * gradient w.r.t. x; dgamma / dbeta / dbias (= sum of dx: the producing conv's bias gradient, may be NULL) accumulate.
+ * Bit-identical to usseg_norm_act_fwd + usseg_avgpool2_fwd (resp. avgpool2_bwd + norm_act_bwd). */
+int usseg_bn_act_pool_fwd(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cphys, int32_t ldx, const float* gamma,
+                          const float* beta, const float* mean, const float* var, float eps, int32_t act, float alpha, void* y,
+                          int32_t ldy, usseg_stream_t stream);
+int usseg_bn_act_pool_bwd(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cphys, int32_t ldx,
+                          int32_t lddy, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                          int32_t act, float alpha, void* dx, int32_t lddx, float* dgamma, float* dbeta, float* dbias, float* ws,
+                          usseg_stream_t stream);
 /* Every per-channel reduction (norm backward, colsum, channel_stats, split-attention reductions) writes one partial
  * row per workgroup into the caller's fp32 workspace `ws` (at least usseg_reduce_ws_floats() floats) and a finishing
  * kernel ADDS the column sums to the destination: no atomics, bitwise reproducible.
@@ -275,6 +287,10 @@ int usseg_act_fwd(const void* x, int64_t M, int32_t C, int32_t ldx, int32_t ldy,
                   usseg_stream_t stream);
 int usseg_act_bwd(const void* x, const void* dy, int64_t M, int32_t C, int32_t ldx, int32_t lddy, int32_t lddx,
                   int32_t act, float alpha, void* dx, usseg_stream_t stream);
+/* act_bwd that also accumulates db[c] += sum_m dx[m][c] (C logical channels): the bias gradient of the conv whose fused
+ * activation it undoes (ResNest.py:39-40), in the same pass.  ws: usseg_reduce_ws_floats() floats. */
+int usseg_act_bwd_colsum(const void* x, const void* dy, int64_t M, int32_t C, int32_t ldx, int32_t lddy, int32_t lddx, int32_t act,
+                         float alpha, void* dx, float* db, float* ws, usseg_stream_t stream);
 
 /* ---- AveragePooling2D(2,2) (ResNest.py:25-28,47-53; TBI_ResNest.py:92-107) -------------------- */
 int usseg_avgpool2_fwd(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy, void* y,

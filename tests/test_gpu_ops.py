@@ -488,6 +488,60 @@ def test_split_attention_folded_into_its_norms(gen, B, H, W, P, Cg, radix):
         assert rel(got, want) < 2e-3, (got.shape,)
 
 
+@pytest.mark.parametrize("B,H,W,C,act", [(2, 16, 16, 32, "lrelu"), (3, 8, 12, 24, "elu"), (1, 64, 32, 32, "lrelu")])
+def test_bn_act_pool_one_pass(gen, B, H, W, C, act):
+    """Inference BatchNorm + activation + AveragePooling2D(2,2) in one launch (the stems, ResNest.py:45-47 / TBI_ResNest.py:90-92):
+    bit-identical to the two-launch form, and within tolerance of the oracle, forward and backward."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import AveragePooling2D, BatchNormalization
+    A, alpha, fa = (ops.ACT_LRELU, 0.3, O.leaky_relu) if act == "lrelu" else (ops.ACT_ELU, 1.0, O.elu)
+    bn = BatchNormalization(C)
+    finalize(bn)
+    f = lambda *s, sc=1.0: (torch.randn(*s, generator=gen, dtype=torch.float64) * sc).float().double()
+    gam, bet, mean, var = 1 + f(C, sc=0.2), f(C, sc=0.1), f(C, sc=0.3), 0.5 + torch.rand(C, generator=gen, dtype=torch.float64).float().double()
+    bn.gamma.data.copy_(gam); bn.beta.data.copy_(bet); bn.moving_mean_p[:C] = mean.float().to(DEV); bn.moving_variance_p[:C] = var.float().to(DEV)
+    x = rnd(gen, B, H, W, C) * 1.3
+    x = bf(x)
+    dy = rnd(gen, B, H // 2, W // 2, C)
+    xl, gl, bl = (t.clone().requires_grad_(True) for t in (x, gam, bet))
+    ref = O.avg_pool2(fa(O.batch_norm(xl, gl, bl, mean, var)))
+    gx, gg, gb = torch.autograd.grad(ref, [xl, gl, bl], dy)
+    xd, dyd = to_dev_padded(x), to_dev_padded(dy)
+    pooled = bn.forward_pool(xd, A, alpha)
+    two = AveragePooling2D()
+    want = two.forward(bn.forward(xd, A, alpha))
+    assert torch.equal(pooled, want)
+    # the four activated values are rounded to bf16 before they are averaged (what the two-launch form stored), then the mean is
+    # rounded: ~2.5e-3 against the single-rounding fp64 result - the bit-identity above is the kernel check
+    assert rel(pooled[..., :C], bf(ref)) < 4e-3
+    bn.gamma.grad.zero_(); bn.beta.grad.zero_()
+    db = torch.zeros((C + 7) // 8 * 8, device=DEV)
+    dx = bn.backward_pool(dyd, dbias=db)
+    torch.cuda.synchronize()
+    g1, b1 = bn.gamma.grad.clone(), bn.beta.grad.clone()
+    bn.gamma.grad.zero_(); bn.beta.grad.zero_()
+    db2 = torch.zeros_like(db)
+    bn.forward(xd, A, alpha)
+    dx2 = bn.backward(two.backward(dyd), dbias=db2)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2)
+    assert rel(g1, bn.gamma.grad) < 1e-5 and rel(b1, bn.beta.grad) < 1e-5 and rel(db, db2) < 1e-5
+    assert rel(dx[..., :C], bf(gx)) < REL_BF16 and rel(g1, gg) < 2e-3 and rel(b1, gb) < 2e-3 and rel(db[:C], gx.sum(dim=(0, 1, 2))) < 2e-3
+
+
+def test_act_bwd_with_column_sums(gen):
+    from ultrasound_modeling_amd import ops
+    B, H, W, C = 2, 9, 7, 16
+    x, dy = rnd(gen, B, H, W, C), rnd(gen, B, H, W, C)
+    xd, dyd = to_dev_padded(x), to_dev_padded(dy)
+    db = torch.zeros(C, device=DEV)
+    dx = ops.act_bwd_colsum(xd, dyd, torch.empty_like(dyd), ops.ACT_LRELU, 0.3, db, C)
+    dx2 = ops.act_bwd(xd, dyd, torch.empty_like(dyd), ops.ACT_LRELU, 0.3)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2)
+    assert rel(db, dx2.float().sum(dim=(0, 1, 2))) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ loss / optimiser
 def test_softmax_cce_loss_fwd_bwd(gen):
     from ultrasound_modeling_amd import ops

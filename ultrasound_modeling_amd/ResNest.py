@@ -305,6 +305,7 @@ class ResNest(nn.Module):
         self._y1 = self.conv1.forward(x, act=ACT_LRELU, alpha=a)                                  # :39-40
         bn1, bn2 = self.convtmp_1bn, self.convtmp_2bn
         self._fold = _FOLD_BN and not (bn1.training_mode or bn2.training_mode)
+        self._pool_fused = False
         if self._fold:   # inference-mode BN + LeakyReLU ride in the conv epilogue: the pre-norm tensors are never written
             self._t1 = t = self.convtmp_1.forward(self._y1, act=ACT_LRELU, alpha=a, scale=bn1.fold_scale, shift=bn1.fold_shift)   # :41-43
             self._t2 = t = self.convtmp_2.forward(t, act=ACT_LRELU, alpha=a, scale=bn2.fold_scale, shift=bn2.fold_shift)          # :44-46
@@ -312,8 +313,13 @@ class ResNest(nn.Module):
             t = self.convtmp_1.forward(self._y1)                                                 # :41
             t = self.convtmp_1bn.forward(t, ACT_LRELU, a)                                        # :42-43
             t = self.convtmp_2.forward(t)                                                        # :44
-            t = self.convtmp_2bn.forward(t, ACT_LRELU, a)                                        # :45-46
-        t = self.conv1_pool.forward(t)                                                           # :47
+            self._pool_fused = not bn2.training_mode
+            if self._pool_fused:    # :45-47 in one pass: the activated 256x256 tensor feeds the pool only and is never written
+                t = self.convtmp_2bn.forward_pool(t, ACT_LRELU, a)
+            else:
+                t = self.convtmp_2bn.forward(t, ACT_LRELU, a)                                    # :45-46
+        if self._fold or not self._pool_fused:
+            t = self.conv1_pool.forward(t)                                                       # :47
         x_1 = self.conv_1.forward(t, out=o1)                                                     # :48
         x_2 = self.conv_2.forward(self.conv2_pool.forward(x_1), out=o2)                          # :49-50
         x_3 = self.conv_3.forward(self.conv3_pool.forward(x_2), out=o3)                          # :51-52
@@ -330,20 +336,22 @@ class ResNest(nn.Module):
         d = self.conv_2.backward(d)
         d = self.conv2_pool.backward(d, add=d_x1)
         d = self.conv_1.backward(d)
-        d = self.conv1_pool.backward(d)
         a = KERAS_LRELU_ALPHA
-        if self._fold:
-            d = self.convtmp_2bn.backward_folded(self._t2, d, ACT_LRELU, a, dbias=self.convtmp_2.bias.grad)
+        if self._pool_fused:
+            d = self.convtmp_2bn.backward_pool(d, dbias=self.convtmp_2.bias.grad)
+        elif self._fold:
+            d = self.convtmp_2bn.backward_folded(self._t2, self.conv1_pool.backward(d), ACT_LRELU, a, dbias=self.convtmp_2.bias.grad)
         else:
-            d = self.convtmp_2bn.backward(d, dbias=self.convtmp_2.bias.grad)
+            d = self.convtmp_2bn.backward(self.conv1_pool.backward(d), dbias=self.convtmp_2.bias.grad)
         d = self.convtmp_2.backward(d, skip_bias=True)
         if self._fold:
             d = self.convtmp_1bn.backward_folded(self._t1, d, ACT_LRELU, a, dbias=self.convtmp_1.bias.grad)
         else:
             d = self.convtmp_1bn.backward(d, dbias=self.convtmp_1.bias.grad)
         d = self.convtmp_1.backward(d, skip_bias=True)
-        d = ops.act_bwd(self._y1, d, torch.empty_like(d), ACT_LRELU, KERAS_LRELU_ALPHA)   # LeakyReLU': sign(y) == sign(pre)
-        self.conv1.backward(d, need_dx=False)
+        # LeakyReLU': sign(y) == sign(pre); the same pass sums its output over the pixels = conv1's bias gradient
+        d = ops.act_bwd_colsum(self._y1, d, torch.empty_like(d), ACT_LRELU, KERAS_LRELU_ALPHA, self.conv1.bias.grad, self.conv1.cout)
+        self.conv1.backward(d, need_dx=False, skip_bias=True)
         return None
 
     def bn_fold_jobs(self):

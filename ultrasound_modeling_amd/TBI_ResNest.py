@@ -160,17 +160,17 @@ class _SlabA:
         dv = ops.norm_act_bwd(v_raw, dy, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, 1, 1, e, ACT_ELU, 1.0,
                               self.m2, self.v2, dbias=self.db2)
         s1, s2, tab1, tab2 = self._unpack_tables(dev)
+        # 12 (path, radix) blocks > the 4 of a mapped destination: the dense gradient goes through this slab's private scratch and
+        # its diagonal blocks are scattered (one launch) once the deferred split-K finishes have run at the end of the backward pass
         ops.fill_f32(s2, 0.0)
         ops.conv2d_wgrad(u, dv, self.k, 1, s2)
-        ops.defer_flush()                       # 12 (path, radix) blocks > the 4 of a mapped destination: scratch is read right away
-        ops.unpack_wgrad_batched(tab2)          # all diagonal blocks of the slab in one launch
+        ops.after_flush(lambda: ops.unpack_wgrad_batched(tab2))
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, 1, torch.empty_like(u))
         du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, 1, 1, e, ACT_ELU, 1.0,
                                   self.m1, self.v1, dbias=self.db1)
         ops.fill_f32(s1, 0.0)
         ops.conv2d_wgrad(x, du_raw, 1, 1, s1)
-        ops.defer_flush()
-        ops.unpack_wgrad_batched(tab1)
+        ops.after_flush(lambda: ops.unpack_wgrad_batched(tab1))
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
 
 
@@ -334,9 +334,14 @@ class _ResModel(nn.Module):
         t = ops.act_fwd(self._r1, torch.empty_like(self._r1), ACT_ELU, a)              # :84
         self._r2 = g("conv2_1_1").forward(t)                                           # :85
         t = ops.act_fwd(self._r2, torch.empty_like(self._r2), ACT_ELU, a)              # :87
-        t = g("conv2_1_2bn").forward(g("conv2_1_2").forward(t), ACT_ELU, a)            # :88-91
         self._pools = [AveragePooling2D() for _ in range(6)]
-        pooled = [self._pools[0].forward(t)]                                           # pool_1 (:92)
+        bn = g("conv2_1_2bn")
+        self._pool_fused = not bn.training_mode
+        if self._pool_fused:   # :88-92 BN + ELU + pool_1 in one pass: the activated 256x256 tensor feeds the pool only
+            pooled = [bn.forward_pool(g("conv2_1_2").forward(t), ACT_ELU, a)]
+        else:
+            t = bn.forward(g("conv2_1_2").forward(t), ACT_ELU, a)                      # :88-91
+            pooled = [self._pools[0].forward(t)]                                       # pool_1 (:92)
         for i, st in enumerate(self._build()):                                         # :93-107
             pooled.append(self._pools[i + 1].forward(st.forward(pooled[-1])))
         # pooled = [pool1(32ch), pool2(64), pool3(128), pool4(256), pool5(512), pool6(512)]
@@ -386,14 +391,17 @@ class _ResModel(nn.Module):
         for i in reversed(range(5)):
             d = stages[i].backward(self._pools[i + 1].backward(d))   # through pool_{i+2} and stage i -> w.r.t. pool_{i+1}
             d = self._add(d, dpool[i])                               # + the skip branch of the decoder concat
-        d = self._pools[0].backward(d)
         a = KERAS_ELU_ALPHA
-        d = g("conv2_1_2bn").backward(d, dbias=g("conv2_1_2").bias.grad)
+        if self._pool_fused:
+            d = g("conv2_1_2bn").backward_pool(d, dbias=g("conv2_1_2").bias.grad)
+        else:
+            d = g("conv2_1_2bn").backward(self._pools[0].backward(d), dbias=g("conv2_1_2").bias.grad)
         d = g("conv2_1_2").backward(d, skip_bias=True)
-        d = ops.act_bwd(self._r2, d, torch.empty_like(d), ACT_ELU, a)
-        d = g("conv2_1_1").backward(d)
-        d = ops.act_bwd(self._r1, d, torch.empty_like(d), ACT_ELU, a)
-        g("Conv1").backward(d, need_dx=False)
+        # ELU' on the stored pre-activations; the same pass sums its output over the pixels = the conv's bias gradient
+        d = ops.act_bwd_colsum(self._r2, d, torch.empty_like(d), ACT_ELU, a, g("conv2_1_1").bias.grad, g("conv2_1_1").cout)
+        d = g("conv2_1_1").backward(d, skip_bias=True)
+        d = ops.act_bwd_colsum(self._r1, d, torch.empty_like(d), ACT_ELU, a, g("Conv1").bias.grad, g("Conv1").cout)
+        g("Conv1").backward(d, need_dx=False, skip_bias=True)
 
     @staticmethod
     def _add(a, b):

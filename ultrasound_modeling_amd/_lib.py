@@ -115,12 +115,16 @@ _PROTOS = {
     "usseg_dropout_mask": (C.c_int, [c_vp, c_i64, c_i32, c_i32, C.c_uint64, c_f32, c_vp]),
     "usseg_dropout_mask_step": (C.c_int, [c_vp, c_i64, c_i32, c_i32, C.c_uint64, c_vp, c_f32, c_vp]),
     "usseg_norm_act_bwd": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_bn_act_pool_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_f32, c_vp, c_i32, c_vp]),
+    "usseg_bn_act_pool_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_f32,
+                                        c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_reduce_ws_floats": (c_i64, []),
     "usseg_channel_stats": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "usseg_bn_finalize_stats": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_bn_train_bwd_fix": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "usseg_act_fwd": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
     "usseg_act_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
+    "usseg_act_bwd_colsum": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "usseg_avgpool2_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "usseg_avgpool2_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "usseg_copy_channels": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),

@@ -415,6 +415,145 @@ extern "C" int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, cons
   return usseg_check_launch("norm_act_bwd_sa");
 }
 
+// ---- inference BatchNorm + activation + 2x2 average pool in one pass (the stem's convtmp_2bn -> LeakyReLU -> conv1_pool,
+// ResNest.py:45-47; TBI_ResNest.py:90-92): the activated full-resolution tensor is consumed by the pool only, so it is never
+// written (forward) and the pool's backward never materialises the upsampled gradient (backward).  Values are rounded to bf16
+// where the two-kernel form stored them, so the results are bit-identical to norm_act_kernel + avgpool2_*_kernel.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const NormParams p, int Ho, int Wo) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int LPP = p.LPP, ppw = 64 / LPP;
+  const int chunk = lane & (LPP - 1), slot = lane / LPP;
+  const int CH = p.Cphys >> 3;
+  const bool chunk_ok = chunk < CH;
+  const int c0 = chunk * 8;
+  float ga[8], be[8], mu_c[8], rs_c[8], okf[8];
+  {
+    const int cl = chunk_ok ? c0 : 0;
+    float gv[8], bv[8], mv[8], vv[8];
+    *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(p.gamma + cl);
+    *reinterpret_cast<float4*>(gv + 4) = *reinterpret_cast<const float4*>(p.gamma + cl + 4);
+    *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(p.beta + cl);
+    *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(p.beta + cl + 4);
+    *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(p.mean + cl);
+    *reinterpret_cast<float4*>(mv + 4) = *reinterpret_cast<const float4*>(p.mean + cl + 4);
+    *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(p.var + cl);
+    *reinterpret_cast<float4*>(vv + 4) = *reinterpret_cast<const float4*>(p.var + cl + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = chunk_ok && c0 + j < p.C;
+      okf[j] = ok ? 1.f : 0.f;
+      ga[j] = ok ? gv[j] : 0.f;
+      be[j] = ok ? bv[j] : 0.f;
+      mu_c[j] = ok ? mv[j] : 0.f;
+      rs_c[j] = ok ? rsqrtf(vv[j] + p.eps) : 0.f;
+    }
+  }
+  __shared__ float s_red[BWD ? 4 * 512 : 1];
+  float dga[8], dbe[8], dbi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { dga[j] = 0.f; dbe[j] = 0.f; dbi[j] = 0.f; }
+  const int Wi = 2 * Wo;
+  const int64_t ppb = 4 * ppw;
+  for (int64_t base = (int64_t)blockIdx.x * ppb; base < p.M; base += (int64_t)gridDim.x * ppb) {
+    const int64_t m = base + wv * ppw + slot;          // pooled pixel
+    const bool valid = chunk_ok && m < p.M;
+    const int64_t mc = valid ? m : 0;
+    const int ox = (int)(mc % Wo);
+    const int64_t t = mc / Wo;
+    const int oy = (int)(t % Ho);
+    const int64_t b = t / Ho;
+    const int64_t pi = ((b * 2 * Ho + 2 * oy) * Wi + 2 * ox);
+    const int64_t sub[4] = {pi, pi + 1, pi + Wi, pi + Wi + 1};
+    uint4 raw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[q] = valid ? *reinterpret_cast<const uint4*>(p.x + sub[q] * p.ldx + c0) : make_uint4(0, 0, 0, 0);
+    if (!BWD) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float xv[8], o[8], r8[8];
+        unpack8(raw[q], xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = okf[j] * apply_act(ga[j] * ((xv[j] - mu_c[j]) * rs_c[j]) + be[j], p.act, p.alpha);
+        unpack8(pack8(o), r8);                         // the value the unfused form stored
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += r8[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] *= 0.25f;
+      if (valid) *reinterpret_cast<uint4*>(p.y + m * p.ldy + c0) = pack8(acc);
+    } else {
+      float dyv[8];
+      unpack8(valid ? *reinterpret_cast<const uint4*>(p.dy + m * p.lddy + c0) : make_uint4(0, 0, 0, 0), dyv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dyv[j] *= 0.25f;     // exact in bf16: the upsampled gradient the pool backward would have stored
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float xv[8], o[8];
+        unpack8(raw[q], xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (xv[j] - mu_c[j]) * rs_c[j];
+          const float dh = okf[j] * dyv[j] * act_grad(ga[j] * xh + be[j], p.act, p.alpha);
+          dga[j] = fmaf(dh, xh, dga[j]);
+          dbe[j] += dh;
+          o[j] = dh * ga[j] * rs_c[j];
+          dbi[j] += o[j];
+        }
+        if (valid) *reinterpret_cast<uint4*>(p.dx + sub[q] * p.lddx + c0) = pack8(o);
+      }
+    }
+  }
+  if (BWD) {
+    float* row = p.ws + (int64_t)blockIdx.x * 3 * p.Cphys;
+    block_chunk_partial(dga, LPP, chunk, chunk_ok, row, p.Cphys, s_red);
+    block_chunk_partial(dbe, LPP, chunk, chunk_ok, row + p.Cphys, p.Cphys, s_red);
+    block_chunk_partial(dbi, LPP, chunk, chunk_ok, row + 2 * p.Cphys, p.Cphys, s_red);
+  }
+}
+
+static int bn_pool_common(NormParams& p, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cphys, const float* gamma, const float* beta,
+                          const float* mean, const float* var, float eps, int32_t act, float alpha) {
+  USSEG_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && Cphys % 8 == 0 && Cphys >= C && Cphys <= 512, "bn_act_pool: bad geometry");
+  USSEG_CHECK_ARG(gamma && beta && mean && var && ((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0,
+                  "bn_act_pool: channel vectors must be 16-byte aligned");
+  p.M = (int64_t)B * (H / 2) * (W / 2); p.C = C; p.Cphys = Cphys; p.G = 1; p.Cg = C; p.mode = 1; p.act = act; p.eps = eps; p.alpha = alpha;
+  p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
+  p.LPP = lanes_per_pixel(Cphys / 8);
+  return USSEG_OK;
+}
+extern "C" int usseg_bn_act_pool_fwd(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cphys, int32_t ldx, const float* gamma,
+                                     const float* beta, const float* mean, const float* var, float eps, int32_t act, float alpha, void* y,
+                                     int32_t ldy, usseg_stream_t stream) {
+  NormParams p = {};
+  int rc = bn_pool_common(p, B, H, W, C, Cphys, gamma, beta, mean, var, eps, act, alpha);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(x && y && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= Cphys && ldy >= Cphys, "bn_act_pool_fwd: bad pointers / strides");
+  p.x = (const bf16_t*)x; p.y = (bf16_t*)y; p.ldx = ldx; p.ldy = ldy;
+  const int ppb = 4 * (64 / p.LPP);
+  hipLaunchKernelGGL(bn_act_pool_kernel<false>, dim3(grid_for(p.M, ppb * 2)), dim3(256), 0, (hipStream_t)stream, p, H / 2, W / 2);
+  return usseg_check_launch("bn_act_pool_fwd");
+}
+extern "C" int usseg_bn_act_pool_bwd(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cphys, int32_t ldx,
+                                     int32_t lddy, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                     int32_t act, float alpha, void* dx, int32_t lddx, float* dgamma, float* dbeta, float* dbias, float* ws,
+                                     usseg_stream_t stream) {
+  NormParams p = {};
+  int rc = bn_pool_common(p, B, H, W, C, Cphys, gamma, beta, mean, var, eps, act, alpha);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(x && dy && dx && dgamma && dbeta && ws && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldx >= Cphys && lddy >= Cphys && lddx >= Cphys,
+                  "bn_act_pool_bwd: bad pointers / strides");
+  p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.ldx = ldx; p.lddy = lddy; p.lddx = lddx;
+  p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
+  const int ppb = 4 * (64 / p.LPP);
+  unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
+  p.ws = ws = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * 3 * p.Cphys);
+  hipLaunchKernelGGL(bn_act_pool_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, H / 2, W / 2);
+  usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
+  return usseg_check_launch("bn_act_pool_bwd");
+}
+
 // ------------------------------------------------------------------------------------------ column sums
 // MODE 0: out[c] += sum_m a[m][c]; MODE 1: out[c] += sum a, out2[c] += sum a^2
 template <int MODE>
@@ -498,6 +637,49 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* x, const bf1
     *reinterpret_cast<uint4*>(dx + m * lddx + c0) = pack8(g);
   }
 }
+// activation backward that also yields the column sums of its output (the bias gradient of the conv whose fused activation this
+// undoes - ResNest.py:39-40 conv1 + LeakyReLU): one pass instead of act_bwd + colsum.  Sums the STORED (bf16) values, as colsum would.
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const bf16_t* x, const bf16_t* dy, int64_t M, int C, int ldx, int lddy, int lddx, int LPP,
+                                                              int act, float alpha, bf16_t* dx, float* ws) {
+  __shared__ float s_red[4 * 512];
+  const int Cp = (C + 7) & ~7;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ppw = 64 / LPP, chunk = lane & (LPP - 1), slot = lane / LPP;
+  const bool chunk_ok = chunk * 8 < C;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int64_t ppb = 4 * ppw;
+  for (int64_t base = (int64_t)blockIdx.x * ppb; base < M; base += (int64_t)gridDim.x * ppb) {
+    const int64_t m = base + wv * ppw + slot;
+    if (chunk_ok && m < M) {
+      float v[8], g[8], r8[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + chunk * 8), v);
+      unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + chunk * 8), g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] *= act_grad(v[j], act, alpha);
+      const uint4 o = pack8(g);
+      *reinterpret_cast<uint4*>(dx + m * lddx + chunk * 8) = o;
+      unpack8(o, r8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += r8[j];
+    }
+  }
+  block_chunk_partial(s, LPP, chunk, chunk_ok, ws + (int64_t)blockIdx.x * Cp, Cp, s_red);
+}
+extern "C" int usseg_act_bwd_colsum(const void* x, const void* dy, int64_t M, int32_t C, int32_t ldx, int32_t lddy, int32_t lddx, int32_t act,
+                                    float alpha, void* dx, float* db, float* ws, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(x && dy && dx && db && ws && C > 0 && C <= 512 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "act_bwd_colsum: bad args");
+  if (M <= 0) return USSEG_OK;
+  const int cwp = roundup(C, 8);
+  const int LPP = lanes_per_pixel(cwp / 8);
+  const int ppb = 4 * (64 / LPP);
+  unsigned grid = grid_for(M, ppb * 8, USSEG_REDUCE_MAX_BLOCKS);
+  float* wsr = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * cwp);
+  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, M, C, ldx, lddy, lddx,
+                     LPP, act, alpha, (bf16_t*)dx, wsr);
+  usseg_launch_reduce_finish(wsr, 1, (int)grid, 1, cwp, C, 1.f, db, nullptr, nullptr, (hipStream_t)stream);
+  return usseg_check_launch("act_bwd_colsum");
+}
+
 extern "C" int usseg_act_fwd(const void* x, int64_t M, int32_t C, int32_t ldx, int32_t ldy, int32_t act, float alpha, void* y,
                              usseg_stream_t stream) {
   USSEG_CHECK_ARG(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "act_fwd: bad args");

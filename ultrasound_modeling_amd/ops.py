@@ -472,6 +472,23 @@ def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, ep
     return dx
 
 
+def bn_act_pool_fwd(x, C_logical, gamma, beta, mean, var, eps, act, alpha, out=None):
+    """inference BatchNorm + activation + AveragePooling2D(2,2) in one pass: x [B,H,W,Cp] -> [B,H/2,W/2,Cp]."""
+    B, H, W, Cp, ldx = geom(x)
+    out = out if out is not None else new_act(B, H // 2, W // 2, Cp, x.device)
+    L.check(L.load().usseg_bn_act_pool_fwd(x.data_ptr(), B, H, W, C_logical, Cp, ldx, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                           eps, act, alpha, out.data_ptr(), geom(out)[4], _stream()), "bn_act_pool_fwd")
+    return out
+
+
+def bn_act_pool_bwd(x, dy, C_logical, gamma, beta, mean, var, eps, act, alpha, dx, dgamma, dbeta, dbias=None):
+    B, H, W, Cp, ldx = geom(x)
+    L.check(L.load().usseg_bn_act_pool_bwd(x.data_ptr(), dy.data_ptr(), B, H, W, C_logical, Cp, ldx, geom(dy)[4], gamma.data_ptr(), beta.data_ptr(),
+                                           mean.data_ptr(), var.data_ptr(), eps, act, alpha, dx.data_ptr(), geom(dx)[4], dgamma.data_ptr(),
+                                           dbeta.data_ptr(), _ptr(dbias), reduce_ws(x.device).data_ptr(), _stream()), "bn_act_pool_bwd")
+    return dx
+
+
 def dropout_mask(mask, seed: int, rate: float, step_dev=None):
     """``step_dev``: int32 device counter mixed into the seed (fresh masks when the launch is replayed from a HIP graph)."""
     B, H, W, Cc, ld = geom(mask)
@@ -509,6 +526,14 @@ def act_bwd(x, dy, dx, act, alpha):
     B, H, W, Cc, ldx = geom(x)
     L.check(L.load().usseg_act_bwd(x.data_ptr(), dy.data_ptr(), B * H * W, Cc, ldx, geom(dy)[4], geom(dx)[4], act, alpha,
                                    dx.data_ptr(), _stream()), "act_bwd")
+    return dx
+
+
+def act_bwd_colsum(x, dy, dx, act, alpha, db, C_logical):
+    """act_bwd + the column sums of its output into ``db`` (the producing conv's bias gradient) in one pass."""
+    B, H, W, Cc, ldx = geom(x)
+    L.check(L.load().usseg_act_bwd_colsum(x.data_ptr(), dy.data_ptr(), B * H * W, C_logical, ldx, geom(dy)[4], geom(dx)[4], act, alpha, dx.data_ptr(),
+                                          db.data_ptr(), reduce_ws(x.device).data_ptr(), _stream()), "act_bwd_colsum")
     return dx
 
 
