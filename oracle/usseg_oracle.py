@@ -193,7 +193,16 @@ def cardinal_channels(stage_out: int, radix: int, kpaths: int) -> Tuple[int, int
 # ----------------------------------------------------------------------------
 # Arch B: ResNest.py
 # ----------------------------------------------------------------------------
-def split_attention(inputs: Sequence[Tensor], P: Params, prefix: str, radix: int) -> Tensor:
+def _norm(x: Tensor, P: Params, name: str, norm: str) -> Tensor:
+    """The layer called ``*_bn`` / ``bn1``: LayerNormalization in ResNest.py / Decoder.py (ResNest.py:86,125,132,164; Decoder.py:112),
+    BatchNormalization (inference mode as driven, App. A.4) in the older copy TBI_TransUNet.py (:304,426,465,472,503)."""
+    if norm == "ln":
+        return layer_norm(x, P[name + ".gamma"], P[name + ".beta"])
+    assert norm == "bn"
+    return _bn(x, P, name)
+
+
+def split_attention(inputs: Sequence[Tensor], P: Params, prefix: str, radix: int, norm: str = "ln") -> Tensor:
     """split_attention.forward - ResNest.py:171-199.
 
     sum of the radix inputs, global average pool, dense1 (1x1)+LN+LeakyReLU, then ``radix``
@@ -207,7 +216,7 @@ def split_attention(inputs: Sequence[Tensor], P: Params, prefix: str, radix: int
     y = holder.mean(dim=(1, 2))[:, None, None, :]                      # :179-180
     saved_storage, STORAGE_DTYPE = STORAGE_DTYPE, None                 # the product runs this tiny MLP in fp32
     y = conv2d_same(y, P[prefix + "dense1.kernel"], P[prefix + "dense1.bias"])       # :182
-    y = layer_norm(y, P[prefix + "dense1_bn.gamma"], P[prefix + "dense1_bn.beta"])   # :183
+    y = _norm(y, P, prefix + "dense1_bn", norm)                        # :183 (TBI_TransUNet.py:503: BatchNormalization)
     y = leaky_relu(y)                                                  # :184
     out = None
     for r in range(radix):                                             # :187
@@ -218,7 +227,7 @@ def split_attention(inputs: Sequence[Tensor], P: Params, prefix: str, radix: int
     return _q(out)
 
 
-def cardinal(x: Tensor, P: Params, prefix: str, radix: int, as_executed: bool = True) -> Tensor:
+def cardinal(x: Tensor, P: Params, prefix: str, radix: int, as_executed: bool = True, norm: str = "ln") -> Tensor:
     """cardinal.forward - ResNest.py:136-147.
 
     The loop applies the SAME conv1/conv1_bn/conv2/conv2_bn ``radix`` times to the same input,
@@ -227,25 +236,25 @@ def cardinal(x: Tensor, P: Params, prefix: str, radix: int, as_executed: bool = 
     """
     def branch():
         y = conv2d_same(x, P[prefix + "conv1.kernel"], P[prefix + "conv1.bias"])        # :139
-        y = leaky_relu(layer_norm(y, P[prefix + "conv1_bn.gamma"], P[prefix + "conv1_bn.beta"]))  # :140-141
+        y = leaky_relu(_norm(y, P, prefix + "conv1_bn", norm))                          # :140-141 (TBI_TransUNet.py:465)
         y = conv2d_same(y, P[prefix + "conv2.kernel"], P[prefix + "conv2.bias"])        # :142
-        return leaky_relu(layer_norm(y, P[prefix + "conv2_bn.gamma"], P[prefix + "conv2_bn.beta"]))  # :143-144
+        return leaky_relu(_norm(y, P, prefix + "conv2_bn", norm))                       # :143-144 (TBI_TransUNet.py:472)
     if as_executed:
         inputs = [branch() for _ in range(radix)]
     else:
         y = branch()
         inputs = [y] * radix
-    return split_attention(inputs, P, prefix + "split.", radix)        # :147
+    return split_attention(inputs, P, prefix + "split.", radix, norm)  # :147
 
 
 def residual_S(x: Tensor, P: Params, prefix: str, radix: int, kpaths: int,
-               as_executed: bool = True) -> Tensor:
+               as_executed: bool = True, norm: str = "ln") -> Tensor:
     """residual_S.forward - ResNest.py:89-104."""
-    cards = [cardinal(x, P, f"{prefix}cardinal_blocks.{k}.", radix, as_executed) for k in range(kpaths)]
+    cards = [cardinal(x, P, f"{prefix}cardinal_blocks.{k}.", radix, as_executed, norm) for k in range(kpaths)]
     concats_1 = torch.cat(cards, dim=3)                                 # :91-96
     concats_2 = conv2d_same(concats_1, P[prefix + "concats_2.kernel"], P[prefix + "concats_2.bias"])  # :98
     sc = conv2d_same(x, P[prefix + "convtmp_sc.kernel"], P[prefix + "convtmp_sc.bias"])  # :99
-    sc = leaky_relu(layer_norm(sc, P[prefix + "convtmp_scbn.gamma"], P[prefix + "convtmp_scbn.beta"]))  # :100-101
+    sc = leaky_relu(_norm(sc, P, prefix + "convtmp_scbn", norm))                        # :100-101 (TBI_TransUNet.py:426)
     return _q(sc + concats_2)                                           # :102
 
 
@@ -256,7 +265,7 @@ def _bn(x, P, name, training=None):
 
 
 def resnest_forward(x: Tensor, P: Params, radix: int, kpaths: int, prefix: str = "",
-                    as_executed: bool = True, taps: Optional[dict] = None):
+                    as_executed: bool = True, taps: Optional[dict] = None, norm: str = "ln"):
     """ResNest.forward - ResNest.py:38-55.  Returns (x_4, [x_3, x_2, x_1])."""
     p = prefix
     x = leaky_relu(conv2d_same(x, P[p + "conv1.kernel"], P[p + "conv1.bias"]))             # :39-40
@@ -267,10 +276,10 @@ def resnest_forward(x: Tensor, P: Params, radix: int, kpaths: int, prefix: str =
     if taps is not None:
         taps["stem"] = x
     x = avg_pool2(x)                                                                        # :47
-    x_1 = residual_S(x, P, p + "conv_1.", radix, kpaths, as_executed)                       # :48
-    x_2 = residual_S(avg_pool2(x_1), P, p + "conv_2.", radix, kpaths, as_executed)          # :49-50
-    x_3 = residual_S(avg_pool2(x_2), P, p + "conv_3.", radix, kpaths, as_executed)          # :51-52
-    x_4 = residual_S(avg_pool2(x_3), P, p + "conv_4.", radix, kpaths, as_executed)          # :53-54
+    x_1 = residual_S(x, P, p + "conv_1.", radix, kpaths, as_executed, norm)                       # :48
+    x_2 = residual_S(avg_pool2(x_1), P, p + "conv_2.", radix, kpaths, as_executed, norm)          # :49-50
+    x_3 = residual_S(avg_pool2(x_2), P, p + "conv_3.", radix, kpaths, as_executed, norm)          # :51-52
+    x_4 = residual_S(avg_pool2(x_3), P, p + "conv_4.", radix, kpaths, as_executed, norm)          # :53-54
     return x_4, [x_3, x_2, x_1]                                                             # :55
 
 
@@ -293,7 +302,7 @@ def decoder_block(x: Tensor, skip: Optional[Tensor], P: Params, prefix: str) -> 
 
 
 def decoder_cup(hidden: Tensor, features: Optional[List[Tensor]], P: Params, grid: Tuple[int, int],
-                prefix: str = "") -> Tensor:
+                prefix: str = "", norm: str = "ln") -> Tensor:
     """DecoderCup.forward - Decoder.py:124-143.
 
     ``grid`` generalises the literal (16, 5) of :128,:140 to (H/16, W/16).
@@ -305,7 +314,7 @@ def decoder_cup(hidden: Tensor, features: Optional[List[Tensor]], P: Params, gri
     y = hidden
     x = hidden.reshape(B, gh, gw, -1)                                                        # :128
     x = conv2d_same(x, P[prefix + "conv_more.kernel"], P[prefix + "conv_more.bias"])        # :129
-    x = leaky_relu(layer_norm(x, P[prefix + "bn1.gamma"], P[prefix + "bn1.beta"]))         # :130-131
+    x = leaky_relu(_norm(x, P, prefix + "bn1", norm))                                       # :130-131 (TBI_TransUNet.py:304,549-550)
     for i in range(3):                                                                      # :132
         skip = features[i] if features is not None else None                               # :133-136
         x = decoder_block(x, skip, P, f"{prefix}blocks.{i}.")                               # :137
@@ -345,7 +354,7 @@ def vit_block(x: Tensor, P: Params, prefix: str, num_heads: int = 4):
 
 def vision_transformer_forward(x: Tensor, P: Params, radix: int = 3, kpaths: int = 3,
                                use_vit: bool = False, num_vit_layers: int = 8,
-                               as_executed: bool = True) -> Tensor:
+                               as_executed: bool = True, norm: str = "ln") -> Tensor:
     """VisionTransformer.forward - VisionTransformer.py:220-223 (Embeddings :112-120, Transformer :183-186).
 
     ``use_vit=False`` is BASELINE config 2 ("Arch B, no ViT"): the hidden state fed to the decoder is
@@ -353,7 +362,7 @@ def vision_transformer_forward(x: Tensor, P: Params, radix: int = 3, kpaths: int
     The position "embedding" is a constant zero tensor (:108) and dropout rates are 0 (:10,:61,:85).
     """
     B, H, W, _ = x.shape
-    x4, feats = resnest_forward(x, P, radix, kpaths, "transformer.embeddings.hybrid_model.", as_executed)
+    x4, feats = resnest_forward(x, P, radix, kpaths, "transformer.embeddings.hybrid_model.", as_executed, norm=norm)
     e = conv2d_same(x4, P["transformer.embeddings.patch_embeddings.kernel"],
                     P["transformer.embeddings.patch_embeddings.bias"])                      # :114
     gh, gw = H // 16, W // 16
@@ -363,7 +372,7 @@ def vision_transformer_forward(x: Tensor, P: Params, radix: int = 3, kpaths: int
             hidden, _ = vit_block(hidden, P, f"transformer.encoder.Transformer_layers.{l}.")
         hidden = layer_norm(hidden, P["transformer.encoder.encoder_norm.gamma"],
                             P["transformer.encoder.encoder_norm.beta"], KERAS["vit_ln_eps"])  # :169
-    return decoder_cup(hidden, feats, P, (gh, gw), "decoder.")                              # :222
+    return decoder_cup(hidden, feats, P, (gh, gw), "decoder.", norm)                        # :222
 
 
 def cce_label_smoothing(y_true: Tensor, probs: Tensor) -> Tensor:
@@ -415,7 +424,7 @@ def trainable_names(P: Params) -> List[str]:
 
 def train_step(x: Tensor, y: Tensor, P: Params, opt_state: dict, global_batch_size: int, lr: float = 1e-3,
                radix: int = 3, kpaths: int = 3, use_vit: bool = False, as_executed: bool = False,
-               grad_allreduce=None):
+               grad_allreduce=None, transunet: bool = False):
     """VisionTransformer.train_step - VisionTransformer.py:235-246.
 
     forward -> loss (sum / GLOBAL batch) -> gradients -> clip_by_global_norm(1.0) -> Adam.
@@ -428,8 +437,11 @@ def train_step(x: Tensor, y: Tensor, P: Params, opt_state: dict, global_batch_si
     leaves = [P[n].detach().clone().requires_grad_(True) for n in names]
     Pl = dict(P)
     Pl.update(dict(zip(names, leaves)))
-    probs = vision_transformer_forward(x, Pl, radix, kpaths, use_vit, as_executed=as_executed)
-    loss = compute_loss(y, probs, global_batch_size)
+    probs = vision_transformer_forward(x, Pl, radix, kpaths, use_vit, as_executed=as_executed, norm="bn" if transunet else "ln")
+    if transunet:   # TBI_TransUNet.py:546,583: CategoricalCrossentropy(label_smoothing=0.1) with the DEFAULT reduction = mean over B*H*W
+        loss = cce_label_smoothing(y, probs).mean()
+    else:
+        loss = compute_loss(y, probs, global_batch_size)
     grads = torch.autograd.grad(loss, leaves)
     clipped, gnorm = clip_by_global_norm(grads)
     if grad_allreduce is not None:
@@ -598,7 +610,7 @@ class _Builder:
 
 def init_resnest_params(channel: int, radix: int, kpaths: int, ksize: int = 3, seed: int = 0,
                         dtype=torch.float64, prefix: str = "", perturb: bool = False,
-                        builder: Optional[_Builder] = None) -> Params:
+                        builder: Optional[_Builder] = None, widths=(64, 128, 256, 512), bn: bool = False) -> Params:
     """Parameters of ResNest(height,width,channel,ksize,radix,kpaths) - ResNest.py:7-36 (HeNormal everywhere).
 
     ``perturb=True`` randomises biases / norm affine parameters / BN moving statistics so that
@@ -612,32 +624,32 @@ def init_resnest_params(channel: int, radix: int, kpaths: int, ksize: int = 3, s
     bld.conv(p + "convtmp_2", 3, 32, 32, rand_bias=perturb)
     bld.norm(p + "convtmp_2bn", 32, bn=True, perturb=perturb)
     cin = 32
-    for s, oc in enumerate((64, 128, 256, 512), start=1):
+    for s, oc in enumerate(widths, start=1):   # TBI_TransUNet.py:368: conv_4 has 256 output channels
         sp = f"{p}conv_{s}."
         cv11, cvkk, hid = cardinal_channels(oc, radix, kpaths)
         for k in range(kpaths):
             cp = f"{sp}cardinal_blocks.{k}."
             bld.conv(cp + "conv1", 1, cin, cv11, rand_bias=perturb)
-            bld.norm(cp + "conv1_bn", cv11, perturb=perturb)
+            bld.norm(cp + "conv1_bn", cv11, bn=bn, perturb=perturb)
             bld.conv(cp + "conv2", ksize, cv11, cvkk, rand_bias=perturb)
-            bld.norm(cp + "conv2_bn", cvkk, perturb=perturb)
+            bld.norm(cp + "conv2_bn", cvkk, bn=bn, perturb=perturb)
             bld.conv(cp + "split.dense1", 1, cvkk, hid, rand_bias=perturb)
-            bld.norm(cp + "split.dense1_bn", hid, perturb=perturb)
+            bld.norm(cp + "split.dense1_bn", hid, bn=bn, perturb=perturb)
             bld.conv(cp + "split.dense2", 1, hid, cvkk, rand_bias=perturb)
         bld.conv(sp + "concats_2", ksize, kpaths * cvkk, oc, rand_bias=perturb)
         bld.conv(sp + "convtmp_sc", 1, cin, oc, rand_bias=perturb)
-        bld.norm(sp + "convtmp_scbn", oc, perturb=perturb)
+        bld.norm(sp + "convtmp_scbn", oc, bn=bn, perturb=perturb)
         cin = oc
     return bld.P
 
 
 def init_decoder_params(num_classes: int = 3, hidden: int = 512, seed: int = 0, dtype=torch.float64,
-                        prefix: str = "", perturb: bool = False, builder: Optional[_Builder] = None) -> Params:
+                        prefix: str = "", perturb: bool = False, builder: Optional[_Builder] = None, bn: bool = False) -> Params:
     """Parameters of DecoderCup(num_classes) - Decoder.py:99-122 with DecoderBlock :8-59."""
     bld = builder or _Builder(seed, dtype)
     p = prefix
     bld.conv(p + "conv_more", 3, hidden, 256, rand_bias=perturb)
-    bld.norm(p + "bn1", 256, perturb=perturb)
+    bld.norm(p + "bn1", 256, bn=bn, perturb=perturb)
     cin = 256
     for i, oc in enumerate((256, 128, 64)):
         bp = f"{p}blocks.{i}."
@@ -667,15 +679,18 @@ def init_vit_params(bld: _Builder, prefix: str, hidden: int = 512, mlp: int = 20
 
 def init_vision_transformer_params(channel: int = 10, num_classes: int = 3, radix: int = 3, kpaths: int = 3,
                                    use_vit: bool = False, seed: int = 0, dtype=torch.float64,
-                                   perturb: bool = False) -> Params:
-    """Parameters of VisionTransformer(...) - VisionTransformer.py:193-210 (ResNest radix=3,kpaths=3,ksize=3, :100)."""
+                                   perturb: bool = False, transunet: bool = False) -> Params:
+    """Parameters of VisionTransformer(...) - VisionTransformer.py:193-210 (ResNest radix=3,kpaths=3,ksize=3, :100).
+    ``transunet=True``: the older self-contained copy TBI_TransUNet.py - BatchNormalization where ResNest.py / Decoder.py use
+    LayerNormalization (:304,426,465,472,503) and a 256-channel stage 4 (:368), hence a 256 -> 512 patch embedding (:110)."""
     bld = _Builder(seed, dtype)
+    widths = (64, 128, 256, 256) if transunet else (64, 128, 256, 512)
     init_resnest_params(channel, radix, kpaths, 3, prefix="transformer.embeddings.hybrid_model.",
-                        perturb=perturb, builder=bld)
-    bld.conv("transformer.embeddings.patch_embeddings", 1, 512, 512, he=False, rand_bias=perturb)  # :106 (Glorot)
+                        perturb=perturb, builder=bld, widths=widths, bn=transunet)
+    bld.conv("transformer.embeddings.patch_embeddings", 1, widths[3], 512, he=False, rand_bias=perturb)  # :106 (Glorot)
     if use_vit:
         init_vit_params(bld, "transformer.encoder.", perturb=perturb)
-    init_decoder_params(num_classes, 512, prefix="decoder.", perturb=perturb, builder=bld)
+    init_decoder_params(num_classes, 512, prefix="decoder.", perturb=perturb, builder=bld, bn=transunet)
     return bld.P
 
 

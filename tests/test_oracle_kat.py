@@ -226,3 +226,24 @@ def test_fd_loss_through_softmax():
     y = torch.softmax(torch.randn(2, 3, 3, 3, dtype=D, generator=g), -1)
     _fd_check(lambda z: O.cce_label_smoothing(y, O.softmax_lastaxis(z)), [torch.randn(2, 3, 3, 3, dtype=D, generator=g)])
     _fd_check(lambda z: O.my_loss_cat(y, O.softmax_lastaxis(z), 3, 3), [torch.randn(2, 3, 3, 3, dtype=D, generator=g)])
+
+
+def test_transunet_variant_of_the_oracle():
+    """TBI_TransUNet.py: BatchNormalization for LayerNormalization (:304,426,465,472,503), conv_4 = 256 channels (:368), mean loss (:546)."""
+    P = O.init_vision_transformer_params(channel=1, seed=0, use_vit=True, transunet=True)
+    assert P["transformer.embeddings.hybrid_model.conv_4.concats_2.kernel"].shape == (3, 3, 126, 256)
+    assert P["transformer.embeddings.patch_embeddings.kernel"].shape == (1, 1, 256, 512)
+    for k in ("transformer.embeddings.hybrid_model.conv_1.cardinal_blocks.0.conv1_bn", "decoder.bn1",
+              "transformer.embeddings.hybrid_model.conv_2.convtmp_scbn", "transformer.embeddings.hybrid_model.conv_3.cardinal_blocks.2.split.dense1_bn"):
+        assert k + ".moving_mean" in P and k + ".moving_variance" in P, k
+    # BN inference with fresh statistics is x / sqrt(1 + 1e-3): a cardinal block of the variant on a constant-free input
+    x = torch.randn(1, 8, 8, 32, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    pre = "transformer.embeddings.hybrid_model.conv_1.cardinal_blocks.0."
+    u = O.conv2d_same(x, P[pre + "conv1.kernel"], P[pre + "conv1.bias"])
+    want = O.leaky_relu(u / (1 + 1e-3) ** 0.5)
+    got = O.leaky_relu(O._norm(u, P, pre + "conv1_bn", "bn"))
+    assert torch.allclose(got, want, atol=1e-12)
+    # the loss is the MEAN over pixels (Keras default reduction), i.e. the newer model's sum / (B*H*W)
+    xx, y = O.synthetic_batch(1, 32, 32, 1, seed=1)
+    loss, probs, _, _ = O.train_step(xx, y, dict(P), {}, 1, use_vit=True, transunet=True)
+    assert abs(loss.item() - O.cce_label_smoothing(y, probs).mean().item()) < 1e-12

@@ -227,13 +227,14 @@ class DecoderCup(nn.Module):
     H=256, W=80 it reproduces the reference's reshapes exactly.
     """
 
-    def __init__(self, num_classes, wDecay=None, hidden_size=512, grid=(16, 5)):
+    def __init__(self, num_classes, wDecay=None, hidden_size=512, grid=(16, 5), norm="ln"):
         super().__init__()
         head_channels = 256
         self.wDecay, self.num_classes, self.hidden_size, self.grid = wDecay, num_classes, hidden_size, tuple(grid)
         self.conv_more = Conv2D(hidden_size, head_channels, 3)                        # :103
         self.LeakyReLU1 = LeakyReLU()
-        self.bn1 = LayerNormalization(head_channels)                                  # :112
+        # :112 LayerNormalization; the copy in TBI_TransUNet.py:304 uses BatchNormalization
+        self.bn1 = LayerNormalization(head_channels) if norm == "ln" else BatchNormalization(head_channels)
         skip_channels = [256, 128, 64]
         blocks, cin = [], head_channels
         for i, sk in enumerate(skip_channels):                                        # :114-117

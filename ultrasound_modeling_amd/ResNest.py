@@ -37,14 +37,20 @@ def _span(t: torch.Tensor, n: int) -> torch.Tensor:
     return torch.as_strided(t, (n,), (1,))
 
 
+def _make_norm(kind: str, channels: int):
+    """``*_bn`` layers: LayerNormalization in ResNest.py / Decoder.py, BatchNormalization in the older copy TBI_TransUNet.py."""
+    assert kind in ("ln", "bn")
+    return LayerNormalization(channels) if kind == "ln" else BatchNormalization(channels)
+
+
 class split_attention(nn.Module):
     """ResNest.py:153-199.  Holds dense1 / dense1_bn / dense2; executed by the owning cardinal group."""
 
-    def __init__(self, inchannel, radix, atrous=1, wDecay=None):
+    def __init__(self, inchannel, radix, atrous=1, wDecay=None, norm="ln"):
         super().__init__()
         self.inchannel, self.radix, self.atrous, self.wDecay = inchannel, radix, atrous, wDecay
         self.dense1 = Conv2D(inchannel, inchannel // 2, 1)
-        self.dense1_bn = LayerNormalization(inchannel // 2)
+        self.dense1_bn = _make_norm(norm, inchannel // 2)            # LayerNormalization (:164); BatchNormalization in TBI_TransUNet.py:503
         self.dense1_act = LeakyReLU()
         self.dense2 = Conv2D(inchannel // 2, inchannel, 1)
         for c in (self.dense1, self.dense2):
@@ -62,11 +68,13 @@ class split_attention(nn.Module):
         stack = torch.cat([ops.to_f32(t, Cg) for t in inputs], dim=3)
         ycat[..., :R * Cg] = stack.to(BF16)
         out = ops.new_act(B, H, W, roundup(Cg, 8), dev)
-        d = ops.splitattn_desc(B, H * W, 1, R, Cg, Cg // 2, ycat.shape[3], out.shape[3], ycat.shape[3], out.shape[3], 1.0, 0,
+        bn = isinstance(self.dense1_bn, BatchNormalization)
+        d = ops.splitattn_desc(B, H * W, 1, R, Cg, Cg // 2, ycat.shape[3], out.shape[3], ycat.shape[3], out.shape[3], 1.0, 1 if bn else 0,
                                KERAS_LN_EPS, ACT_LRELU, KERAS_LRELU_ALPHA, R == 1)
         w2 = self.dense2.kernel.data.reshape(1, Cg // 2, Cg).repeat(R, 1, 1).contiguous()   # the SAME dense2 for every r (:188)
         b2 = self.dense2.bias.data.repeat(R).contiguous()
-        params = (self.dense1.kernel.data, self.dense1.bias.data, self.dense1_bn.gamma.data, self.dense1_bn.beta.data, None, None, w2, b2)
+        stats = (self.dense1_bn.moving_mean_p, self.dense1_bn.moving_variance_p) if bn else (None, None)
+        params = (self.dense1.kernel.data, self.dense1.bias.data, self.dense1_bn.gamma.data, self.dense1_bn.beta.data) + stats + (w2, b2)
         ops.splitattn_fwd(d, ycat, params, out)
         return out
 
@@ -77,19 +85,19 @@ class split_attention(nn.Module):
 class cardinal(nn.Module):
     """ResNest.py:110-150."""
 
-    def __init__(self, ksize, outchannel, radix, kpaths, atrous=1, wDecay=None, in_channels=None):
+    def __init__(self, ksize, outchannel, radix, kpaths, atrous=1, wDecay=None, in_channels=None, norm="ln"):
         super().__init__()
         self.outchannel, self.ksize, self.radix, self.kpaths, self.atrous, self.wDecay = outchannel, ksize, radix, kpaths, atrous, wDecay
         self.in_channels = in_channels if in_channels is not None else outchannel   # stage input = outchannel (= stage_out/2)
         self.cv11 = int(outchannel / radix / kpaths)    # ResNest.py:120
         self.cvkk = int(outchannel / kpaths)            # ResNest.py:121
         self.conv1 = Conv2D(self.in_channels, self.cv11, 1, atrous)
-        self.conv1_bn = LayerNormalization(self.cv11)
+        self.conv1_bn = _make_norm(norm, self.cv11)
         self.conv1_act = LeakyReLU()
         self.conv2 = Conv2D(self.cv11, self.cvkk, ksize, atrous)
-        self.conv2_bn = LayerNormalization(self.cvkk)
+        self.conv2_bn = _make_norm(norm, self.cvkk)
         self.conv2_act = LeakyReLU()
-        self.split = split_attention(self.cvkk, radix, atrous, wDecay)
+        self.split = split_attention(self.cvkk, radix, atrous, wDecay, norm=norm)
         for c in (self.conv1, self.conv2):
             c.on_finalize = lambda device: None   # packed by the owning _CardinalGroup
         self._solo = None
@@ -118,6 +126,10 @@ class _CardinalGroup:
         self.U, self.V = self.P * self.cv11, self.P * self.cvkk
         self.Up, self.Vp = roundup(self.U, 8), roundup(self.V, 8)
         self.cin_p = roundup(self.cin, 8)
+        # TBI_TransUNet.py variant: the three norms are inference BatchNormalizations -> per-channel affine (norm mode 1, one "group")
+        self.bn = isinstance(c0.conv1_bn, BatchNormalization)
+        self.nmode, self.ngroups = (1, 1) if self.bn else (0, self.P)
+        self.st1 = self.st2 = self.sta = (None, None)
 
     # variables that must be back to back in the flat buffer (per-path vectors are read as one [P*...] vector)
     def adjacent_params(self):
@@ -147,11 +159,27 @@ class _CardinalGroup:
         names = (s.dense1.kernel, s.dense1.bias, s.dense1_bn.gamma, s.dense1_bn.beta, s.dense2.kernel, s.dense2.bias)
         self.mlp_p = tuple(p.data for p in names)
         self.mlp_g = tuple(p.grad for p in names)
+        if self.bn:   # the per-path moving statistics as ONE contiguous vector per norm (the layers keep views of it)
+            self.st1 = self._share_stats([c.conv1_bn for c in self.cards], self.Up, device)
+            self.st2 = self._share_stats([c.conv2_bn for c in self.cards], self.Vp, device)
+            self.sta = self._share_stats([c.split.dense1_bn for c in self.cards], roundup(self.P * self.hid, 8), device)
         # adjacency sanity: path p's variable must start right after path p-1's
         for a, b in zip(self.cards[:-1], self.cards[1:]):
             assert b.conv1.bias.data_ptr() == a.conv1.bias.data_ptr() + 4 * self.cv11, "cardinal params are not adjacent"
             assert b.split.dense2.kernel.data_ptr() == a.split.dense2.kernel.data_ptr() + 4 * self.hid * self.cvkk
         self.repack()
+
+    @staticmethod
+    def _share_stats(bns, width, device):
+        mean = torch.zeros(width, dtype=torch.float32, device=device)
+        var = torch.ones(width, dtype=torch.float32, device=device)
+        o = 0
+        for bn in bns:
+            mean[o:o + bn.C] = bn.moving_mean.to(device)
+            var[o:o + bn.C] = bn.moving_variance.to(device)
+            bn._buffers["moving_mean_p"], bn._buffers["moving_variance_p"] = mean[o:o + bn.C], var[o:o + bn.C]
+            o += bn.C
+        return mean, var
 
     def pack_jobs(self):
         T = self.k * self.k
@@ -184,22 +212,26 @@ class _CardinalGroup:
 
     def _sa_desc(self, B, HW):
         use_sigmoid = self.radix == 1   # ResNest.py:189-190
-        return ops.splitattn_desc(B, HW, self.P, 1, self.cvkk, self.hid, self.Vp, self.Vp, self.Vp, self.Vp, float(self.radix), 0,
+        return ops.splitattn_desc(B, HW, self.P, 1, self.cvkk, self.hid, self.Vp, self.Vp, self.Vp, self.Vp, float(self.radix), self.nmode,
                                   KERAS_LN_EPS, ACT_LRELU, KERAS_LRELU_ALPHA, use_sigmoid)
+
+    def _mlp_params(self):
+        return self.mlp_p[:4] + self.sta + self.mlp_p[4:]
 
     def forward(self, x, out=None):
         B, H, W, C, _ = ops.geom(x)
         dev = x.device
         a = KERAS_LRELU_ALPHA
         u_raw = ops.conv2d_fwd(x, self.w1_f, self.b1, 1, 1, ops.new_act(B, H, W, self.Up, dev))                 # :139
-        u = ops.norm_act_fwd(u_raw, self.U, self.g1, self.be1, torch.empty_like(u_raw), 0, self.P, KERAS_LN_EPS, ACT_LRELU, a)  # :140-141
+        u = ops.norm_act_fwd(u_raw, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.nmode, self.ngroups, KERAS_LN_EPS, ACT_LRELU, a,
+                             *self.st1)                                                                                    # :140-141
         v_raw = ops.conv2d_fwd(u, self.w2_f, self.b2, self.k, self.dil, ops.new_act(B, H, W, self.Vp, dev))    # :142
         # :143-144; the same launch emits the partial rows of the global average pool the split attention starts with (:179)
-        y, gap = ops.norm_act_fwd_gap(v_raw, self.V, self.g2, self.be2, torch.empty_like(v_raw), 0, self.P, KERAS_LN_EPS, ACT_LRELU, a)
+        y, gap = ops.norm_act_fwd_gap(v_raw, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.nmode, self.ngroups, KERAS_LN_EPS,
+                                      ACT_LRELU, a, *self.st2)
         out = out if out is not None else ops.new_act(B, H, W, self.Vp, dev)
         d = self._sa_desc(B, H * W)
-        params = self.mlp_p[:4] + (None, None) + self.mlp_p[4:]
-        _, g, s, ws = ops.splitattn_fwd(d, y, params, out, gap=gap)                                               # :171-199
+        _, g, s, ws = ops.splitattn_fwd(d, y, self._mlp_params(), out, gap=gap)                                   # :171-199
         self._saved = (x, u_raw, u, v_raw, y, g, s, ws)
         return out
 
@@ -210,18 +242,17 @@ class _CardinalGroup:
         a = KERAS_LRELU_ALPHA
         T = self.k * self.k
         d = self._sa_desc(B, H * W)
-        params = self.mlp_p[:4] + (None, None) + self.mlp_p[4:]
         # the re-weighting's backward (dy = radix*s*dout + dg) is formed inside the norm backward: no dy tensor, no apply pass
-        sa_s, sa_dg = ops.splitattn_bwd(d, y, dout, params, self.mlp_g, g, s, ws, None)
-        dv = ops.norm_act_bwd_sa(v_raw, dout, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, 0, self.P,
-                                 KERAS_LN_EPS, ACT_LRELU, a, sa_s, sa_dg, float(self.radix), dbias=self.db2)
+        sa_s, sa_dg = ops.splitattn_bwd(d, y, dout, self._mlp_params(), self.mlp_g, g, s, ws, None)
+        dv = ops.norm_act_bwd_sa(v_raw, dout, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, self.nmode, self.ngroups,
+                                 KERAS_LN_EPS, ACT_LRELU, a, sa_s, sa_dg, float(self.radix), *self.st2, dbias=self.db2)
         # grouped 3x3: dense wgrad into scratch, keep the diagonal blocks
         # grouped 3x3: the dense [T][Up][Vp] gradient is never materialised - only the diagonal blocks are scattered
         with ops.side_stream(u, dv):
             ops.conv2d_wgrad_mapped(u, dv, self.k, self.dil, self._maps()[1])
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, self.dil, torch.empty_like(u))
-        du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, 0, self.P,
-                                  KERAS_LN_EPS, ACT_LRELU, a, dbias=self.db1)
+        du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, self.nmode, self.ngroups,
+                                  KERAS_LN_EPS, ACT_LRELU, a, *self.st1, dbias=self.db1)
         with ops.side_stream(x, du_raw):
             ops.conv2d_wgrad_mapped(x, du_raw, 1, 1, self._maps()[0])
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
@@ -230,16 +261,16 @@ class _CardinalGroup:
 class residual_S(nn.Module):
     """ResNest.py:61-107."""
 
-    def __init__(self, ksize, outchannel, radix, kpaths, atrous=1, wDecay=None, in_channels=None):
+    def __init__(self, ksize, outchannel, radix, kpaths, atrous=1, wDecay=None, in_channels=None, norm="ln"):
         super().__init__()
         self.kpaths, self.atrous, self.ksize, self.outchannel, self.radix, self.wDecay = kpaths, atrous, ksize, outchannel, radix, wDecay
         self.in_channels = in_channels if in_channels is not None else outchannel // 2
         self.cardinal_blocks = nn.ModuleList(
-            [cardinal(ksize, outchannel // 2, radix, kpaths, atrous, wDecay, in_channels=self.in_channels) for _ in range(kpaths)])
+            [cardinal(ksize, outchannel // 2, radix, kpaths, atrous, wDecay, in_channels=self.in_channels, norm=norm) for _ in range(kpaths)])
         cvkk = self.cardinal_blocks[0].cvkk
         self.concats_2 = Conv2D(kpaths * cvkk, outchannel, ksize, atrous)
         self.convtmp_sc = Conv2D(self.in_channels, outchannel, 1, atrous)
-        self.convtmp_scbn = LayerNormalization(outchannel)
+        self.convtmp_scbn = _make_norm(norm, outchannel)
         self.convtmp_scact = LeakyReLU()
         self._group = _CardinalGroup(list(self.cardinal_blocks), radix)
 
@@ -274,7 +305,9 @@ class residual_S(nn.Module):
 class ResNest(nn.Module):
     """ResNest.py:4-58.  ``forward(x)`` returns ``(x_4, [x_3, x_2, x_1])`` (NHWC, bf16)."""
 
-    def __init__(self, height, width, channel, ksize, radix=4, kpaths=4, wDecay=None):
+    def __init__(self, height, width, channel, ksize, radix=4, kpaths=4, wDecay=None, *, norm="ln", widths=(64, 128, 256, 512)):
+        """``norm`` / ``widths``: ("ln", (64,128,256,512)) is ResNest.py; ("bn", (64,128,256,256)) the copy inside TBI_TransUNet.py
+        (BatchNormalization at :426,465,472,503 and a 256-channel conv_4 at :368)."""
         super().__init__()
         self.height, self.width, self.channel = height, width, channel
         self.ksize, self.radix, self.kpaths, self.wDecay = ksize, radix, kpaths, wDecay
@@ -290,10 +323,12 @@ class ResNest(nn.Module):
         self.conv2_pool = AveragePooling2D()
         self.conv3_pool = AveragePooling2D()
         self.conv4_pool = AveragePooling2D()
-        self.conv_1 = residual_S(ksize, 64, radix, kpaths, wDecay=wDecay, in_channels=32)
-        self.conv_2 = residual_S(ksize, 128, radix, kpaths, wDecay=wDecay, in_channels=64)
-        self.conv_3 = residual_S(ksize, 256, radix, kpaths, wDecay=wDecay, in_channels=128)
-        self.conv_4 = residual_S(ksize, 512, radix, kpaths, wDecay=wDecay, in_channels=256)
+        w = tuple(widths)
+        self.widths = w
+        self.conv_1 = residual_S(ksize, w[0], radix, kpaths, wDecay=wDecay, in_channels=32, norm=norm)
+        self.conv_2 = residual_S(ksize, w[1], radix, kpaths, wDecay=wDecay, in_channels=w[0], norm=norm)
+        self.conv_3 = residual_S(ksize, w[2], radix, kpaths, wDecay=wDecay, in_channels=w[1], norm=norm)
+        self.conv_4 = residual_S(ksize, w[3], radix, kpaths, wDecay=wDecay, in_channels=w[2], norm=norm)
 
     def forward(self, x, outs=None):
         """x: NHWC float32/float64 [B,H,W,channel] (cast to bf16 here, ResNest.py:39) or an already-cast bf16 tensor.
