@@ -36,7 +36,7 @@ import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
 HBM_BYTES_PER_S = 8.0e12     # HBM3E peak, MI355X_MICROARCH.md
-BASE_BATCH = {"B": 16, "A": 32}   # images per GPU at N=1 (BASELINE configs[1] / configs[2])
+BASE_BATCH = {"B": 16, "A": 32, "T": 8}   # images per GPU at N=1 (BASELINE configs[1] / configs[2] / configs[3])
 H = W = 256
 C_IN = 1
 
@@ -240,7 +240,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--arch", choices=["B", "A"], default="B", help="B: ResNest.py+Decoder.py (configs[1], default); A: TBI_ResNest.py (configs[2])")
+    ap.add_argument("--arch", choices=["B", "A", "T"], default="B",
+                    help="B: ResNest.py+Decoder.py (configs[1], default); A: TBI_ResNest.py (configs[2]); T: TBI_TransUNet.py at 512x512 (configs[3], throughput only)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: fixed per-GPU batch; strong: fixed global batch split over the replicas")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -256,6 +257,10 @@ def main():
     dev = torch.device("cuda", local)
     arch = args.arch
     base = BASE_BATCH[arch]
+    global H, W
+    if arch == "T":                  # configs[3] is quoted at 512x512; the roofline / CPU legs are defined for the headline configs only
+        H = W = 512
+        args.profile_steps, args.no_cpu_baseline = 0, True
     if args.scaling == "strong":
         assert base % world == 0, f"strong scaling: the global batch {base} must divide over {world} replicas"
         per_gpu = base // world
@@ -267,6 +272,9 @@ def main():
     if arch == "B":
         from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
         net = VisionTransformer(batch_size=global_batch, img_size=(H, W), in_channels=C_IN, device=str(dev), seed=0)
+    elif arch == "T":
+        from ultrasound_modeling_amd.TBI_TransUNet import VisionTransformer as TransUNet
+        net = TransUNet(img_size=(H, W), batch_size=global_batch, in_channels=C_IN, device=str(dev), seed=0)
     else:
         from ultrasound_modeling_amd.TBI_ResNest import ResNest
         net = ResNest(H, W, C_IN, 3, ksize=3, radix=3, kpaths=4, learning_rate=5e-3, device=str(dev), seed=0)
@@ -353,12 +361,13 @@ def main():
 
     if rank == 0:
         names = {"B": "BASELINE configs[1]: Arch B (ResNest.py r=3,k=3 + Decoder.py, no ViT) train step",
-                 "A": "BASELINE configs[2]: Arch A (TBI_ResNest.py model r=3,k=4, my_loss_cat, Adam 5e-3) train step"}
-        out = {"metric": "segmentation training images/sec at 256x256", "value": round(global_batch * args.steps / el, 2),
+                 "A": "BASELINE configs[2]: Arch A (TBI_ResNest.py model r=3,k=4, my_loss_cat, Adam 5e-3) train step",
+                 "T": "BASELINE configs[3]: TBI_TransUNet.py (ResNeSt encoder with BatchNorm + 8-layer ViT bottleneck, 1024 tokens + decoder) train step"}
+        out = {"metric": f"segmentation training images/sec at {H}x{W}", "value": round(global_batch * args.steps / el, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"{names[arch]}, 256x256x1, {per_gpu} images per GPU, bf16 MFMA / fp32 accumulate, fp32 master weights + Adam",
+               "config": {"workload": f"{names[arch]}, {H}x{W}x1, {per_gpu} images per GPU, bf16 MFMA / fp32 accumulate, fp32 master weights + Adam",
                           "arch": arch, "per_gpu_batch": per_gpu, "global_batch": global_batch, "parallelism": f"dp{world}",
                           "hip_graph": bool(use_graph), "dp_exchange_chunks": getattr(net.grad_sync, "nchunks", 0) if net.grad_sync is not None else 0,
                           "final_loss": round(loss_val, 4)},

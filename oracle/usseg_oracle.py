@@ -325,6 +325,70 @@ def decoder_cup(hidden: Tensor, features: Optional[List[Tensor]], P: Params, gri
 
 
 # ----------------------------------------------------------------------------
+# Decoder.py:150-346 - kernel-sharing atrous convolution (KSAC); defined in the reference, used by no driver
+# ----------------------------------------------------------------------------
+KSAC_DILATIONS = (1, 2, 4, 8, 16)   # Decoder.py:294
+
+
+def ksac_effective_dilations(dilations=KSAC_DILATIONS, as_written: bool = True):
+    """kernel_sharing_conv2d (Decoder.py:266-288) computes one 1x1 product per tap and, for every dilation rate in turn, slices
+    and zero-pads it to apply the tap's shift - but it re-assigns ``value`` inside the loop over the rates (:280-285), so rate j
+    shifts the ALREADY shifted tensor: the shifts accumulate.  Shifting twice in the same direction with zero fill equals one
+    shift by the sum, hence as written branch j is an ordinary 'same' dilated convolution with dilation d_0 + ... + d_j:
+    (1, 2, 4, 8, 16) -> (1, 3, 7, 15, 31).  ``as_written=False`` gives the listed rates (what the KSAC paper intends)."""
+    if not as_written:
+        return tuple(dilations)
+    out, acc = [], 0
+    for d in dilations:
+        acc += d
+        out.append(acc)
+    return tuple(out)
+
+
+def kernel_sharing_conv2d(x: Tensor, w: Tensor, dilations=KSAC_DILATIONS, as_written: bool = True) -> List[Tensor]:
+    """Decoder.py:227-291: the SAME 3x3 kernel [kh,kw,Cin,Cout] (no bias) at every dilation rate -> list of tensors."""
+    return [conv2d_same(x, w, None, dilation=d) for d in ksac_effective_dilations(dilations, as_written)]
+
+
+def kernel_sharing_conv2d_literal(x: Tensor, w: Tensor, dilations=KSAC_DILATIONS) -> List[Tensor]:
+    """Line-by-line restatement of Decoder.py:227-291 (k*k batched matmuls, slice, pad, add) INCLUDING the cumulative re-slicing of
+    ``value`` - the known-answer check for ksac_effective_dilations (pure slicing / padding, small inputs only)."""
+    N, H, W, c = x.shape
+    kh, kw, _, C = w.shape
+    xs = x.reshape(N, H * W, c)
+    ys = [torch.zeros(N, H, W, C, dtype=x.dtype) for _ in dilations]
+    for i in range(kh * kw):
+        r, q = i // kw, i % kw
+        value = (xs @ w[r, q]).reshape(N, H, W, C)                                   # :268-269
+        for j, d in enumerate(dilations):
+            v_shift, h_shift = (kh // 2 - r) * d, (kw // 2 - q) * d                    # :183-184
+            v0, h0 = (-v_shift if v_shift < 0 else 0), (-h_shift if h_shift < 0 else 0)
+            v1, h1 = (-v_shift if v_shift > 0 else H), (-h_shift if h_shift > 0 else W)   # :277-278 (0 -> full extent)
+            value = value[:, v0:v1, h0:h1, :]                                          # :280 (re-assigned: cumulative!)
+            pad_v = (v_shift, 0) if v_shift > 0 else (0, -v_shift)                     # :196-197
+            pad_h = (h_shift, 0) if h_shift > 0 else (0, -h_shift)
+            value = F.pad(value, (0, 0, pad_h[0], pad_h[1], pad_v[0], pad_v[1]))       # :284
+            ys[j] = ys[j] + value                                                      # :288
+    return ys
+
+
+def ksac_layer(x: Tensor, P: Params, prefix: str, dilations=KSAC_DILATIONS, as_written: bool = True) -> List[Tensor]:
+    """KernelSharingConv.call - Decoder.py:335-346: shared-kernel convs, per-rate BatchNormalization (inference mode), exact GELU."""
+    ys = kernel_sharing_conv2d(x, P[prefix + "kernel"], dilations, as_written)
+    return [_q(gelu_exact(_bn(y, P, f"{prefix}bn_r_{r}"))) for y, r in zip(ys, dilations)]
+
+
+def init_ksac_params(cin: int, filters: int, seed: int = 0, dtype=torch.float64, prefix: str = "", perturb: bool = False,
+                     dilations=KSAC_DILATIONS, he: bool = True) -> Params:
+    bld = _Builder(seed, dtype)
+    w = _he_normal(bld.gen, (3, 3, cin, filters), 9 * cin, dtype) if he else _glorot_uniform(bld.gen, (3, 3, cin, filters), 9 * cin, 9 * filters, dtype)
+    bld.P[prefix + "kernel"] = w
+    for r in dilations:
+        bld.norm(f"{prefix}bn_r_{r}", filters, bn=True, perturb=perturb)
+    return bld.P
+
+
+# ----------------------------------------------------------------------------
 # Arch B wrapper: VisionTransformer.py
 # ----------------------------------------------------------------------------
 def gelu_exact(x: Tensor) -> Tensor:

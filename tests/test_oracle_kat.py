@@ -247,3 +247,24 @@ def test_transunet_variant_of_the_oracle():
     xx, y = O.synthetic_batch(1, 32, 32, 1, seed=1)
     loss, probs, _, _ = O.train_step(xx, y, dict(P), {}, 1, use_vit=True, transunet=True)
     assert abs(loss.item() - O.cce_label_smoothing(y, probs).mean().item()) < 1e-12
+
+
+def test_ksac_as_written_is_a_dilated_conv_with_cumulative_rates():
+    """Decoder.py:266-288: the literal slice / pad / add restatement (with ``value`` re-assigned inside the loop over the rates,
+    :280-285) equals ordinary 'same' dilated convolutions with the SHARED kernel at dilations (1, 3, 7, 15, 31)."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 20, 18, 3, generator=g, dtype=torch.float64)     # every single rate (<= 16) must be smaller than H and W: the
+    w = torch.randn(3, 3, 3, 4, generator=g, dtype=torch.float64)       # reference's slice + pad + EnsureShape fails otherwise (:280-286)
+    assert O.ksac_effective_dilations() == (1, 3, 7, 15, 31) and O.ksac_effective_dilations(as_written=False) == (1, 2, 4, 8, 16)
+    lit = O.kernel_sharing_conv2d_literal(x, w)
+    fast = O.kernel_sharing_conv2d(x, w)
+    for a, b in zip(lit, fast):
+        assert torch.allclose(a, b, atol=1e-12)
+    # only the first rate agrees with the as-intended reading
+    intended = O.kernel_sharing_conv2d(x, w, as_written=False)
+    assert torch.allclose(lit[0], intended[0], atol=1e-12) and not torch.allclose(lit[1], intended[1], atol=1e-6)
+    # a delta input shows the taps of branch 1 at distance 3 (= 1 + 2), not 2
+    d = torch.zeros(1, 9, 9, 1, dtype=torch.float64)
+    d[0, 4, 4, 0] = 1.0
+    y = O.kernel_sharing_conv2d_literal(d, torch.ones(3, 3, 1, 1, dtype=torch.float64), dilations=(1, 2))[1][0, :, :, 0]
+    assert y[1, 1] == 1 and y[4, 7] == 1 and y[2, 2] == 0 and y.sum() == 9

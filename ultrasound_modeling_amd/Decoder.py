@@ -322,3 +322,136 @@ class DecoderCup(nn.Module):
 
     def __call__(self, hidden_states, features=None, *args, **kwargs):
         return self.forward(hidden_states, features)
+
+
+# ------------------------------------------------------------------------------------------------ KSAC (Decoder.py:150-346)
+def ksac_effective_dilations(dilation_rates_list, as_written=True):
+    """kernel_sharing_conv2d re-assigns ``value`` inside its loop over the rates (Decoder.py:280-285), so the per-tap shifts
+    ACCUMULATE: as written, branch j is a 'same' dilated convolution with dilation d_0 + ... + d_j ((1,2,4,8,16) -> (1,3,7,15,31)).
+    ``as_written=False``: the listed rates (the KSAC paper's intent).  oracle/usseg_oracle.py proves the equivalence against a
+    line-by-line restatement (tests/test_oracle_kat.py)."""
+    if not as_written:
+        return tuple(dilation_rates_list)
+    out, acc = [], 0
+    for d in dilation_rates_list:
+        acc += d
+        out.append(acc)
+    return tuple(out)
+
+
+class KernelSharingConv(nn.Module):
+    """Decoder.py:294-346: ONE 3x3 kernel [kh,kw,Cin,filters] (no bias) applied at every dilation rate, each branch followed by its
+    own BatchNormalization (inference mode as driven) and exact GELU; ``forward`` returns the LIST of branch tensors.
+
+    MI355X form: the branches are independent jobs that share one packed weight operand - forward and backward-data run as
+    multi-job conv launches (rates that divide the image take the LDS-DMA halo kernels, the others the gather GEMM), the five
+    weight gradients accumulate into the one shared variable.  Keras builds the kernel lazily from the input shape; here the
+    input width is the keyword ``in_channels``."""
+
+    def __init__(self, filters, kernel_size, dilation_rates_list=(1, 2, 4, 8, 16), trainable=True, kernel_initializer="glorot_uniform",
+                 kernel_regularizer=None, use_bn=True, name=None, *, in_channels, as_written=True):
+        super().__init__()
+        ks = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        assert ks == 3, "the reference instantiates 3x3 kernels (Decoder.py:154)"
+        self.filters, self.dilation_rates_list, self.use_bn = int(filters), tuple(dilation_rates_list), use_bn
+        self.dilations = ksac_effective_dilations(self.dilation_rates_list, as_written)
+        init = "he" if str(kernel_initializer).lower().startswith("he") else "glorot"
+        self.conv = Conv2D(in_channels, self.filters, 3, 1, init=init)
+        del self.conv._parameters["bias"]                      # add_weight('kernel') only (:322-327): no bias variable
+        self.conv.bias = None
+        if use_bn:
+            for r in self.dilation_rates_list:                 # :333 name=f"bn_r_{r}"
+                setattr(self, f"bn_r_{r}", BatchNormalization(self.filters))
+
+    @property
+    def kernel(self):
+        return self.conv.kernel
+
+    def forward(self, inputs):
+        B, H, W, _, _ = ops.geom(inputs)
+        dev = inputs.device
+        c = self.conv
+        c._x = inputs
+        raws = [ops.new_act(B, H, W, c.cout_p, dev) for _ in self.dilations]
+        jobs = [(inputs, c.wp_f, None, 3, d, raws[j], ACT_NONE, 0.0) for j, d in enumerate(self.dilations)]
+        for i in range(0, len(jobs), 4):
+            ops.conv2d_fwd_multi(jobs[i:i + 4])                # :266-288, all rates of a group in one launch where the geometry allows
+        self._raws = raws
+        if not self.use_bn:
+            self._outs = [ops.act_fwd(r, torch.empty_like(r), ops.ACT_GELU, 0.0) for r in raws]
+            return self._outs
+        return [getattr(self, f"bn_r_{r}").forward(raw, ops.ACT_GELU, 0.0) for raw, r in zip(raws, self.dilation_rates_list)]   # :337-345
+
+    def backward(self, dys, need_dx=True):
+        """dys: list of gradients w.r.t. the branch outputs -> gradient w.r.t. the input; the kernel gradient accumulates."""
+        c, x = self.conv, self.conv._x
+        draws = []
+        for dy, raw, r in zip(dys, self._raws, self.dilation_rates_list):
+            draws.append(getattr(self, f"bn_r_{r}").backward(dy) if self.use_bn else ops.act_bwd(raw, dy, torch.empty_like(dy), ops.ACT_GELU, 0.0))
+        plain = c.cin_p == c.cin and c.cout_p == c.cout
+        wj = [(x, dr, 3, d, c.kernel.grad if plain else None, None if plain else c._wgrad_map()) for dr, d in zip(draws, self.dilations)]
+        for i in range(0, len(wj), 4):
+            ops.conv2d_wgrad_multi(wj[i:i + 4])                # five gradients into ONE variable (deferred finishes are serialised per destination)
+        if not need_dx:
+            return None
+        B, H, W, _, _ = ops.geom(x)
+        dx = ops.new_act(B, H, W, c.cin_p, x.device)
+        for j, (dr, d) in enumerate(zip(draws, self.dilations)):
+            ops.conv2d_dgrad(dr, c.wp_d, 3, d, dx, None, j > 0)
+        return dx
+
+    def __call__(self, inputs, *args, **kwargs):
+        return self.forward(inputs)
+
+
+class KSACBlock(nn.Module):
+    """Decoder.py:150-176: Conv2DTranspose(3x3, s2) -> concat skip -> KernelSharingConv -> KernelSharingConv.
+
+    As written the block cannot run: ``conv1`` returns a LIST of five tensors, ``tf.convert_to_tensor`` stacks it to
+    [5,N,H,W,C] (:168) and ``conv2`` then reshapes that with N,H,W read from the wrong axes (:241-249), which fails for W > 1; no
+    driver instantiates it.  ``fuse="sum"`` (default) is the executable reading this class offers: the branches of each
+    KernelSharingConv are SUMMED (the fusion of the KSAC paper); ``fuse=None`` reproduces the reference's failure."""
+
+    def __init__(self, out_channels, wDecay=None, *, in_channels=None, skip_channels=None, fuse="sum", as_written=True):
+        super().__init__()
+        oc = out_channels
+        self.wDecay, self.kernel_size, self.out_channels, self.fuse = wDecay, [3, 3], oc, fuse
+        self.in_channels = in_channels if in_channels is not None else oc
+        self.skip_channels = oc if skip_channels is None else skip_channels
+        self.conv1 = KernelSharingConv(oc, self.kernel_size, kernel_regularizer=wDecay, name="KSAC_1", kernel_initializer="HeNormal",
+                                       in_channels=oc + self.skip_channels, as_written=as_written)
+        self.conv2 = KernelSharingConv(oc, self.kernel_size, kernel_regularizer=wDecay, name="KSAC_1", kernel_initializer="HeNormal",
+                                       in_channels=oc, as_written=as_written)
+        self.up = Conv2DTranspose(self.in_channels, oc, 3)
+
+    @staticmethod
+    def _sum(ts):
+        out = ts[0].clone()
+        for t in ts[1:]:
+            ops.copy_channels(t, out, accumulate=True)
+        return out
+
+    def forward(self, x, skip=None):
+        if self.fuse is None:
+            raise ValueError("KSACBlock as written (Decoder.py:168-171) feeds the stacked [5,N,H,W,C] list into a layer that reshapes it as "
+                             "[N,H*W,c]: it cannot run for W > 1; build it with fuse='sum'")
+        B, H, W, _, _ = ops.geom(x)
+        oc = self.out_channels
+        cat = ops.new_act(B, 2 * H, 2 * W, oc + (self.skip_channels if skip is not None else 0), x.device)
+        self.up.forward(x, out=cat[..., :oc])                                         # :163
+        if skip is not None:
+            ops.copy_channels(skip, cat[..., oc:])                                    # :166
+        self._has_skip = skip is not None
+        y = self._sum(self.conv1.forward(cat))                                        # :167 (+ branch fusion)
+        return self._sum(self.conv2.forward(y))                                       # :169
+
+    def backward(self, dout):
+        n = len(self.conv2.dilations)
+        dy = self.conv2.backward([dout] * n)                                          # d(sum)/d(branch) = identity
+        dcat = self.conv1.backward([dy] * n)
+        oc = self.out_channels
+        dx = self.up.backward(dcat[..., :oc])
+        return dx, (dcat[..., oc:] if self._has_skip else None)
+
+    def __call__(self, x, skip=None, *args, **kwargs):
+        return self.forward(x, skip)
