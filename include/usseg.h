@@ -450,6 +450,37 @@ int usseg_augment(const UssegAugDesc* d, const UssegAugSample* samples_dev, cons
 int usseg_reinject_hidden(void* hidden, int64_t numel, int32_t n, void* const* bufs, const int32_t* c0, const int32_t* ld,
                           int32_t backward, usseg_stream_t stream);
 
+/* ---- windowed-attention encoder (SwinTransformer.py: PatchEmbed :341-365, WindowAttention :60-141, SwinTransformerBlock :162-261,
+ * PatchMerging :264-290, GlobalAveragePooling1D :451).  Tokens are NHWC bf16 tensors [B][H][W][C] (the reference's [B, H*W, C]).
+ *
+ * usseg_patchify: x fp32/fp64 [B][H][W][C] -> bf16 [B][H/p][W/p][Cp], channel (ph*p + pw)*C + c (zero pad up to Cp): the
+ *   space-to-depth half of Conv2D(kernel = stride = p); the other half is a 1x1 conv whose kernel is the Keras [p][p][C][E] variable
+ *   read as [p*p*C][E] (same memory).
+ * usseg_patch_merge: merged[b][i][j][(a + 2*bb)*C + c] = full[b][2i+a][2j+bb][c] (:280-284); backward != 0 scatters merged -> full.
+ * usseg_ln_wide_*: LayerNormalization over C <= 4096 channels (C % 8 == 0) of M tokens; backward accumulates dgamma / dbeta
+ *   (ws: >= 2*C floats per workgroup, ws_floats total - more is faster up to 512 workgroups).
+ * usseg_window_attn_*: qkv [B][H][W][3C] (q | k | v, each [heads][C/heads]) -> out [B][H][W][C]; window side ws in {2,4,8}, cyclic
+ *   shift `shift` (0 <= shift < ws) with the -100 region mask of :192-217, relative-position bias table [(2ws-1)^2][heads] (:78-99),
+ *   q scaled by (C/heads)^-0.5.  Backward writes dqkv (same layout as qkv) and ACCUMULATES the table gradient;
+ *   ws_rows: usseg_window_attn_bwd_ws_floats() floats.
+ * usseg_token_mean_*: out[b][c] = mean over the L tokens; backward dx[b][t][c] = dy[b][c] / L. */
+int usseg_patchify(const void* x, int32_t x_is_f64, int32_t B, int32_t H, int32_t W, int32_t C, int32_t patch, void* out, int32_t Cp,
+                   usseg_stream_t stream);
+int usseg_patch_merge(void* full, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldf, void* merged, int32_t ldm, int32_t backward,
+                      usseg_stream_t stream);
+int usseg_ln_wide_fwd(const void* x, int64_t M, int32_t C, int32_t ldx, const float* gamma, const float* beta, float eps, void* y,
+                      int32_t ldy, usseg_stream_t stream);
+int usseg_ln_wide_bwd(const void* x, const void* dy, int64_t M, int32_t C, int32_t ldx, int32_t lddy, const float* gamma, float eps,
+                      void* dx, int32_t lddx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, usseg_stream_t stream);
+int usseg_window_attn_fwd(const void* qkv, int32_t ldq, const float* table, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
+                          int32_t ws, int32_t shift, void* out, int32_t ldo, usseg_stream_t stream);
+int64_t usseg_window_attn_bwd_ws_floats(int32_t B, int32_t H, int32_t W, int32_t heads, int32_t ws);
+int usseg_window_attn_bwd(const void* qkv, int32_t ldq, const void* dout, int32_t ldo, const float* table, int32_t B, int32_t H, int32_t W,
+                          int32_t C, int32_t heads, int32_t ws, int32_t shift, void* dqkv, float* dtable, float* ws_rows,
+                          usseg_stream_t stream);
+int usseg_token_mean_fwd(const void* x, int32_t B, int32_t L, int32_t C, int32_t ld, float* out, usseg_stream_t stream);
+int usseg_token_mean_bwd(const float* dy, int32_t B, int32_t L, int32_t C, int32_t ld, void* dx, usseg_stream_t stream);
+
 /* ---- bias gradient: db[c] += sum_pixels dy[m][c] --------------------------------------------- */
 int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, float* ws, usseg_stream_t stream);
 

@@ -328,8 +328,8 @@ class DecoderCup(nn.Module):
 def ksac_effective_dilations(dilation_rates_list, as_written=True):
     """kernel_sharing_conv2d re-assigns ``value`` inside its loop over the rates (Decoder.py:280-285), so the per-tap shifts
     ACCUMULATE: as written, branch j is a 'same' dilated convolution with dilation d_0 + ... + d_j ((1,2,4,8,16) -> (1,3,7,15,31)).
-    ``as_written=False``: the listed rates (the KSAC paper's intent).  oracle/usseg_oracle.py proves the equivalence against a
-    line-by-line restatement (tests/test_oracle_kat.py)."""
+    ``as_written=False``: the listed rates (the KSAC paper's intent).  The equivalence is proven against a line-by-line
+    restatement of the reference in tests/test_oracle_kat.py."""
     if not as_written:
         return tuple(dilation_rates_list)
     out, acc = [], 0

@@ -153,6 +153,15 @@ _PROTOS = {
     "usseg_label2vec": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "usseg_augment": (C.c_int, [P(AugDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_loss_cat_scale": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_patchify": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    "usseg_patch_merge": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
+    "usseg_ln_wide_fwd": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_i32, c_vp]),
+    "usseg_ln_wide_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "usseg_window_attn_fwd": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    "usseg_window_attn_bwd_ws_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "usseg_window_attn_bwd": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_token_mean_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_token_mean_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "usseg_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "usseg_sumsq": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "usseg_sumsq_advance": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),

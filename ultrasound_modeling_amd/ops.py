@@ -784,3 +784,65 @@ def transpose_batched(src, R, Cc, lds, nb1, nb2, ss, dst):
 def cast_f32_to_bf16_batched(src, R, Cc, nb1, nb2, dst, ldd, ds):
     L.check(L.load().usseg_cast_f32_to_bf16_batched(src.data_ptr(), R, Cc, nb1, nb2, dst.data_ptr(), ldd, ds[0], ds[1], _stream()),
             "cast_f32_to_bf16_batched")
+
+
+# ------------------------------------------------------------------------------------------------ windowed-attention encoder (Swin)
+def patchify(x: torch.Tensor, patch: int) -> torch.Tensor:
+    """fp32/fp64 [B,H,W,C] -> bf16 [B,H/p,W/p,roundup(p*p*C,8)]: the space-to-depth half of Conv2D(kernel = stride = p)."""
+    assert x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, torch.float64)
+    B, H, W, Cc = x.shape
+    Cp = roundup(patch * patch * Cc, 8)
+    out = new_act(B, H // patch, W // patch, Cp, x.device)
+    L.check(L.load().usseg_patchify(x.data_ptr(), 1 if x.dtype == torch.float64 else 0, B, H, W, Cc, patch, out.data_ptr(), Cp, _stream()), "patchify")
+    return out
+
+
+def patch_merge(full, merged, backward=False):
+    """full [B,H,W,C] <-> merged [B,H/2,W/2,4C] in the reference's order x0=(0,0), x1=(1,0), x2=(0,1), x3=(1,1)."""
+    B, H, W, Cc, ldf = geom(full)
+    L.check(L.load().usseg_patch_merge(full.data_ptr(), B, H, W, Cc, ldf, merged.data_ptr(), geom(merged)[4], 1 if backward else 0, _stream()), "patch_merge")
+
+
+def ln_wide_fwd(x, gamma, beta, eps, out):
+    B, H, W, Cc, ldx = geom(x)
+    L.check(L.load().usseg_ln_wide_fwd(x.data_ptr(), B * H * W, Cc, ldx, gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), geom(out)[4], _stream()),
+            "ln_wide_fwd")
+    return out
+
+
+def ln_wide_bwd(x, dy, gamma, eps, dx, dgamma, dbeta):
+    B, H, W, Cc, ldx = geom(x)
+    ws = reduce_ws(x.device)
+    L.check(L.load().usseg_ln_wide_bwd(x.data_ptr(), dy.data_ptr(), B * H * W, Cc, ldx, geom(dy)[4], gamma.data_ptr(), eps, dx.data_ptr(), geom(dx)[4],
+                                       dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ln_wide_bwd")
+    return dx
+
+
+def window_attn_fwd(qkv, table, heads, ws, shift, out):
+    B, H, W, C3, ldq = geom(qkv)
+    L.check(L.load().usseg_window_attn_fwd(qkv.data_ptr(), ldq, table.data_ptr(), B, H, W, C3 // 3, heads, ws, shift, out.data_ptr(), geom(out)[4], _stream()),
+            "window_attn_fwd")
+    return out
+
+
+def window_attn_bwd(qkv, dout, table, heads, ws, shift, dqkv, dtable):
+    B, H, W, C3, ldq = geom(qkv)
+    lib = L.load()
+    rows = torch.empty(int(lib.usseg_window_attn_bwd_ws_floats(B, H, W, heads, ws)), dtype=torch.float32, device=qkv.device)
+    L.check(lib.usseg_window_attn_bwd(qkv.data_ptr(), ldq, dout.data_ptr(), geom(dout)[4], table.data_ptr(), B, H, W, C3 // 3, heads, ws, shift,
+                                      dqkv.data_ptr(), dtable.data_ptr(), rows.data_ptr(), _stream()), "window_attn_bwd")
+    return dqkv
+
+
+def token_mean_fwd(x):
+    B, H, W, Cc, ld = geom(x)
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    L.check(L.load().usseg_token_mean_fwd(x.data_ptr(), B, H * W, Cc, ld, out.data_ptr(), _stream()), "token_mean_fwd")
+    return out
+
+
+def token_mean_bwd(dy, like):
+    B, H, W, Cc, ld = geom(like)
+    dx = torch.empty_like(like)
+    L.check(L.load().usseg_token_mean_bwd(dy.data_ptr(), B, H * W, Cc, ld, dx.data_ptr(), _stream()), "token_mean_bwd")
+    return dx
