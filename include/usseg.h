@@ -298,6 +298,10 @@ int usseg_avgpool2_fwd(const void* x, int32_t B, int32_t H, int32_t W, int32_t C
 /* dx = 0.25 * dy[h/2,w/2] (+ add, bf16 stride ldadd, may be NULL) */
 int usseg_avgpool2_bwd(const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t lddy, int32_t lddx,
                        const void* add, int32_t ldadd, void* dx, usseg_stream_t stream);
+/* avgpool2_bwd that also accumulates db[c] += sum over the pixels of dx: dx is the gradient w.r.t. the output of the conv in front of
+ * the pool (a residual_S stage's concats_2, ResNest.py:98,49-54), so this is that conv's bias gradient.  C <= 512. */
+int usseg_avgpool2_bwd_colsum(const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t lddy, int32_t lddx, const void* add,
+                              int32_t ldadd, void* dx, float* db, float* ws, usseg_stream_t stream);
 
 /* ---- channel-slice copy / accumulate: tf.concat(axis=3) and the raw reshape re-injection
  * (ResNest.py:96; Decoder.py:66,75,87,140-141; TBI_ResNest.py:110-122,139) ---------------------- */

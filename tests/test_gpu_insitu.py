@@ -94,10 +94,10 @@ class Recorder:
             rec.pool.append((x, rec._keep(y)))
             return y
 
-        def split_attention(inputs, P, prefix, radix):
+        def split_attention(inputs, P, prefix, radix, norm="ln"):
             rec.in_sa += 1
             try:
-                y = o["split_attention"](inputs, P, prefix, radix)
+                y = o["split_attention"](inputs, P, prefix, radix, norm)
             finally:
                 rec.in_sa -= 1
             rec.sa[prefix] = (inputs[0], rec._keep(y))

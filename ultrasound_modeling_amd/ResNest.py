@@ -292,8 +292,9 @@ class residual_S(nn.Module):
         sc = self.convtmp_scbn.forward(sc_raw, ACT_LRELU, KERAS_LRELU_ALPHA)                        # :100-101
         return self.concats_2.forward(concats_1, out=out, residual=sc)                               # :98,:102
 
-    def backward(self, dout, need_dx=True):
-        d_c1 = self.concats_2.backward(dout)
+    def backward(self, dout, need_dx=True, bias_done=False):
+        """``bias_done``: concats_2's bias gradient (the column sums of dout) was already produced by the kernel that made dout."""
+        d_c1 = self.concats_2.backward(dout, skip_bias=bias_done)
         dsc_raw = self.convtmp_scbn.backward(dout, dbias=self.convtmp_sc.bias.grad)
         dx_a = self._group.backward(d_c1)
         return self.convtmp_sc.backward(dsc_raw, need_dx=need_dx, dx_residual=dx_a, skip_bias=True)
@@ -364,13 +365,14 @@ class ResNest(nn.Module):
     def backward(self, d_x4, d_feats):
         """Gradients w.r.t. (x_4, [x_3, x_2, x_1]) -> accumulates all parameter gradients (input gradient not needed)."""
         d_x3, d_x2, d_x1 = d_feats
+        # the pool backward in front of a stage also sums its output over the pixels: that stage's concats_2 bias gradient
         d = self.conv_4.backward(d_x4)
-        d = self.conv4_pool.backward(d, add=d_x3)
-        d = self.conv_3.backward(d)
-        d = self.conv3_pool.backward(d, add=d_x2)
-        d = self.conv_2.backward(d)
-        d = self.conv2_pool.backward(d, add=d_x1)
-        d = self.conv_1.backward(d)
+        d = self.conv4_pool.backward(d, add=d_x3, db=self.conv_3.concats_2.bias.grad)
+        d = self.conv_3.backward(d, bias_done=True)
+        d = self.conv3_pool.backward(d, add=d_x2, db=self.conv_2.concats_2.bias.grad)
+        d = self.conv_2.backward(d, bias_done=True)
+        d = self.conv2_pool.backward(d, add=d_x1, db=self.conv_1.concats_2.bias.grad)
+        d = self.conv_1.backward(d, bias_done=True)
         a = KERAS_LRELU_ALPHA
         if self._pool_fused:
             d = self.convtmp_2bn.backward_pool(d, dbias=self.convtmp_2.bias.grad)

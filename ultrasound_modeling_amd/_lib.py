@@ -127,6 +127,7 @@ _PROTOS = {
     "usseg_act_bwd_colsum": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "usseg_avgpool2_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "usseg_avgpool2_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "usseg_avgpool2_bwd_colsum": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "usseg_copy_channels": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "usseg_cast_input": (C.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_vp]),
     "usseg_cast_bf16_to_f32": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),

@@ -458,12 +458,12 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const NormParams p, in
   for (int64_t base = (int64_t)blockIdx.x * ppb; base < p.M; base += (int64_t)gridDim.x * ppb) {
     const int64_t m = base + wv * ppw + slot;          // pooled pixel
     const bool valid = chunk_ok && m < p.M;
-    const int64_t mc = valid ? m : 0;
-    const int ox = (int)(mc % Wo);
-    const int64_t t = mc / Wo;
-    const int oy = (int)(t % Ho);
-    const int64_t b = t / Ho;
-    const int64_t pi = ((b * 2 * Ho + 2 * oy) * Wi + 2 * ox);
+    const uint32_t mc = valid ? (uint32_t)m : 0u;      // 32-bit decode (the launcher checks M < 2^31): 64-bit div / mod cost ~100 cycles each
+    const uint32_t t = mc / (uint32_t)Wo;
+    const int ox = (int)(mc - t * (uint32_t)Wo);
+    const uint32_t b = t / (uint32_t)Ho;
+    const int oy = (int)(t - b * (uint32_t)Ho);
+    const int64_t pi = (((int64_t)b * 2 * Ho + 2 * oy) * Wi + 2 * ox);
     const int64_t sub[4] = {pi, pi + 1, pi + Wi, pi + Wi + 1};
     uint4 raw[4];
 #pragma unroll
@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const NormParams p, in
 static int bn_pool_common(NormParams& p, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cphys, const float* gamma, const float* beta,
                           const float* mean, const float* var, float eps, int32_t act, float alpha) {
   USSEG_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && Cphys % 8 == 0 && Cphys >= C && Cphys <= 512, "bn_act_pool: bad geometry");
+  USSEG_CHECK_ARG((int64_t)B * H * W < (1ll << 31), "bn_act_pool: more than 2^31 pixels");
   USSEG_CHECK_ARG(gamma && beta && mean && var && ((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0,
                   "bn_act_pool: channel vectors must be 16-byte aligned");
   p.M = (int64_t)B * (H / 2) * (W / 2); p.C = C; p.Cphys = Cphys; p.G = 1; p.Cg = C; p.mode = 1; p.act = act; p.eps = eps; p.alpha = alpha;
@@ -547,7 +548,7 @@ extern "C" int usseg_bn_act_pool_bwd(const void* x, const void* dy, int32_t B, i
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.ldx = ldx; p.lddy = lddy; p.lddx = lddx;
   p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
   const int ppb = 4 * (64 / p.LPP);
-  unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
+  unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);     // (4096 one-item workgroups measured 104 us against 58 us: the three block reductions dominate)
   p.ws = ws = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * 3 * p.Cphys);
   hipLaunchKernelGGL(bn_act_pool_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, H / 2, W / 2);
   usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
@@ -746,6 +747,61 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16_t* dy, int
     *reinterpret_cast<uint4*>(dx + pix * lddx + c0) = pack8(v);
   }
 }
+// avgpool2 backward (+ skip-connection gradient `add`) that also yields the column sums of its output: dx of the pool behind a
+// residual_S stage is the gradient w.r.t. that stage's concats_2 output, whose sum over the pixels is concats_2's bias gradient
+// (ResNest.py:98,49-54) - one pass instead of avgpool2_bwd + colsum.  Sums the STORED (bf16) values, as colsum would.
+__global__ __launch_bounds__(256) void avgpool2_bwd_colsum_kernel(const bf16_t* dy, int B, int H, int W, int C, int lddy, int lddx, const bf16_t* add,
+                                                                   int ldadd, int LPP, bf16_t* dx, float* ws) {
+  __shared__ float s_red[4 * 512];
+  const int Cp = (C + 7) & ~7;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ppw = 64 / LPP, chunk = lane & (LPP - 1), slot = lane / LPP;
+  const bool chunk_ok = chunk * 8 < C;
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t M = (int64_t)B * H * W;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int64_t ppb = 4 * ppw;
+  for (int64_t base = (int64_t)blockIdx.x * ppb; base < M; base += (int64_t)gridDim.x * ppb) {
+    const int64_t pix = base + wv * ppw + slot;
+    if (chunk_ok && pix < M) {
+      const int x_ = (int)(pix % W);
+      const int64_t t = pix / W;
+      const int y_ = (int)(t % H);
+      const int64_t b = t / H;
+      float v[8], r8[8];
+      unpack8(*reinterpret_cast<const uint4*>(dy + ((b * Ho + (y_ >> 1)) * Wo + (x_ >> 1)) * lddy + chunk * 8), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= 0.25f;
+      if (add) {
+        float a[8];
+        unpack8(*reinterpret_cast<const uint4*>(add + pix * ldadd + chunk * 8), a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += a[j];
+      }
+      const uint4 o = pack8(v);
+      *reinterpret_cast<uint4*>(dx + pix * lddx + chunk * 8) = o;
+      unpack8(o, r8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += r8[j];
+    }
+  }
+  block_chunk_partial(s, LPP, chunk, chunk_ok, ws + (int64_t)blockIdx.x * Cp, Cp, s_red);
+}
+extern "C" int usseg_avgpool2_bwd_colsum(const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t lddy, int32_t lddx, const void* add,
+                                         int32_t ldadd, void* dx, float* db, float* ws, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dy && dx && db && ws && H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && C <= 512 && lddy % 8 == 0 && lddx % 8 == 0, "avgpool2_bwd_colsum: bad args");
+  const int64_t M = (int64_t)B * H * W;
+  if (M <= 0) return USSEG_OK;
+  const int LPP = lanes_per_pixel(C / 8);
+  const int ppb = 4 * (64 / LPP);
+  unsigned grid = grid_for(M, ppb * 4, USSEG_REDUCE_MAX_BLOCKS);
+  float* wsr = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * C);
+  hipLaunchKernelGGL(avgpool2_bwd_colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, B, H, W, C, lddy, lddx,
+                     (const bf16_t*)add, ldadd, LPP, (bf16_t*)dx, wsr);
+  usseg_launch_reduce_finish(wsr, 1, (int)grid, 1, C, C, 1.f, db, nullptr, nullptr, (hipStream_t)stream);
+  return usseg_check_launch("avgpool2_bwd_colsum");
+}
+
 extern "C" int usseg_avgpool2_fwd(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy, void* y,
                                   usseg_stream_t stream) {
   USSEG_CHECK_ARG(x && y && H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "avgpool2_fwd: bad args");

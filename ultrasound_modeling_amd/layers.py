@@ -85,10 +85,11 @@ class AveragePooling2D(nn.Module):
         self._shape = (B, H, W, C)
         return ops.avgpool2_fwd(x, out)
 
-    def backward(self, dy, add=None, dx=None):
+    def backward(self, dy, add=None, dx=None, db=None):
+        """``db``: optional bias-gradient vector of the conv whose output this pool consumed (column sums of dx, same pass)."""
         B, H, W, C = self._shape
         dx = dx if dx is not None else ops.new_act(B, H, W, C, dy.device)
-        return ops.avgpool2_bwd(dy, dx, add)
+        return ops.avgpool2_bwd(dy, dx, add, db)
 
 
 # ------------------------------------------------------------------------------------------------ convolutions

@@ -543,9 +543,14 @@ def avgpool2_fwd(x, out):
     return out
 
 
-def avgpool2_bwd(dy, dx, add=None):
+def avgpool2_bwd(dy, dx, add=None, db=None):
+    """``db``: optional fp32 vector that receives the column sums of dx (the bias gradient of the conv in front of the pool)."""
     B, H, W, Cc, lddx = geom(dx)
     ldadd = geom(add)[4] if add is not None else 0
+    if db is not None and Cc <= 512:
+        L.check(L.load().usseg_avgpool2_bwd_colsum(dy.data_ptr(), B, H, W, Cc, geom(dy)[4], lddx, _ptr(add), ldadd, dx.data_ptr(), db.data_ptr(),
+                                                   reduce_ws(dx.device).data_ptr(), _stream()), "avgpool2_bwd_colsum")
+        return dx
     L.check(L.load().usseg_avgpool2_bwd(dy.data_ptr(), B, H, W, Cc, geom(dy)[4], lddx, _ptr(add), ldadd, dx.data_ptr(),
                                         _stream()), "avgpool2_bwd")
     return dx
