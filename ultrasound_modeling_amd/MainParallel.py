@@ -74,9 +74,11 @@ class GradSync:
 class MirroredTrainer:
     """Wraps a model that has ``flat`` (FlatParams), ``grad_sync`` and ``train_step`` (VisionTransformer / Arch A).
 
-    ``chunks``: pieces the gradient exchange is pipelined in (None = 1 below 48 MB of gradients, 4 above: Arch A's 103 MB and
-    the ViT model's 126 MB hide their Adam kernels under the wire time; the 25 MB conv-only Arch B keeps one collective and
-    a graph-replayed update)."""
+    ``chunks``: pieces the gradient exchange is pipelined in (None / 1 = ONE collective and a graph-replayed update - the default;
+    k > 1 = k pieces with the Adam kernel of piece i under the wire time of piece i+1, see GradSync).  Measured on one GPU
+    (RCCL group of one rank, so no wire time to hide): the chunked form's eagerly launched update costs Arch A +0.2 ms per step
+    (7.88 vs 7.68 ms) against at most 0.12 ms of Adam time it could hide behind a 103 MB all-reduce - so it stays opt-in
+    (``USSEG_DP_CHUNKS`` / ``bench.py --dp-chunks``) until it can be measured on an 8-GPU node."""
 
     def __init__(self, net, group=None, force: bool = False, chunks: Optional[int] = None):
         self.net, self.group = net, group
@@ -91,7 +93,7 @@ class MirroredTrainer:
             if hasattr(net, "repack"):
                 net.repack()
             if chunks is None:
-                chunks = int(os.environ.get("USSEG_DP_CHUNKS", "0")) or (4 if net.flat.flat.numel() * 4 > (48 << 20) else 1)
+                chunks = int(os.environ.get("USSEG_DP_CHUNKS", "0")) or 1
             net.grad_sync = GradSync(group, chunks)
 
     def train_step(self, x_local, y_local):
