@@ -192,6 +192,9 @@ typedef struct UssegPackJob {
   void* dst;
   int64_t sT, sN, sK;
   int32_t T, Nn, Kk, Kw, tap_stride, n_off, k_off, reserved;
+  const float* nscale; /* optional fp32 multiplier per row n (NULL = none): an inference BatchNormalization folded into the
+                          FORWARD operand, W'[n][..] = W[n][..] * gamma[n]*rsqrt(var[n]+eps) (the conv then runs its plain
+                          bias + activation epilogue with bias' = beta - mean*scale + scale*bias) */
 } UssegPackJob;
 int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t njobs, usseg_stream_t stream);
 int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t Ncols, int32_t T, int32_t Nn, int32_t Kk,

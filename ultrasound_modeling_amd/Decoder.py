@@ -22,7 +22,10 @@ from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 
 _FUSED_DGRAD = os.environ.get("USSEG_FUSED_DGRAD", "1") != "0"
 _QUAD_UP = os.environ.get("USSEG_QUAD_UP", "0") != "0"
-_FOLD_BN = os.environ.get("USSEG_FOLD_BN", "0") != "0"   # built and parity-tested; measured neutral on the step (4.98 vs 4.99 ms), so off by default
+# Inference-mode BatchNorm folded into the producing conv: its scale goes into the PACKED forward operand (W' = W*gamma*rstd per output
+# channel), its shift replaces the bias, LeakyReLU rides in the plain epilogue - no norm launch and no pre-norm tensor in the forward
+# pass; the backward pass recovers what it needs from the activated output (norm backward mode 2).
+_FOLD_BN = os.environ.get("USSEG_FOLD_BN", "1") != "0"
 
 
 class DecoderBlock(nn.Module):
@@ -85,9 +88,15 @@ class DecoderBlock(nn.Module):
             self._wd_cat[st] = torch.zeros((roundup(cin_p, 16), 28 * q), dtype=BF16, device=device)
         if self._qup is not None:
             self._qup.on_finalize(device)
-        ops.pack_weights_batched(ops.make_pack_table(self.pack_jobs(), device), len(self.pack_jobs()))
         jobs = self.bn_fold_jobs()
         ops.bn_fold_batched(ops.make_bn_fold_table(jobs, device), len(jobs))
+        if _FOLD_BN:     # the branch convs pack their forward operands with the folded scale (their own on_finalize / repack_all run after this)
+            for st in ("1", "2"):
+                for j in range(4):
+                    cv = getattr(self, f"conv{st}_{j}")
+                    cv._fold_scale = self._bn[st]["fscale"][j * q:(j + 1) * q]
+                    cv._fold_bns = [getattr(self, f"bn{s2}_{jj}") for s2 in ("1", "2") for jj in range(4)]    # the block folds as a whole
+        ops.pack_weights_batched(ops.make_pack_table(self.pack_jobs(), device), len(self.pack_jobs()))
 
     def bn_fold_jobs(self):
         """One folded inference BatchNorm per stage (its four branch BNs are adjacent vectors): scale/shift for the conv epilogues."""
@@ -128,8 +137,8 @@ class DecoderBlock(nn.Module):
         convs = [getattr(self, f"conv{st}_{j}") for j in range(4)]
         b = self._bn[st]
         sl = lambda t, j: t[j * q:(j + 1) * q]
-        if self._fold:
-            convs[0].forward(x, out=raw[..., :q], act=ACT_LRELU, alpha=KERAS_LRELU_ALPHA, scale=sl(b["fscale"], 0), shift=sl(b["fshift"], 0))
+        if self._fold:      # the scale is inside wp_f (pack time); the shift is the bias; LeakyReLU in the plain epilogue
+            convs[0].forward(x, out=raw[..., :q], act=ACT_LRELU, alpha=KERAS_LRELU_ALPHA, bias=sl(b["fshift"], 0))
         else:
             convs[0].forward(x, out=raw[..., :q])
         jobs = []
@@ -137,7 +146,7 @@ class DecoderBlock(nn.Module):
             c = convs[j]
             c._x = x
             if self._fold:
-                jobs.append((x, c.wp_f, sl(b["fshift"], j), c.k, c.dil, raw[..., j * q:(j + 1) * q], ACT_LRELU, KERAS_LRELU_ALPHA, sl(b["fscale"], j)))
+                jobs.append((x, c.wp_f, sl(b["fshift"], j), c.k, c.dil, raw[..., j * q:(j + 1) * q], ACT_LRELU, KERAS_LRELU_ALPHA))
             else:
                 jobs.append((x, c.wp_f, c.bias.data, c.k, c.dil, raw[..., j * q:(j + 1) * q], ACT_NONE, 0.0))
         ops.conv2d_fwd_multi(jobs)
@@ -182,7 +191,7 @@ class DecoderBlock(nn.Module):
             self.up.forward(x, out=cat[..., :oc])                                     # :63
         if has_skip and not in_place:
             ops.copy_channels(skip, cat[..., oc:])                                    # :66
-        self._fold = _FOLD_BN and not any(getattr(self, f"bn{st}_{j}").training_mode for st in ("1", "2") for j in range(4))
+        self._fold = self.conv1_0.fold_scale() is not None and self.conv2_0.fold_scale() is not None     # both stages in inference mode
         out = out if out is not None else ops.new_act(B, 2 * H, 2 * W, oc, dev)
         if self._fold:   # :67-76, :79-88 with BN + LeakyReLU in the conv epilogues: no pre-norm tensors, no norm launches
             act1 = ops.new_act(B, 2 * H, 2 * W, oc, dev)

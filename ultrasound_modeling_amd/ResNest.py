@@ -29,7 +29,9 @@ from .layers import (KERAS_LN_EPS, KERAS_LRELU_ALPHA, AveragePooling2D, BatchNor
 from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 
 
-_FOLD_BN = os.environ.get("USSEG_FOLD_BN", "0") != "0"   # built and parity-tested; measured neutral on the step (4.98 vs 4.99 ms), so off by default
+# see Decoder._FOLD_BN: convtmp_1bn's scale is folded into convtmp_1's packed forward operand (convtmp_2bn stays unfolded: it is
+# already fused with the pool that follows it)
+_FOLD_BN = os.environ.get("USSEG_FOLD_BN", "1") != "0"
 
 
 def _span(t: torch.Tensor, n: int) -> torch.Tensor:
@@ -340,22 +342,19 @@ class ResNest(nn.Module):
         a = KERAS_LRELU_ALPHA
         self._y1 = self.conv1.forward(x, act=ACT_LRELU, alpha=a)                                  # :39-40
         bn1, bn2 = self.convtmp_1bn, self.convtmp_2bn
-        self._fold = _FOLD_BN and not (bn1.training_mode or bn2.training_mode)
+        self._fold = self.convtmp_1.fold_scale() is not None
         self._pool_fused = False
-        if self._fold:   # inference-mode BN + LeakyReLU ride in the conv epilogue: the pre-norm tensors are never written
-            self._t1 = t = self.convtmp_1.forward(self._y1, act=ACT_LRELU, alpha=a, scale=bn1.fold_scale, shift=bn1.fold_shift)   # :41-43
-            self._t2 = t = self.convtmp_2.forward(t, act=ACT_LRELU, alpha=a, scale=bn2.fold_scale, shift=bn2.fold_shift)          # :44-46
+        if self._fold:   # :41-43: convtmp_1bn's scale sits in the packed operand, its shift is the bias, LeakyReLU in the epilogue
+            self._t1 = t = self.convtmp_1.forward(self._y1, act=ACT_LRELU, alpha=a, bias=bn1.fold_shift)
         else:
             t = self.convtmp_1.forward(self._y1)                                                 # :41
             t = self.convtmp_1bn.forward(t, ACT_LRELU, a)                                        # :42-43
-            t = self.convtmp_2.forward(t)                                                        # :44
-            self._pool_fused = not bn2.training_mode
-            if self._pool_fused:    # :45-47 in one pass: the activated 256x256 tensor feeds the pool only and is never written
-                t = self.convtmp_2bn.forward_pool(t, ACT_LRELU, a)
-            else:
-                t = self.convtmp_2bn.forward(t, ACT_LRELU, a)                                    # :45-46
-        if self._fold or not self._pool_fused:
-            t = self.conv1_pool.forward(t)                                                       # :47
+        t = self.convtmp_2.forward(t)                                                            # :44
+        self._pool_fused = not bn2.training_mode
+        if self._pool_fused:    # :45-47 in one pass: the activated 256x256 tensor feeds the pool only and is never written
+            t = self.convtmp_2bn.forward_pool(t, ACT_LRELU, a)
+        else:
+            t = self.conv1_pool.forward(self.convtmp_2bn.forward(t, ACT_LRELU, a))               # :45-47
         x_1 = self.conv_1.forward(t, out=o1)                                                     # :48
         x_2 = self.conv_2.forward(self.conv2_pool.forward(x_1), out=o2)                          # :49-50
         x_3 = self.conv_3.forward(self.conv3_pool.forward(x_2), out=o3)                          # :51-52
@@ -376,8 +375,6 @@ class ResNest(nn.Module):
         a = KERAS_LRELU_ALPHA
         if self._pool_fused:
             d = self.convtmp_2bn.backward_pool(d, dbias=self.convtmp_2.bias.grad)
-        elif self._fold:
-            d = self.convtmp_2bn.backward_folded(self._t2, self.conv1_pool.backward(d), ACT_LRELU, a, dbias=self.convtmp_2.bias.grad)
         else:
             d = self.convtmp_2bn.backward(self.conv1_pool.backward(d), dbias=self.convtmp_2.bias.grad)
         d = self.convtmp_2.backward(d, skip_bias=True)
@@ -399,6 +396,9 @@ class ResNest(nn.Module):
             jobs = self.bn_fold_jobs()
             self._fold_table = (ops.make_bn_fold_table(jobs, device), len(jobs))
         ops.bn_fold_batched(*self._fold_table)
+        if _FOLD_BN:    # convtmp_1 packs its forward operand with convtmp_1bn's scale (its own on_finalize / repack_all run after this)
+            self.convtmp_1._fold_scale = self.convtmp_1bn.fold_scale
+            self.convtmp_1._fold_bns = [self.convtmp_1bn]
 
     def repack(self):
         for m in self.modules():

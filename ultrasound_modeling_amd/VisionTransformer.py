@@ -54,9 +54,9 @@ def repack_all(root: nn.Module):
                 folds += m.bn_fold_jobs()
         table = (ops.make_pack_table(jobs, dev), len(jobs), ops.make_bn_fold_table(folds, dev) if folds else None, len(folds))
         object.__setattr__(root, "_pack_table", table)
-    ops.pack_weights_batched(table[0], table[1])
     if table[3] and (_DEC._FOLD_BN or _ENC._FOLD_BN):
-        ops.bn_fold_batched(table[2], table[3])     # folded inference BatchNorm constants of the conv epilogues (USSEG_FOLD_BN=1 only)
+        ops.bn_fold_batched(table[2], table[3])     # folded inference BatchNorm constants FIRST: the packs below multiply them in
+    ops.pack_weights_batched(table[0], table[1])
 
 
 class Embeddings(nn.Module):

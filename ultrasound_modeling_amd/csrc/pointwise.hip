@@ -206,13 +206,13 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
     } else {
       // MODE 2 (backward only): x is the ACTIVATED output y of a conv whose epilogue applied the folded affine + activation
       // (usseg_conv2d_fwd_affine); the pre-activation and the normalised value are recovered from it (gamma != 0)
-      const float inv_alpha = p.alpha != 0.f ? 1.f / p.alpha : 0.f;
+      // (LeakyReLU / ReLU / none only - checked by the launcher: an ELU inverse (log1p) in this kernel costs the registers that
+      // take it from 4 to 3 waves per SIMD, 1.34x slower on every launch)
+      const float inv_neg = (p.act == USSEG_ACT_LRELU && p.alpha != 0.f) ? 1.f / p.alpha : 1.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float y = xv[j], pre = y;
-        if (p.act == USSEG_ACT_LRELU) pre = y >= 0.f ? y : y * inv_alpha;
-        else if (p.act == USSEG_ACT_ELU) pre = y > 0.f ? y : log1pf(y * inv_alpha);
-        xh[j] = (pre - be[j]) * mu_c[j];
+        const float y = xv[j];
+        xh[j] = ((y >= 0.f ? y : y * inv_neg) - be[j]) * mu_c[j];
       }
     }
 
@@ -251,13 +251,26 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
         for (int j = 0; j < 8; ++j) dyv[j] *= mk[j];
       }
       float dxh[8];
+      if (MODE == 2) {
+        // the activation's slope follows from the sign of the ACTIVATED value itself: one uniform branch for the 8 elements, no
+        // pre-activation rebuilt through act_grad's per-element switch (this path was 1.4x slower than mode 1 with it)
+        const float neg = p.act == USSEG_ACT_LRELU ? p.alpha : (p.act == USSEG_ACT_RELU ? 0.f : 1.f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float pre = ga[j] * xh[j] + be[j];
-        float dh = okf[j] * dyv[j] * act_grad(pre, p.act, p.alpha);
-        dga[j] = fmaf(dh, xh[j], dga[j]);
-        dbe[j] += dh;
-        dxh[j] = dh * ga[j];
+        for (int j = 0; j < 8; ++j) {
+          const float dh = okf[j] * dyv[j] * (xv[j] > 0.f ? 1.f : neg);
+          dga[j] = fmaf(dh, xh[j], dga[j]);
+          dbe[j] += dh;
+          dxh[j] = dh * ga[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float pre = ga[j] * xh[j] + be[j];
+          float dh = okf[j] * dyv[j] * act_grad(pre, p.act, p.alpha);
+          dga[j] = fmaf(dh, xh[j], dga[j]);
+          dbe[j] += dh;
+          dxh[j] = dh * ga[j];
+        }
       }
       float o[8];
       if (MODE == 0) {
@@ -360,6 +373,8 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   if (rc) return rc;
   USSEG_CHECK_ARG(x && dy && dx && gamma && beta && dgamma && dbeta && ws && (d->mode == 0 || (mean && var)), "norm bwd: null pointer");
   USSEG_CHECK_ARG(d->mode != 2 || !mask, "norm bwd mode 2 does not take a dropout mask");
+  USSEG_CHECK_ARG(d->mode != 2 || d->act == USSEG_ACT_LRELU || d->act == USSEG_ACT_RELU || d->act == USSEG_ACT_NONE,
+                  "norm bwd mode 2 (from the activated output) supports LeakyReLU / ReLU / no activation");
   USSEG_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)mean) | ((uintptr_t)var)) & 15) == 0,
                   "norm: gamma/beta/mean/var must be 16-byte aligned (and readable up to Cphys floats)");
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.gamma = gamma; p.beta = beta; p.mean = mean; p.var = var;
@@ -1024,7 +1039,10 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const UssegPa
     for (int i = 0; i < 4; ++i) {
       const int nn = k_fast ? ly + 8 * i : lx, kk = k_fast ? lx : ly + 8 * i;
       float v = 0.f;
-      if (n0 + nn < j.Nn && k0 + kk < j.Kk) v = j.src[(int64_t)t * j.sT + (int64_t)(n0 + nn) * j.sN + (int64_t)(k0 + kk) * j.sK];
+      if (n0 + nn < j.Nn && k0 + kk < j.Kk) {
+        v = j.src[(int64_t)t * j.sT + (int64_t)(n0 + nn) * j.sN + (int64_t)(k0 + kk) * j.sK];
+        if (j.nscale) v *= j.nscale[n0 + nn];      // folded inference BatchNorm (forward operand only)
+      }
       tile[nn][kk] = v;
     }
     __syncthreads();

@@ -132,8 +132,9 @@ class Conv2D(nn.Module):
         T = self.k * self.k
         sT, sI, sO = self._strides_tio()
         return [
-            # forward: rows n = out channel, K = tap*cin_p + ci
-            ops.pack_job(self.kernel.data, sT, sO, sI, T, self.cout, self.cin, self.wp_f, T * self.cin_p, self.cin_p),
+            # forward: rows n = out channel, K = tap*cin_p + ci (times the folded BatchNorm scale of that channel, if any)
+            ops.pack_job(self.kernel.data, sT, sO, sI, T, self.cout, self.cin, self.wp_f, T * self.cin_p, self.cin_p,
+                         nscale=self.fold_scale()),
             # dgrad: rows n = in channel, K = tap*cout_p + co
             ops.pack_job(self.kernel.data, sT, sI, sO, T, self.cin, self.cout, self.wp_d, T * self.cout_p, self.cout_p)]
 
@@ -141,8 +142,20 @@ class Conv2D(nn.Module):
         jobs = self.pack_jobs()
         ops.pack_weights_batched(ops.make_pack_table(jobs, self.wp_f.device), len(jobs))
 
-    def forward(self, x, out=None, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False, use_bias=True, scale=None, shift=None):
-        """``scale`` / ``shift``: a folded inference BatchNormalization (y = act(scale*conv + shift); ``shift`` holds the bias)."""
+    def fold_scale(self):
+        """The per-output-channel multiplier folded into the packed FORWARD operand (an inference BatchNormalization that follows
+        this conv), or None.  The owner sets ``_fold_scale`` (a device vector kept up to date by usseg_bn_fold_batched) and
+        ``_fold_bns`` (the layers it comes from: folding is only valid while they are in inference mode; toggling
+        ``training_mode`` needs a ``repack()``)."""
+        sc = getattr(self, "_fold_scale", None)
+        if sc is None or any(b.training_mode for b in getattr(self, "_fold_bns", ())):
+            return None
+        return sc
+
+    def forward(self, x, out=None, act=ACT_NONE, alpha=0.0, residual=None, out_f32=False, use_bias=True, scale=None, shift=None, bias=None):
+        """``scale`` / ``shift``: a folded inference BatchNormalization applied in the epilogue (y = act(scale*conv + shift); ``shift``
+        holds the bias).  ``bias``: replaces the layer's own bias vector (a BatchNorm folded into the packed operand brings its
+        own shift: ``_fold_scale`` + ``bias=fold_shift``)."""
         B, H, W, C, _ = ops.geom(x)
         assert C == self.cin_p, f"expected {self.cin_p} physical input channels, got {C}"
         if out is None:
@@ -151,7 +164,8 @@ class Conv2D(nn.Module):
         self._x = x
         if scale is not None:
             return ops.conv2d_fwd(x, self.wp_f, shift, self.k, self.dil, out, act, alpha, residual, out_f32, scale=scale)
-        return ops.conv2d_fwd(x, self.wp_f, self.bias.data if use_bias else None, self.k, self.dil, out, act, alpha, residual, out_f32)
+        b = bias if bias is not None else (self.bias.data if use_bias else None)
+        return ops.conv2d_fwd(x, self.wp_f, b, self.k, self.dil, out, act, alpha, residual, out_f32)
 
     def wgrad_job(self, dy):
         """(x, dy, k, dilation, dw, dst_map) for ops.conv2d_wgrad_multi."""

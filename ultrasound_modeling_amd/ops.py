@@ -359,13 +359,15 @@ def pack_weight(src: torch.Tensor, sT, sN, sK, T, Nn, Kk, dst: torch.Tensor, Kw,
 
 
 PACK_JOB_DTYPE = [("src", "<u8"), ("dst", "<u8"), ("sT", "<i8"), ("sN", "<i8"), ("sK", "<i8"), ("T", "<i4"), ("Nn", "<i4"), ("Kk", "<i4"),
-                  ("Kw", "<i4"), ("tap_stride", "<i4"), ("n_off", "<i4"), ("k_off", "<i4"), ("reserved", "<i4")]
+                  ("Kw", "<i4"), ("tap_stride", "<i4"), ("n_off", "<i4"), ("k_off", "<i4"), ("reserved", "<i4"), ("nscale", "<u8")]
 
 
-def pack_job(src, sT, sN, sK, T, Nn, Kk, dst, Kw, tap_stride, n_off=0, k_off=0):
-    """Descriptor tuple of one pack (same arguments as pack_weight) for pack_weights_batched."""
+def pack_job(src, sT, sN, sK, T, Nn, Kk, dst, Kw, tap_stride, n_off=0, k_off=0, nscale=None):
+    """Descriptor tuple of one pack (same arguments as pack_weight) for pack_weights_batched.  ``nscale``: optional fp32 vector,
+    one multiplier per row n (an inference BatchNorm folded into the forward operand)."""
     assert src.dtype == torch.float32 and dst.dtype == BF16
-    return (src.data_ptr(), dst.data_ptr(), sT, sN, sK, T, Nn, Kk, Kw, tap_stride, n_off, k_off, 0)
+    assert nscale is None or (nscale.dtype == torch.float32 and nscale.numel() >= Nn)
+    return (src.data_ptr(), dst.data_ptr(), sT, sN, sK, T, Nn, Kk, Kw, tap_stride, n_off, k_off, 0, 0 if nscale is None else nscale.data_ptr())
 
 
 def make_pack_table(jobs, device) -> torch.Tensor:
