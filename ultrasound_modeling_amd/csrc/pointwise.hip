@@ -46,6 +46,9 @@ __device__ __forceinline__ void block_chunk_partial(float* acc8, int LPP, int ch
 extern "C" int64_t usseg_reduce_ws_floats(void) { return (int64_t)USSEG_REDUCE_MAX_BLOCKS * 3 * 512; }
 
 // ------------------------------------------------------------------------------------------ norm + act
+#ifndef NORM_OCC_G3
+#define NORM_OCC_G3 1   /* 3 waves (162-168 VGPRs) measured no faster on the latency-bound per-group LayerNorm launches, +7 us with the 24-byte spill of the fused variant */
+#endif
 struct NormParams {
   const bf16_t* x; const bf16_t* dy; bf16_t* y; bf16_t* dx;
   const float *gamma, *beta, *mean, *var;
@@ -61,6 +64,8 @@ struct NormParams {
   //   backward: the incoming gradient is dout*sa_s[b][c] + sa_dg[b][c] (the re-weighting's backward, ResNest.py:194-197 with
   //             identical radix branches), formed in registers instead of by a separate pass over the tensor.
   int64_t HW;
+  int32_t pool_ws, pool_hs;  // log2 of pool_w / pool_h when BOTH are powers of two, else -1
+  int32_t pool_w, pool_h;   // POOL (backward): dy is the gradient of the 2x2-average-POOLED output [B][pool_h/2][pool_w/2]; x / dx are [B][pool_h][pool_w]
   float* gap_ws;
   const float *sa_s, *sa_dg;
   int32_t sa_cy;
@@ -71,8 +76,17 @@ struct NormParams {
 // NG = 1 is the plain LayerNormalization (no group bookkeeping at all); NG = 4 handles up to four groups with 0/1
 // membership masks folded into FMAs (the cardinal paths' LN: 3 groups of 3..85 channels, not aligned to the 8-channel
 // chunks - per-element compare/select chains made that form VALU bound at ~1 TB/s).
-template <bool BWD, int MODE, int NG, bool FUSE = false>
-__global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
+// Waves per SIMD the register allocator is held to (measured: a variant two registers over a boundary runs 1.3-1.6x slower, and
+// the allocator finds the smaller allocation without spilling when asked).
+constexpr int norm_occ(bool bwd, int mode, int ng, bool fuse, bool pool) {
+  if (!bwd) return ng >= 4 ? 2 : (ng == 3 ? 4 : 1);
+  if (ng >= 4) return 2;
+  if (ng == 3) return NORM_OCC_G3;
+  return 4;
+}
+// (POOL sits at 130 VGPRs without the bound: two registers over the four-waves-per-SIMD line, 1.6x slower)
+template <bool BWD, int MODE, int NG, bool FUSE = false, bool POOL = false>
+__global__ __launch_bounds__(256, norm_occ(BWD, MODE, NG, FUSE, POOL)) void norm_act_kernel(const NormParams p) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int LPP = p.LPP, ppw = 64 / LPP;
   const int chunk = lane & (LPP - 1), slot = lane / LPP;
@@ -139,10 +153,27 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const NormParams p) {
     uint4 rawx = make_uint4(0, 0, 0, 0), rawd = make_uint4(0, 0, 0, 0);
     if (valid) {
       rawx = *reinterpret_cast<const uint4*>(p.x + m * p.ldx + c0);
-      if (BWD) rawd = *reinterpret_cast<const uint4*>(p.dy + m * p.lddy + c0);
+      if (BWD && !POOL) rawd = *reinterpret_cast<const uint4*>(p.dy + m * p.lddy + c0);
+      if (BWD && POOL) {     // average-pool backward folded in: every full-resolution pixel reads its pooled pixel's gradient (x 0.25 below)
+        const uint32_t mm = (uint32_t)m;
+        uint32_t t, xx, b, yy;
+        if (p.pool_ws >= 0) {   // power-of-two image (the usual case): shifts and masks instead of two ~40-instruction integer divisions per item
+          t = mm >> p.pool_ws; xx = mm & ((1u << p.pool_ws) - 1u);
+          b = t >> p.pool_hs; yy = t & ((1u << p.pool_hs) - 1u);
+        } else {
+          t = mm / (uint32_t)p.pool_w; xx = mm - t * (uint32_t)p.pool_w;
+          b = t / (uint32_t)p.pool_h; yy = t - b * (uint32_t)p.pool_h;
+        }
+        const int64_t pm = ((int64_t)b * (p.pool_h >> 1) + (yy >> 1)) * (p.pool_w >> 1) + (xx >> 1);
+        rawd = *reinterpret_cast<const uint4*>(p.dy + pm * p.lddy + c0);
+      }
     }
     unpack8(rawx, xv);
     if (BWD) unpack8(rawd, dyv);
+    if (BWD && POOL) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dyv[j] *= 0.25f;    // exact in bf16: what avgpool2_bwd would have stored
+    }
     if (FUSE && BWD) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) dyv[j] = valid ? fmaf(dyv[j], sa_sv[j], sa_dgv[j]) : 0.f;
@@ -435,7 +466,7 @@ extern "C" int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, cons
 // written (forward) and the pool's backward never materialises the upsampled gradient (backward).  Values are rounded to bf16
 // where the two-kernel form stored them, so the results are bit-identical to norm_act_kernel + avgpool2_*_kernel.
 template <bool BWD>
-__global__ __launch_bounds__(256) void bn_act_pool_kernel(const NormParams p, int Ho, int Wo) {
+__global__ __launch_bounds__(256, 4) void bn_act_pool_kernel(const NormParams p, int Ho, int Wo) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int LPP = p.LPP, ppw = 64 / LPP;
   const int chunk = lane & (LPP - 1), slot = lane / LPP;
@@ -481,8 +512,10 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const NormParams p, in
     const int64_t pi = (((int64_t)b * 2 * Ho + 2 * oy) * Wi + 2 * ox);
     const int64_t sub[4] = {pi, pi + 1, pi + Wi, pi + Wi + 1};
     uint4 raw[4];
+    if (!BWD) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) raw[q] = valid ? *reinterpret_cast<const uint4*>(p.x + sub[q] * p.ldx + c0) : make_uint4(0, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) raw[q] = valid ? *reinterpret_cast<const uint4*>(p.x + sub[q] * p.ldx + c0) : make_uint4(0, 0, 0, 0);
+    }
     if (!BWD) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -503,21 +536,33 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const NormParams p, in
       unpack8(valid ? *reinterpret_cast<const uint4*>(p.dy + m * p.lddy + c0) : make_uint4(0, 0, 0, 0), dyv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) dyv[j] *= 0.25f;     // exact in bf16: the upsampled gradient the pool backward would have stored
+      // one uniform branch on the activation for the whole item (act_grad's per-element switch kept every variant's temporaries
+      // alive: 204 VGPRs, two waves per SIMD)
+      auto body = [&](auto slope) {
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {      // rolled: one sub-pixel's temporaries at a time (four waves per SIMD instead of two)
+          float xv[8], o[8];
+          const int64_t sp = pi + (q & 1) + (q >> 1) * Wi;
+          unpack8(valid ? *reinterpret_cast<const uint4*>(p.x + sp * p.ldx + c0) : make_uint4(0, 0, 0, 0), xv);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float xv[8], o[8];
-        unpack8(raw[q], xv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xh = (xv[j] - mu_c[j]) * rs_c[j];
-          const float dh = okf[j] * dyv[j] * act_grad(ga[j] * xh + be[j], p.act, p.alpha);
-          dga[j] = fmaf(dh, xh, dga[j]);
-          dbe[j] += dh;
-          o[j] = dh * ga[j] * rs_c[j];
-          dbi[j] += o[j];
+          for (int j = 0; j < 8; ++j) {
+            const float xh = (xv[j] - mu_c[j]) * rs_c[j];
+            const float dh = dyv[j] * slope(ga[j] * xh + be[j]);      // dyv is zero in pad channels / invalid lanes
+            dga[j] = fmaf(dh, xh, dga[j]);
+            dbe[j] += dh;
+            o[j] = dh * ga[j] * rs_c[j];
+            dbi[j] += o[j];
+          }
+          if (valid) *reinterpret_cast<uint4*>(p.dx + sp * p.lddx + c0) = pack8(o);
         }
-        if (valid) *reinterpret_cast<uint4*>(p.dx + sub[q] * p.lddx + c0) = pack8(o);
-      }
+      };
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dyv[j] *= okf[j];
+      const float alpha = p.alpha;
+      if (p.act == USSEG_ACT_LRELU) body([alpha](float v) { return v >= 0.f ? 1.f : alpha; });
+      else if (p.act == USSEG_ACT_ELU) body([alpha](float v) { return v > 0.f ? 1.f : alpha * __expf(v); });
+      else if (p.act == USSEG_ACT_RELU) body([](float v) { return v > 0.f ? 1.f : 0.f; });
+      else body([](float) { return 1.f; });
     }
   }
   if (BWD) {
@@ -562,10 +607,16 @@ extern "C" int usseg_bn_act_pool_bwd(const void* x, const void* dy, int32_t B, i
                   "bn_act_pool_bwd: bad pointers / strides");
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.ldx = ldx; p.lddy = lddy; p.lddx = lddx;
   p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
+  // backward = the per-channel-affine norm backward over the FULL-resolution pixels (coalesced x / dx streams) whose incoming
+  // gradient is read through the pool's index map: a thread per pooled pixel (bn_act_pool_kernel<true>) touches four strided
+  // pixels per item and reached 3.0 TB/s, this form runs at the norm backward's ~5 TB/s
+  p.M = (int64_t)B * H * W; p.pool_w = W; p.pool_h = H;
+  p.pool_ws = p.pool_hs = -1;
+  if ((W & (W - 1)) == 0 && (H & (H - 1)) == 0) { p.pool_ws = __builtin_ctz(W); p.pool_hs = __builtin_ctz(H); }
   const int ppb = 4 * (64 / p.LPP);
-  unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);     // (4096 one-item workgroups measured 104 us against 58 us: the three block reductions dominate)
+  unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
   p.ws = ws = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * 3 * p.Cphys);
-  hipLaunchKernelGGL(bn_act_pool_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, H / 2, W / 2);
+  hipLaunchKernelGGL((norm_act_kernel<true, 1, 1, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
   return usseg_check_launch("bn_act_pool_bwd");
 }
