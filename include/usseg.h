@@ -533,6 +533,27 @@ int usseg_transpose_batched(const void* src, int32_t R, int32_t C, int32_t lds, 
 int usseg_cast_f32_to_bf16_batched(const float* src, int32_t R, int32_t C, int32_t nb1, int32_t nb2, void* dst, int32_t ldd, int64_t ds1,
                                    int64_t ds2, usseg_stream_t stream);
 
+/* ---- fused multi-head attention (VisionTransformer.py:38-50, TBI_TransUNet.py:44-62; head size 128) -------------------------
+ * O = softmax(scale * Q K^T) V per (image, head) without the [B, heads, N, N] score tensors in memory.  q / k / v point at head 0
+ * of image 0 inside the fused projection output (bf16, row stride ld_qkv elements, image stride N*ld_qkv, head h at columns
+ * h*128); o / d_o are [B][N][ld_o] bf16 with the same head columns.  lse (fp32 [B*H][N], base-2 log-sum-exp of the scaled scores)
+ * is written by the forward and read by the backward; delta (fp32 [B*H][N]) is backward workspace.  o32 (optional, may be NULL)
+ * is an fp32 copy of O, dense [B][N][H*128]: with it the backward's delta = sum_d dO*O is free of O's bf16 rounding, which keeps
+ * the rows of dS summing to zero to rounding noise (the key bias gradient, exactly zero in the reference, stays at noise level).  dq / dk / dv are written
+ * (not accumulated) with row stride ld_qkv - normally the three slices of one [B][N][3*hidden] gradient tensor.  The backward
+ * recomputes the probabilities (two kernels: by query tile and by key tile), uses no atomics and is bitwise reproducible.
+ * The attention weights the reference also returns (:44,56) are not produced: callers that want them use the unfused
+ * usseg_gemm_nt_batched + usseg_softmax_rows_fwd path. */
+typedef struct UssegFlashDesc {
+  int32_t B, N, H, head_dim; /* images, tokens, heads, head size (128) */
+  int32_t ld_qkv, ld_o;      /* row strides in elements */
+  float scale;               /* 1/sqrt(num_heads) in the reference (VisionTransformer.py:42) */
+} UssegFlashDesc;
+int usseg_flash_attn_fwd(const UssegFlashDesc* d, const void* q, const void* k, const void* v, void* o, float* o32, float* lse,
+                         usseg_stream_t stream);
+int usseg_flash_attn_bwd(const UssegFlashDesc* d, const void* q, const void* k, const void* v, const void* o, const float* o32,
+                         const void* d_o, const float* lse, float* delta, void* dq, void* dk, void* dv, usseg_stream_t stream);
+
 /* ---- opt-in per-launch timing (bench.py roofline leg) ------------------------------------------
  * When enabled, every launch of the selected kernel family is bracketed by hipEventRecord on ITS stream.
  * kinds: 1 = gather implicit-GEMM (conv/tconv fwd + dgrad), 2 = weight-gradient GEMM.  Events are created by

@@ -13,6 +13,7 @@ actually build; its variables carry the reference's attribute paths (``transform
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -29,6 +30,7 @@ from .ops import BF16, roundup
 from .step import TrainStepDriver
 
 input_size = (256, 80)   # VisionTransformer.py:7
+_FUSED_ATTN = os.environ.get("USSEG_FUSED_ATTN", "1") != "0"   # train-step attention on csrc/flash_attn.hip (head size 128)
 
 
 def repack_all(root: nn.Module):
@@ -130,11 +132,21 @@ class Attention(nn.Module):
             self._qkv_map_key = key
         return self._qkv_wmap
 
-    def forward(self, xn, residual):
-        """xn, residual: [B,N,1,hidden] bf16 -> (attention output + residual, weights fp32 [B,heads,N,N])."""
+    def forward(self, xn, residual, need_weights=True):
+        """xn, residual: [B,N,1,hidden] bf16 -> (attention output + residual, weights fp32 [B,heads,N,N]).
+        ``need_weights=False`` (the train step, which drops them: :220-223,243) runs the fused kernels of csrc/flash_attn.hip - no
+        [B,heads,N,N] tensor exists - and returns None for the weights."""
         B, N, _, hs = xn.shape
         nh, dh, dev = self.num_heads, self.qkv_size, xn.device
         qkv = ops.conv2d_fwd(xn, self.w_f, self.b_qkv, 1, 1, ops.new_act(B, N, 1, 3 * hs, dev))          # :34-36
+        if not need_weights and dh == 128 and _FUSED_ATTN:
+            ctx = ops.new_act(B, N, 1, hs, dev)
+            lse = torch.empty((B * nh, N), dtype=torch.float32, device=dev)
+            ctx32 = torch.empty((B, N, hs), dtype=torch.float32, device=dev)
+            ops.flash_attn_fwd(qkv, nh, 1.0 / (float(nh) ** 0.5), ctx, lse, ctx32)                         # :41-49
+            out = self.out.forward(ctx, residual=residual)
+            self._saved = (xn, qkv, ctx, lse, ctx32)
+            return out, None
         q, k, v = qkv[..., :hs], qkv[..., hs:2 * hs], qkv[..., 2 * hs:]
         S = torch.empty((B, nh, N, N), dtype=torch.float32, device=dev)
         ops.gemm_nt_batched(q, k, S, N, N, dh, 3 * hs, 3 * hs, N, B, nh, (N * 3 * hs, dh), (N * 3 * hs, dh), (nh * N * N, N * N), out_f32=True)  # :41
@@ -150,7 +162,22 @@ class Attention(nn.Module):
         self._saved = (xn, qkv, P32, Pb, kt)
         return out, P32
 
+    def _backward_tail(self, xn, dqkv):
+        # fused projection backward: the [hidden, 3*hidden] gradient is scattered straight into the three Dense kernels
+        # (one destination block each) - no shared scratch that a deferred split-K finish would still be filling
+        B, N, _, hs = xn.shape
+        ops.conv2d_wgrad_mapped(xn, dqkv, 1, 1, self._qkv_map())
+        ops.colsum(dqkv, self.db_qkv, 3 * hs)
+        return ops.conv2d_dgrad(dqkv, self.w_d, 1, 1, ops.new_act(B, N, 1, hs, xn.device))
+
     def backward(self, d_out):
+        if len(self._saved) == 5 and self._saved[3].dim() == 2:      # fused forward: probabilities recomputed from the log-sum-exp
+            xn, qkv, ctx, lse, ctx32 = self._saved
+            B, N, _, hs = xn.shape
+            dctx = self.out.backward(d_out)
+            dqkv = ops.new_act(B, N, 1, 3 * hs, xn.device)
+            ops.flash_attn_bwd(qkv, self.num_heads, 1.0 / (float(self.num_heads) ** 0.5), ctx, dctx, lse, torch.empty_like(lse), dqkv, ctx32)
+            return self._backward_tail(xn, dqkv)
         xn, qkv, P32, Pb, kt = self._saved
         B, N, _, hs = xn.shape
         nh, dh, dev = self.num_heads, self.qkv_size, xn.device
@@ -169,11 +196,7 @@ class Attention(nn.Module):
         ops.gemm_tn_batched(dS, q, dK, N, dh, N, N, 3 * hs, B, nh, s_pp, s_qkv, s_hd)                       # dK = dS^T Q
         ops.cast_f32_to_bf16_batched(dK, N, dh, B, nh, dqkv[..., hs:2 * hs], 3 * hs, s_qkv)
         ops.cast_f32_to_bf16_batched(dV, N, dh, B, nh, dqkv[..., 2 * hs:], 3 * hs, s_qkv)
-        # fused projection backward: the [hidden, 3*hidden] gradient is scattered straight into the three Dense kernels
-        # (one destination block each) - no shared scratch that a deferred split-K finish would still be filling
-        ops.conv2d_wgrad_mapped(xn, dqkv, 1, 1, self._qkv_map())
-        ops.colsum(dqkv, self.db_qkv, 3 * hs)
-        return ops.conv2d_dgrad(dqkv, self.w_d, 1, 1, ops.new_act(B, N, 1, hs, dev))
+        return self._backward_tail(xn, dqkv)
 
 
 class Mlp(nn.Module):
@@ -205,8 +228,8 @@ class Block(nn.Module):
         self.ffn = Mlp(hidden_size)
         self.attn = Attention(attention_head_size=hidden_size, wDecay=wDecay)
 
-    def forward(self, x):
-        a, weights = self.attn.forward(self.attention_norm.forward(x), residual=x)                        # :137-140
+    def forward(self, x, need_weights=True):
+        a, weights = self.attn.forward(self.attention_norm.forward(x), residual=x, need_weights=need_weights)   # :137-140
         return self.ffn.forward(self.ffn_norm.forward(a), residual=a), weights                            # :142-146
 
     def backward(self, d):
@@ -226,10 +249,10 @@ class Encoder(nn.Module):
         self.encoder_norm = LayerNormalization(512, epsilon=1e-6)
         self.Transformer_layers = nn.ModuleList([Block(wDecay=wDecay) for _ in range(num_layers)])
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states, need_weights=True):
         attn_weights = []
         for blk in self.Transformer_layers:                                                               # :166-168
-            hidden_states, w = blk.forward(hidden_states)
+            hidden_states, w = blk.forward(hidden_states, need_weights)
             attn_weights.append(w)
         return self.encoder_norm.forward(hidden_states), attn_weights                                     # :169
 
@@ -248,12 +271,12 @@ class Transformer(nn.Module):
         self.embeddings = Embeddings(img_size=img_size, in_channels=in_channels, transunet=transunet)
         self.encoder = Encoder(img_size[0], img_size[1], wDecay=wDecay) if use_vit else None
 
-    def forward(self, input_ids, feature_slots=None):
+    def forward(self, input_ids, feature_slots=None, need_weights=True):
         embedding_output, features = self.embeddings.forward(input_ids, feature_slots)
         if self.encoder is None:
             return embedding_output, [], features
         B, N, hs = embedding_output.shape
-        encoded, attn_weights = self.encoder.forward(embedding_output.reshape(B, N, 1, hs))              # :185
+        encoded, attn_weights = self.encoder.forward(embedding_output.reshape(B, N, 1, hs), need_weights)   # :185
         return encoded.reshape(B, N, hs), attn_weights, features
 
     def backward(self, d_hidden, d_feats):
@@ -370,7 +393,7 @@ class VisionTransformer(TrainStepDriver, nn.Module):
         return self.decoder.forward(hidden, features), attn_weights
 
     def _forward_loss(self, x, y, with_grad: bool):
-        hidden, _, features = self.transformer.forward(x, feature_slots=self.decoder.prepare(x.shape[0], self.device))
+        hidden, _, features = self.transformer.forward(x, feature_slots=self.decoder.prepare(x.shape[0], self.device), need_weights=False)
         logits = self.decoder.forward(hidden, features, return_logits=True)
         B = logits.shape[0]
         H, W = self.decoder.out_hw

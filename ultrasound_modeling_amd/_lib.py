@@ -79,6 +79,10 @@ class GemmDesc(C.Structure):
                 ("xs1", c_i64), ("xs2", c_i64), ("ws1", c_i64), ("ws2", c_i64), ("ys1", c_i64), ("ys2", c_i64), ("flags", c_i32)]
 
 
+class FlashDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("N", c_i32), ("H", c_i32), ("head_dim", c_i32), ("ld_qkv", c_i32), ("ld_o", c_i32), ("scale", c_f32)]
+
+
 class LossDesc(C.Structure):
     _fields_ = [("M", c_i64), ("HW", c_i32), ("C", c_i32), ("ldl", c_i32), ("lddl", c_i32), ("loss_kind", c_i32),
                 ("label_smoothing", c_f32), ("clip_eps", c_f32), ("inv_global_batch", c_f32), ("quad_w", c_i32)]
@@ -173,6 +177,8 @@ _PROTOS = {
     "usseg_scale_f32": (C.c_int, [c_vp, c_i64, c_vp, c_f32, c_vp]),
     "usseg_gemm_nt_batched": (C.c_int, [P(GemmDesc), c_vp, c_vp, c_vp, c_vp]),
     "usseg_gemm_tn_batched": (C.c_int, [P(GemmDesc), c_vp, c_vp, c_vp, c_vp]),
+    "usseg_flash_attn_fwd": (C.c_int, [P(FlashDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_flash_attn_bwd": (C.c_int, [P(FlashDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_softmax_rows_fwd": (C.c_int, [c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "usseg_softmax_rows_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp]),
     "usseg_transpose_batched": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp]),

@@ -784,6 +784,31 @@ def softmax_rows_bwd(p32, dp, n, scale, ds):
     L.check(L.load().usseg_softmax_rows_bwd(p32.data_ptr(), dp.data_ptr(), p32.numel() // n, n, scale, ds.data_ptr(), _stream()), "softmax_rows_bwd")
 
 
+def flash_attn_fwd(qkv, nh, scale, out, lse, out32=None):
+    """qkv [B,N,1,3*hidden] bf16 -> out [B,N,1,hidden] = softmax(scale q k^T) v per (image, head); lse fp32 [B*nh, N] (base 2);
+    out32: optional dense fp32 copy of out (for the backward's delta)."""
+    B, N, _, C3 = qkv.shape
+    hs = C3 // 3
+    d = L.FlashDesc(B, N, nh, hs // nh, geom(qkv)[4], geom(out)[4], scale)
+    e = qkv.element_size()
+    L.check(L.load().usseg_flash_attn_fwd(C.byref(d), qkv.data_ptr(), qkv.data_ptr() + hs * e, qkv.data_ptr() + 2 * hs * e, out.data_ptr(),
+                                          _ptr(out32), lse.data_ptr(), _stream()), "flash_attn_fwd")
+    return out
+
+
+def flash_attn_bwd(qkv, nh, scale, out, d_out, lse, delta, dqkv, out32=None):
+    """dqkv [B,N,1,3*hidden] bf16 (written): gradients of q, k, v slices; recomputes the probabilities from lse."""
+    B, N, _, C3 = qkv.shape
+    hs = C3 // 3
+    assert geom(dqkv)[4] == geom(qkv)[4] and geom(d_out)[4] == geom(out)[4]
+    d = L.FlashDesc(B, N, nh, hs // nh, geom(qkv)[4], geom(out)[4], scale)
+    e = qkv.element_size()
+    L.check(L.load().usseg_flash_attn_bwd(C.byref(d), qkv.data_ptr(), qkv.data_ptr() + hs * e, qkv.data_ptr() + 2 * hs * e, out.data_ptr(),
+                                          _ptr(out32), d_out.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dqkv.data_ptr() + hs * e,
+                                          dqkv.data_ptr() + 2 * hs * e, _stream()), "flash_attn_bwd")
+    return dqkv
+
+
 def transpose_batched(src, R, Cc, lds, nb1, nb2, ss, dst):
     L.check(L.load().usseg_transpose_batched(src.data_ptr(), R, Cc, lds, nb1, nb2, ss[0], ss[1], dst.data_ptr(), _stream()), "transpose_batched")
 
