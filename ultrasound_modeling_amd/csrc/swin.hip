@@ -412,15 +412,333 @@ __global__ __launch_bounds__(64) void window_attn_kernel(const WinAttn p) {
     row[bin * p.heads + h] = s;
   }
 }
+// ---- MFMA form for 8x8 windows with head size 32 (every stage of the swin_* configurations): one wave per (image, window, head).
+// q, k, v (and dO) of the window's 64 tokens are staged once into LDS as [64][32] bf16 tiles (row stride 48 elements: the row reads
+// ds_read_b128 and the transposed reads ds_read_b64_tr_b16 are both conflict-free).  The score tile is computed TRANSPOSED
+// (S^T = K Q^T: rows keys, columns queries) so that its accumulator layout is the B-operand layout of the second GEMM; MFMA row i of
+// key tile t is key 32*(t>>1) + 8*(i>>2) + 4*(t&1) + (i&3), which makes two tiles fill the 32 contraction slots in natural order.
+// Relative-position bias, shifted-window mask and the softmax run on the accumulators (a query column lives in 4 lanes: two
+// shuffles per reduction).  Probabilities and dS enter the second GEMMs as hi + lo bf16 pairs (relative error 2^-17), so the
+// results match the fp32 scalar kernel to rounding.  Backward: P^T and dS^T are parked in LDS as fp32 [key][query] matrices, from
+// which the dK / dV GEMMs read their B operands (8 consecutive queries per lane) and the bias-table bins are summed in a fixed order.
+#define WM_VS 48
+#define WM_PS 68
+__device__ __forceinline__ bf16x8_t wm_row(const bf16_t* tile, int row, int g) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * WM_VS + 8 * g);
+}
+// A operand [free = 16*dt + li][slot 8g + j] = tile[32c + 8g + j][16*dt + li]
+__device__ __forceinline__ bf16x8_t wm_tr(const bf16_t* tile, int c, int dt, int g, int tq, int tp) {
+  const bf16_t* a0 = tile + (32 * c + 8 * g + tq) * WM_VS + 16 * dt + 4 * tp;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * WM_VS));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ void wm_split(const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  float r[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = v[e] - bf2f(f2bf(v[e]));
+  u32x4_t h = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+  u32x4_t l = {pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7])};
+  hi = __builtin_bit_cast(bf16x8_t, h);
+  lo = __builtin_bit_cast(bf16x8_t, l);
+}
+__device__ __forceinline__ int wm_tile_row(int t, int i) { return 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3); }
+
+// the window's rows as 16 named registers (an aggregate carried round the window loop is kept in scratch memory by the compiler)
+#define WM_FETCH(w_)                                                                                   \
+  {                                                                                                    \
+    const int fy_ = (w_) / nwx, fx_ = (w_) - fy_ * nwx;                                                \
+    const int64_t ft_ = wa_token(p, b, fy_, fx_, lane);                                                \
+    const bf16_t* fs_ = p.qkv + ft_ * p.ldq + h * 32;                                                  \
+    rq0 = *reinterpret_cast<const uint4*>(fs_); rq1 = *reinterpret_cast<const uint4*>(fs_ + 8);        \
+    rq2 = *reinterpret_cast<const uint4*>(fs_ + 16); rq3 = *reinterpret_cast<const uint4*>(fs_ + 24);  \
+    fs_ += p.C;                                                                                        \
+    rk0 = *reinterpret_cast<const uint4*>(fs_); rk1 = *reinterpret_cast<const uint4*>(fs_ + 8);        \
+    rk2 = *reinterpret_cast<const uint4*>(fs_ + 16); rk3 = *reinterpret_cast<const uint4*>(fs_ + 24);  \
+    fs_ += p.C;                                                                                        \
+    rv0 = *reinterpret_cast<const uint4*>(fs_); rv1 = *reinterpret_cast<const uint4*>(fs_ + 8);        \
+    rv2 = *reinterpret_cast<const uint4*>(fs_ + 16); rv3 = *reinterpret_cast<const uint4*>(fs_ + 24);  \
+    if (BWD) {                                                                                         \
+      const bf16_t* fd_ = p.dout + ft_ * p.ldo + h * 32;                                               \
+      rd0 = *reinterpret_cast<const uint4*>(fd_); rd1 = *reinterpret_cast<const uint4*>(fd_ + 8);      \
+      rd2 = *reinterpret_cast<const uint4*>(fd_ + 16); rd3 = *reinterpret_cast<const uint4*>(fd_ + 24);\
+    }                                                                                                  \
+  }
+#define WM_PUT(tile_, r0_, r1_, r2_, r3_)                                  \
+  {                                                                        \
+    uint4* d_ = reinterpret_cast<uint4*>(&tile_[lane * WM_VS]);            \
+    d_[0] = r0_; d_[1] = r1_; d_[2] = r2_; d_[3] = r3_;                    \
+  }
+
+template <bool BWD, bool ONE>
+__global__ __launch_bounds__(64) void window_attn_mfma_kernel(const WinAttn p, const int wpb_) {
+  const int wpb = ONE ? 1 : wpb_;
+  constexpr int WS = 8, N = 64, T = 15;
+  __shared__ __attribute__((aligned(16))) bf16_t s_q[N * WM_VS], s_k[N * WM_VS], s_v[N * WM_VS];
+  __shared__ __attribute__((aligned(16))) bf16_t s_do[BWD ? N * WM_VS : 8];
+  __shared__ __attribute__((aligned(16))) float s_pT[BWD ? N * WM_PS : 4], s_dsT[BWD ? N * WM_PS : 4];   // [key][query]
+  __shared__ __attribute__((aligned(16))) float s_acc[BWD ? N * WM_PS : 4];   // dS summed over the block's windows (same layout)
+  __shared__ float s_tab[T * T];
+  __shared__ int s_reg[N];
+  const int nwx = p.W / WS, nW = (p.H / WS) * nwx;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x, g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int i = lane; i < T * T; i += 64) s_tab[i] = p.table[i * p.heads + h];
+  if (BWD)
+    for (int i = lane; i < N * WM_PS; i += 64) s_acc[i] = 0.f;
+  // a block walks wpb consecutive windows of one (image, head): the next window's rows are loaded while this one computes
+  uint4 rq0, rq1, rq2, rq3, rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3, rd0, rd1, rd2, rd3;
+  rd0 = rd1 = rd2 = rd3 = make_uint4(0, 0, 0, 0);
+  const int w0 = blockIdx.x * wpb;
+  WM_FETCH(w0);
+  for (int wi = 0; wi < wpb; ++wi) {
+  const int w = w0 + wi, wy = w / nwx, wx = w - wy * nwx;
+  WM_PUT(s_q, rq0, rq1, rq2, rq3);
+  WM_PUT(s_k, rk0, rk1, rk2, rk3);
+  WM_PUT(s_v, rv0, rv1, rv2, rv3);
+  if (BWD) WM_PUT(s_do, rd0, rd1, rd2, rd3);
+  s_reg[lane] = p.shift > 0 ? wa_region(p, wy, wx, lane) : 0;
+  __syncthreads();
+  if (!ONE && wi + 1 < wpb) WM_FETCH(w + 1);
+
+  // ---- transposed scores: lane holds key kj = 32*(kt>>1) + 8g + 4*(kt&1) + r (row rj = 4*(kt>>1) + g, column cj = 4*(kt&1) + r)
+  //      of query qi = qt*16 + li
+  f32x4_t st[4][4], dpt[4][4];
+  {
+    bf16x8_t kf[4], qf[4], vf[4], df[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      kf[t] = wm_row(s_k, wm_tile_row(t, li), g);
+      qf[t] = wm_row(s_q, t * 16 + li, g);
+      if (BWD) { vf[t] = wm_row(s_v, wm_tile_row(t, li), g); df[t] = wm_row(s_do, t * 16 + li, g); }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (BWD) dpt[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], df[qt], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+  }
+  int kreg[4][4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kreg[kt][r] = s_reg[32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int qi = qt * 16 + li, ri = qi >> 3, ci = qi & 7, regq = s_reg[qi];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rj = 4 * (kt >> 1) + g, cj = 4 * (kt & 1) + r;
+        float s = st[kt][qt][r] * p.scale + s_tab[(ri - rj + WS - 1) * T + (ci - cj + WS - 1)];      // :94-104
+        if (kreg[kt][r] != regq) s += -100.f;                                                            // :106-110
+        st[kt][qt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { float e = __expf(st[kt][qt][r] - mx); st[kt][qt][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) st[kt][qt] *= inv;
+  }
+
+  if (!BWD) {
+    // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
+    f32x4_t o[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) o[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8_t vt[2] = {wm_tr(s_v, c, 0, g, tq, tp), wm_tr(s_v, c, 1, g, tq, tp)};
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const float pv[8] = {st[2 * c][qt][0], st[2 * c][qt][1], st[2 * c][qt][2], st[2 * c][qt][3],
+                             st[2 * c + 1][qt][0], st[2 * c + 1][qt][1], st[2 * c + 1][qt][2], st[2 * c + 1][qt][3]};
+        bf16x8_t ph, pl;
+        wm_split(pv, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[dt], ph, o[dt][qt], 0, 0, 0);
+          o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[dt], pl, o[dt][qt], 0, 0, 0);
+        }
+      }
+    }
+    // lane holds O[q = qt*16 + li][d = 16*dt + 4g + r]
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      bf16_t* dst = p.out + wa_token(p, b, wy, wx, qt * 16 + li) * p.ldo + h * 32 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        uint2 wv;
+        wv.x = pack2bf(o[dt][qt][0], o[dt][qt][1]);
+        wv.y = pack2bf(o[dt][qt][2], o[dt][qt][3]);
+        *reinterpret_cast<uint2*>(dst + 16 * dt) = wv;
+      }
+    }
+    __syncthreads();
+    continue;
+  }
+
+  // ---- backward: dS^T = P^T (dP^T - delta_q), dQ^T[d][q] = scale * sum_keys K^T[d][key] dS^T[key][q]
+  f32x4_t dq[2][4];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) dq[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    float delta = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) delta = fmaf(st[kt][qt][r], dpt[kt][qt][r], delta);
+    delta += __shfl_xor(delta, 16);
+    delta += __shfl_xor(delta, 32);
+    const int qi = qt * 16 + li;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
+        const float pr = st[kt][qt][r], ds = pr * (dpt[kt][qt][r] - delta);
+        dpt[kt][qt][r] = ds;
+        s_pT[kj * WM_PS + qi] = pr;
+        s_dsT[kj * WM_PS + qi] = ds;
+        s_acc[kj * WM_PS + qi] += ds;          // one owner lane per element: a fixed summation order
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    bf16x8_t kt_[2] = {wm_tr(s_k, c, 0, g, tq, tp), wm_tr(s_k, c, 1, g, tq, tp)};
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const float dv[8] = {dpt[2 * c][qt][0], dpt[2 * c][qt][1], dpt[2 * c][qt][2], dpt[2 * c][qt][3],
+                           dpt[2 * c + 1][qt][0], dpt[2 * c + 1][qt][1], dpt[2 * c + 1][qt][2], dpt[2 * c + 1][qt][3]};
+      bf16x8_t dh, dl;
+      wm_split(dv, dh, dl);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_[dt], dh, dq[dt][qt], 0, 0, 0);
+        dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_[dt], dl, dq[dt][qt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    bf16_t* dst = p.out + wa_token(p, b, wy, wx, qt * 16 + li) * p.ldq + h * 32 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      uint2 wv;
+      wv.x = pack2bf(dq[dt][qt][0] * p.scale, dq[dt][qt][1] * p.scale);
+      wv.y = pack2bf(dq[dt][qt][2] * p.scale, dq[dt][qt][3] * p.scale);
+      *reinterpret_cast<uint2*>(dst + 16 * dt) = wv;
+    }
+  }
+  __syncthreads();
+  // ---- dV^T[d][key] = sum_q dO^T[d][q] P[q][key],  dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
+  //      B operand [slot q = 32c + 8g + j][col key = kt*16 + li]: 8 consecutive floats of row `key` of the [key][query] matrices
+  f32x4_t dvv[2][4], dkk[2][4];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) dvv[dt][kt] = dkk[dt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    bf16x8_t dot[2] = {wm_tr(s_do, c, 0, g, tq, tp), wm_tr(s_do, c, 1, g, tq, tp)};
+    bf16x8_t qtr[2] = {wm_tr(s_q, c, 0, g, tq, tp), wm_tr(s_q, c, 1, g, tq, tp)};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const float* pr = &s_pT[(kt * 16 + li) * WM_PS + 32 * c + 8 * g];
+      const float* dr = &s_dsT[(kt * 16 + li) * WM_PS + 32 * c + 8 * g];
+      const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(pr), p1 = *reinterpret_cast<const f32x4_t*>(pr + 4);
+      const f32x4_t d0 = *reinterpret_cast<const f32x4_t*>(dr), d1 = *reinterpret_cast<const f32x4_t*>(dr + 4);
+      const float pv[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+      const float dv[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+      bf16x8_t ph, pl, dh, dl;
+      wm_split(pv, ph, pl);
+      wm_split(dv, dh, dl);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dvv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], ph, dvv[dt][kt], 0, 0, 0);
+        dvv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], pl, dvv[dt][kt], 0, 0, 0);
+        dkk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dh, dkk[dt][kt], 0, 0, 0);
+        dkk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dl, dkk[dt][kt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    bf16_t* dst = p.out + wa_token(p, b, wy, wx, kt * 16 + li) * p.ldq + h * 32 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      uint2 wv;
+      wv.x = pack2bf(dkk[dt][kt][0] * p.scale, dkk[dt][kt][1] * p.scale);
+      wv.y = pack2bf(dkk[dt][kt][2] * p.scale, dkk[dt][kt][3] * p.scale);
+      *reinterpret_cast<uint2*>(dst + p.C + 16 * dt) = wv;
+      wv.x = pack2bf(dvv[dt][kt][0], dvv[dt][kt][1]);
+      wv.y = pack2bf(dvv[dt][kt][2], dvv[dt][kt][3]);
+      *reinterpret_cast<uint2*>(dst + 2 * p.C + 16 * dt) = wv;
+    }
+  }
+  __syncthreads();
+  }   // windows
+  if (!BWD) return;
+  // relative-position bias gradient: bin (dr, dc) collects dS_ij over the pairs with r_i - r_j = dr, c_i - c_j = dc (fixed order),
+  // once per block from the sum over its windows
+  float* row = p.dtab_ws + ((int64_t)b * (nW / wpb) + blockIdx.x) * (T * T) * p.heads;
+  for (int bin = lane; bin < T * T; bin += 64) {
+    const int dr = bin / T - (WS - 1), dc = bin % T - (WS - 1);
+    float s = 0.f;
+    for (int ii = 0; ii < N; ++ii) {
+      const int ri = ii >> 3, ci = ii & 7;
+      const int rj = ri - dr, cj = ci - dc;
+      if ((unsigned)rj < (unsigned)WS && (unsigned)cj < (unsigned)WS) s += s_acc[(rj * WS + cj) * WM_PS + ii];
+    }
+    row[bin * p.heads + h] = s;
+  }
+}
+
+// returns the number of partial bias-table rows the backward wrote (0 = unsupported window side)
 template <bool BWD>
 static int wa_launch(const WinAttn& p, hipStream_t s) {
-  const int N = p.ws * p.ws;
+  const int N = p.ws * p.ws, nW = (p.H / p.ws) * (p.W / p.ws);
   const size_t dyn = sizeof(float) * ((size_t)(BWD ? 4 : 3) * N * (p.d + 1) + (BWD ? 2 * (size_t)N * (N + 1) : 0));
-  const dim3 grid((p.H / p.ws) * (p.W / p.ws), p.heads, p.B);
-#define WAL(WS_)                                                                                                                     {                                                                                                                                    if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void*)window_attn_kernel<BWD, WS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);     hipLaunchKernelGGL((window_attn_kernel<BWD, WS_>), grid, dim3(64), dyn, s, p);                                                    }
+  static const int no_mfma = getenv("USSEG_WINATTN_MFMA") && atoi(getenv("USSEG_WINATTN_MFMA")) == 0;
+  if (p.ws == 8 && p.d == 32 && !no_mfma) {
+    // windows per block: a power of two dividing nW that still fills the chip (the forward holds 8 one-wave blocks per CU, the
+    // backward 2: 78 KB of LDS); the backward gains most - one bias-table reduction per block instead of one per window
+    const int64_t min_blocks = BWD ? 1024 : 8192;
+    int wpb = BWD ? 16 : 4;
+    while (wpb > 1 && (nW % wpb != 0 || (int64_t)(nW / wpb) * p.heads * p.B < min_blocks)) wpb >>= 1;
+    if (wpb == 1) hipLaunchKernelGGL((window_attn_mfma_kernel<BWD, true>), dim3(nW, p.heads, p.B), dim3(64), 0, s, p, 1);
+    else hipLaunchKernelGGL((window_attn_mfma_kernel<BWD, false>), dim3(nW / wpb, p.heads, p.B), dim3(64), 0, s, p, wpb);
+    return p.B * (nW / wpb);
+  }
+  const dim3 grid(nW, p.heads, p.B);
+#define WAL(WS_)                                                                                                                     \
+  {                                                                                                                                  \
+    if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void*)window_attn_kernel<BWD, WS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);   \
+    hipLaunchKernelGGL((window_attn_kernel<BWD, WS_>), grid, dim3(64), dyn, s, p);                                                  \
+  }
   if (p.ws == 2) WAL(2) else if (p.ws == 4) WAL(4) else if (p.ws == 8) WAL(8) else return 0;
 #undef WAL
-  return 1;
+  return p.B * nW;
 }
 
 static int wa_common(WinAttn& p, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift) {
@@ -454,8 +772,8 @@ extern "C" int usseg_window_attn_bwd(const void* qkv, int32_t ldq, const void* d
   p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.table = table; p.out = (bf16_t*)dqkv; p.ldq = ldq; p.ldo = ldo;
   const int nW = (H / ws) * (W / ws), bins = (2 * ws - 1) * (2 * ws - 1) * heads;
   p.dtab_ws = usseg_defer_reduce_ws((hipStream_t)stream, ws_rows, (int64_t)B * nW * bins);
-  (void)wa_launch<true>(p, (hipStream_t)stream);
-  usseg_launch_reduce_finish(p.dtab_ws, 1, B * nW, 1, bins, bins, 1.f, dtable, nullptr, nullptr, (hipStream_t)stream);
+  const int rows = wa_launch<true>(p, (hipStream_t)stream);
+  usseg_launch_reduce_finish(p.dtab_ws, 1, rows, 1, bins, bins, 1.f, dtable, nullptr, nullptr, (hipStream_t)stream);
   return usseg_check_launch("window_attn_bwd");
 }
 
