@@ -36,7 +36,7 @@ import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
 HBM_BYTES_PER_S = 8.0e12     # HBM3E peak, MI355X_MICROARCH.md
-BASE_BATCH = {"B": 16, "A": 32, "T": 8}   # images per GPU at N=1 (BASELINE configs[1] / configs[2] / configs[3])
+BASE_BATCH = {"B": 16, "A": 32, "T": 8, "S": 16}   # images per GPU at N=1 (BASELINE configs[1] / [2] / [3] / [4])
 H = W = 256
 C_IN = 1
 
@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--arch", choices=["B", "A", "T"], default="B",
+    ap.add_argument("--arch", choices=["B", "A", "T", "S"], default="B",
                     help="B: ResNest.py+Decoder.py (configs[1], default); A: TBI_ResNest.py (configs[2]); T: TBI_TransUNet.py at 512x512 (configs[3], throughput only)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: fixed per-GPU batch; strong: fixed global batch split over the replicas")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
@@ -258,7 +258,7 @@ def main():
     arch = args.arch
     base = BASE_BATCH[arch]
     global H, W
-    if arch == "T":                  # configs[3] is quoted at 512x512; the roofline / CPU legs are defined for the headline configs only
+    if arch in ("T", "S"):           # configs[3] / [4] are quoted at 512x512; the roofline / CPU legs are defined for the headline configs only
         H = W = 512
         args.profile_steps, args.no_cpu_baseline = 0, True
     if args.scaling == "strong":
@@ -275,6 +275,10 @@ def main():
     elif arch == "T":
         from ultrasound_modeling_amd.TBI_TransUNet import VisionTransformer as TransUNet
         net = TransUNet(img_size=(H, W), batch_size=global_batch, in_channels=C_IN, device=str(dev), seed=0)
+    elif arch == "S":
+        from ultrasound_modeling_amd.SwinTransformer import SwinTransformerModel
+        net = SwinTransformerModel(model_name="swin_tiny_512", img_size=(H, W), patch_size=(4, 4), in_chans=C_IN, embed_dim=96, depths=[2, 2, 6, 2],
+                                   num_heads=[3, 6, 12, 24], window_size=8, device=str(dev), seed=0)
     else:
         from ultrasound_modeling_amd.TBI_ResNest import ResNest
         net = ResNest(H, W, C_IN, 3, ksize=3, radix=3, kpaths=4, learning_rate=5e-3, device=str(dev), seed=0)
@@ -292,6 +296,8 @@ def main():
     c2 = torch.where(lab >= 1.05, (lab - 1).clamp(0, 1), torch.zeros_like(lab))
     y = torch.stack([(lab <= 0.95).float(), torch.where(lab > 0.95, 1 - c2, torch.zeros_like(lab)), c2], dim=-1).to(dev)
 
+    if arch == "S":      # the reference defines no loss for SwinTransformer.py: the step is driven by a fixed upstream gradient of the pooled output
+        y = torch.full((per_gpu, 768), 1.0 / (768 * global_batch), device=dev)
     use_graph = not args.no_graph                    # N > 1: the step up to the per-replica clip is one graph, then the RCCL exchange, then the update
     log(f"rank {rank}/{world}: Arch {arch} built ({net.flat.n_trainable} params), {per_gpu} images per GPU, warming up (graph={use_graph})")
     for _ in range(max(args.warmup, 1) if not use_graph else 1):
@@ -362,7 +368,9 @@ def main():
     if rank == 0:
         names = {"B": "BASELINE configs[1]: Arch B (ResNest.py r=3,k=3 + Decoder.py, no ViT) train step",
                  "A": "BASELINE configs[2]: Arch A (TBI_ResNest.py model r=3,k=4, my_loss_cat, Adam 5e-3) train step",
-                 "T": "BASELINE configs[3]: TBI_TransUNet.py (ResNeSt encoder with BatchNorm + 8-layer ViT bottleneck, 1024 tokens + decoder) train step"}
+                 "T": "BASELINE configs[3]: TBI_TransUNet.py (ResNeSt encoder with BatchNorm + 8-layer ViT bottleneck, 1024 tokens + decoder) train step",
+                 "S": "BASELINE configs[4]: SwinTransformer.py windowed-attention encoder (swin_tiny widths, 8x8 windows; forward + backward from a fixed "
+                      "upstream gradient of the pooled output + Adam; the reference defines no loss for it)"}
         out = {"metric": f"segmentation training images/sec at {H}x{W}", "value": round(global_batch * args.steps / el, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,

@@ -176,3 +176,29 @@ def test_swin_cfg5_512x512_batch16_properties():
     top.flat.zero_grad()
     top.backward(torch.ones(2, 10))
     assert torch.isfinite(top.flat.grad).all() and top.head.kernel.grad.abs().max().item() > 0
+
+
+def test_swin_train_step_graph_replay_equals_eager():
+    """The shared step driver (step.TrainStepDriver) on the Swin encoder: three optimisation steps driven by upstream gradients, eager vs
+    HIP-graph replay (what ``bench.py --arch S`` times) - outputs, parameters and Adam state bit for bit; capture consumes no step."""
+    from ultrasound_modeling_amd.SwinTransformer import SwinTransformerModel
+    kw = dict(model_name="t", img_size=(64, 64), patch_size=(4, 4), in_chans=1, embed_dim=96, depths=[2, 2], num_heads=[3, 6], window_size=8, seed=3)
+    eager, graph = SwinTransformerModel(**kw), SwinTransformerModel(**kw)
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(2, 64, 64, 1, generator=g) for _ in range(3)]
+    ds = [torch.randn(2, 192, generator=g) for _ in range(3)]
+
+    def state(n):
+        torch.cuda.synchronize()
+        return n.flat.flat.clone(), n.optimizer.m.clone(), n.optimizer.v.clone(), int(n.optimizer.step_dev.item())
+    graph.capture_graph(xs[0], ds[0])
+    for a, b in zip(state(eager), state(graph)):
+        assert (a == b) if isinstance(a, int) else torch.equal(a, b), "capture must not change the training state"
+    for i in range(3):
+        l0, o0 = eager.train_step(xs[i], ds[i])
+        l1, o1 = graph.train_step(xs[i], ds[i])
+        torch.cuda.synchronize()
+        assert torch.equal(o0, o1) and l0.item() == l1.item(), i
+        for a, b in zip(state(eager), state(graph)):
+            assert (a == b) if isinstance(a, int) else torch.equal(a, b), f"step {i}"
+    assert state(graph)[3] == 3 and not torch.equal(state(graph)[0], SwinTransformerModel(**kw).flat.flat)

@@ -13,11 +13,7 @@ g = (torch.ones(16, 768) / 768).cuda()
 
 
 def step():
-    net.flat.zero_grad()
-    net(x)
-    net.backward(g)
-    net.optimizer.apply()
-    net.repack()
+    net.train_step(x, g)
 
 
 for _ in range(3):

@@ -32,6 +32,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from .step import TrainStepDriver
 from . import ops
 from .flat import AdamClip, FlatParams
 from .layers import Conv2D
@@ -251,7 +252,7 @@ class PatchEmbed(nn.Module):
         self.proj.backward(dy, need_dx=False)                  # the image needs no gradient
 
 
-class SwinTransformerModel(nn.Module):
+class SwinTransformerModel(TrainStepDriver, nn.Module):
     """SwinTransformer.py:372-455.  ``forward(x)`` -> (pooled features [B, num_features] fp32, or logits with include_top;
     [token tensor of every stage but the last, as [B, L, C] views]).  ``backward(d_out, d_features=None)`` accumulates every
     parameter gradient.  Owns its parameters in one flat fp32 buffer (flat.FlatParams) with a clip + Adam optimiser, like the
@@ -285,9 +286,45 @@ class SwinTransformerModel(nn.Module):
         self.features: List[torch.Tensor] = []
 
     def repack(self):
-        for m in self.modules():
-            if isinstance(m, Conv2D) and m.wp_f is not None:
-                m.repack()
+        """Every bf16 GEMM operand rebuilt from the fp32 masters in ONE batched launch (device-resident job table)."""
+        from .VisionTransformer import repack_all
+        repack_all(self)
+
+    # ---- the shared step driver (step.TrainStepDriver): zero -> forward -> backward -> [per-replica clip -> exchange] -> Adam -> repack.
+    # The reference defines no loss for this file (nothing imports it), so the "label" of a step is the upstream gradient of the
+    # first output (pooled features, or logits with include_top).
+    def _prep_x(self, x):
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(x)
+        x = x.to(self.device)
+        return (x if x.dtype in (torch.float32, torch.float64) else x.float()).contiguous()
+
+    def _prep_y(self, y):
+        if not torch.is_tensor(y):
+            y = torch.as_tensor(y)
+        return y.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _zero_grad(self):
+        self.flat.zero_grad()
+
+    def _forward_backward(self, x, y):
+        out, _ = self.forward(x)
+        self._loss = (out * y).sum()          # the linear functional whose gradient w.r.t. the output is ``y``
+        self.backward(y)
+        return out
+
+    def _repack(self):
+        self.repack()
+
+    def _graph_state(self):
+        return [self.flat.flat] + self.optimizer.state_tensors()
+
+    def train_step(self, x, d_out):
+        """One optimisation step driven by the upstream gradient ``d_out`` of the first output: -> (sum(out * d_out), out); after
+        ``capture_graph`` ``out`` is the captured step's static buffer."""
+        x, d_out = self._prep_x(x), self._prep_y(d_out)
+        out = self._graph_replay(x, d_out) if self._graph is not None else self._train_body(x, d_out)
+        return self._loss.clone(), out
 
     def forward_features(self, x):
         """-> pooled [B, num_features] fp32 (:437-452)."""
