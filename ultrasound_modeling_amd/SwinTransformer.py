@@ -111,7 +111,9 @@ class Mlp(nn.Module):
 
     def backward(self, dy):
         dg = self.fc2.backward(dy)
-        return self.fc1.backward(ops.act_bwd(self._h, dg, torch.empty_like(dg), ACT_GELU, 0.0))
+        # GELU backward + fc1's bias gradient (column sums of its output) in one pass
+        dh = ops.act_bwd_colsum(self._h, dg, torch.empty_like(dg), ACT_GELU, 0.0, self.fc1.bias.grad, self.fc1.cout)
+        return Conv2D.backward(self.fc1, dh, skip_bias=True)
 
 
 class WindowAttention(nn.Module):

@@ -214,7 +214,9 @@ class Mlp(nn.Module):
 
     def backward(self, d):
         dg = self.fc2.backward(d)
-        return self.fc1.backward(ops.act_bwd(self._raw, dg, torch.empty_like(dg), ops.ACT_GELU, 0.0))
+        # GELU backward + fc1's bias gradient (column sums of its output) in one pass
+        dr = ops.act_bwd_colsum(self._raw, dg, torch.empty_like(dg), ops.ACT_GELU, 0.0, self.fc1.bias.grad, self.fc1.cout)
+        return self.fc1.backward(dr, skip_bias=True)
 
 
 class Block(nn.Module):

@@ -623,10 +623,14 @@ extern "C" int usseg_bn_act_pool_bwd(const void* x, const void* dy, int32_t B, i
 
 // ------------------------------------------------------------------------------------------ column sums
 // MODE 0: out[c] += sum_m a[m][c]; MODE 1: out[c] += sum a, out2[c] += sum a^2
+// Rows wider than 512 channels: grid.y walks 512-channel slabs (partial rows of slab y at ws + y * gridDim.x * rows-per-block * 512).
 template <int MODE>
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* a, int64_t M, int C, int ld, int LPP, float* ws) {
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* a, int64_t M, int Ctot, int ld, int LPP, float* ws) {
   __shared__ float s_red[4 * 512];
-  const int Cp = (C + 7) & ~7;
+  const int c0 = blockIdx.y * 512, C = Ctot - c0 < 512 ? Ctot - c0 : 512;
+  a += c0;
+  ws += (int64_t)blockIdx.y * gridDim.x * (MODE + 1) * 512;
+  const int Cp = gridDim.y > 1 ? 512 : (C + 7) & ~7;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ppw = 64 / LPP, chunk = lane & (LPP - 1), slot = lane / LPP;
   const bool chunk_ok = chunk * 8 < C;
@@ -651,16 +655,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* a, int64_t M,
 extern "C" int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, float* ws, usseg_stream_t stream) {
   USSEG_CHECK_ARG(dy && db && ws && C > 0 && ld % 8 == 0 && C <= 16384, "colsum: bad args");
   if (M <= 0) return USSEG_OK;
-  // wide rows: process in slabs of 512 channels
-  for (int c0 = 0; c0 < C; c0 += 512) {
-    int cw = C - c0 < 512 ? C - c0 : 512;
-    int cwp = roundup(cw, 8);
-    int LPP = lanes_per_pixel(cwp / 8);
-    int ppb = 4 * (64 / LPP);
-    unsigned grid = grid_for(M, ppb * 8, USSEG_REDUCE_MAX_BLOCKS);
-    float* wsr = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * cwp);
-    hipLaunchKernelGGL(colsum_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy + c0, M, cw, ld, LPP, wsr);
-    usseg_launch_reduce_finish(wsr, 1, (int)grid, 1, cwp, cw, 1.f, db + c0, nullptr, nullptr, (hipStream_t)stream);
+  // wide rows: 512-channel slabs along grid.y of ONE launch
+  const int nslab = (C + 511) / 512;
+  const int cwp = nslab > 1 ? 512 : roundup(C, 8);
+  const int LPP = lanes_per_pixel(cwp / 8);
+  const int ppb = 4 * (64 / LPP);
+  unsigned grid = grid_for(M, ppb * 8, USSEG_REDUCE_MAX_BLOCKS * 3 / nslab < USSEG_REDUCE_MAX_BLOCKS ? USSEG_REDUCE_MAX_BLOCKS * 3 / nslab : USSEG_REDUCE_MAX_BLOCKS);
+  float* wsr = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * nslab * cwp);
+  hipLaunchKernelGGL(colsum_kernel<0>, dim3(grid, nslab), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, M, C, ld, LPP, wsr);
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int cw = C - sl * 512 < 512 ? C - sl * 512 : 512;
+    usseg_launch_reduce_finish(wsr + (int64_t)sl * grid * cwp, 1, (int)grid, 1, cwp, cw, 1.f, db + sl * 512, nullptr, nullptr, (hipStream_t)stream);
   }
   return usseg_check_launch("colsum");
 }
@@ -706,10 +711,13 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* x, const bf1
 }
 // activation backward that also yields the column sums of its output (the bias gradient of the conv whose fused activation this
 // undoes - ResNest.py:39-40 conv1 + LeakyReLU): one pass instead of act_bwd + colsum.  Sums the STORED (bf16) values, as colsum would.
-__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const bf16_t* x, const bf16_t* dy, int64_t M, int C, int ldx, int lddy, int lddx, int LPP,
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const bf16_t* x, const bf16_t* dy, int64_t M, int Ctot, int ldx, int lddy, int lddx, int LPP,
                                                               int act, float alpha, bf16_t* dx, float* ws) {
   __shared__ float s_red[4 * 512];
-  const int Cp = (C + 7) & ~7;
+  const int c0 = blockIdx.y * 512, C = Ctot - c0 < 512 ? Ctot - c0 : 512;      // 512-channel slabs along grid.y
+  x += c0; dy += c0; dx += c0;
+  ws += (int64_t)blockIdx.y * gridDim.x * 512;
+  const int Cp = gridDim.y > 1 ? 512 : (C + 7) & ~7;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ppw = 64 / LPP, chunk = lane & (LPP - 1), slot = lane / LPP;
   const bool chunk_ok = chunk * 8 < C;
@@ -734,16 +742,20 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const bf16_t* x, co
 }
 extern "C" int usseg_act_bwd_colsum(const void* x, const void* dy, int64_t M, int32_t C, int32_t ldx, int32_t lddy, int32_t lddx, int32_t act,
                                     float alpha, void* dx, float* db, float* ws, usseg_stream_t stream) {
-  USSEG_CHECK_ARG(x && dy && dx && db && ws && C > 0 && C <= 512 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "act_bwd_colsum: bad args");
+  USSEG_CHECK_ARG(x && dy && dx && db && ws && C > 0 && C <= 16384 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "act_bwd_colsum: bad args");
   if (M <= 0) return USSEG_OK;
-  const int cwp = roundup(C, 8);
+  const int nslab = (C + 511) / 512;
+  const int cwp = nslab > 1 ? 512 : roundup(C, 8);
   const int LPP = lanes_per_pixel(cwp / 8);
   const int ppb = 4 * (64 / LPP);
-  unsigned grid = grid_for(M, ppb * 8, USSEG_REDUCE_MAX_BLOCKS);
-  float* wsr = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * cwp);
-  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, M, C, ldx, lddy, lddx,
-                     LPP, act, alpha, (bf16_t*)dx, wsr);
-  usseg_launch_reduce_finish(wsr, 1, (int)grid, 1, cwp, C, 1.f, db, nullptr, nullptr, (hipStream_t)stream);
+  unsigned grid = grid_for(M, ppb * 8, USSEG_REDUCE_MAX_BLOCKS * 3 / nslab < USSEG_REDUCE_MAX_BLOCKS ? USSEG_REDUCE_MAX_BLOCKS * 3 / nslab : USSEG_REDUCE_MAX_BLOCKS);
+  float* wsr = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * nslab * cwp);
+  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3(grid, nslab), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, M, C, ldx, lddy,
+                     lddx, LPP, act, alpha, (bf16_t*)dx, wsr);
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int cw = C - sl * 512 < 512 ? C - sl * 512 : 512;
+    usseg_launch_reduce_finish(wsr + (int64_t)sl * grid * cwp, 1, (int)grid, 1, cwp, cw, 1.f, db + sl * 512, nullptr, nullptr, (hipStream_t)stream);
+  }
   return usseg_check_launch("act_bwd_colsum");
 }
 
