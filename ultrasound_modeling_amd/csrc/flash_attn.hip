@@ -37,20 +37,22 @@ struct FlashParams {
 
 __device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-// 64 rows x 128 columns -> registers (4 x 16 B per thread of 256), rows >= nvalid read as zero
-__device__ __forceinline__ void fa_load_tile(uint4 (&r)[4], const bf16_t* base, int64_t ld, int row0, int N, int tid) {
+// 64 rows x 128 columns -> registers (1024 / NTHR x 16 B per thread), rows >= N read as zero
+template <int NTHR>
+__device__ __forceinline__ void fa_load_tile(uint4 (&r)[1024 / NTHR], const bf16_t* base, int64_t ld, int row0, int N, int tid) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
+  for (int it = 0; it < 1024 / NTHR; ++it) {
+    int idx = tid + NTHR * it, row = idx >> 4, ch = idx & 15;
     int gr = row0 + row;
     r[it] = make_uint4(0, 0, 0, 0);
     if (gr < N) r[it] = *reinterpret_cast<const uint4*>(base + (int64_t)gr * ld + ch * 8);
   }
 }
-__device__ __forceinline__ void fa_store_tile(char* lds, const uint4 (&r)[4], int tid) {
+template <int NTHR>
+__device__ __forceinline__ void fa_store_tile(char* lds, const uint4 (&r)[1024 / NTHR], int tid) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
+  for (int it = 0; it < 1024 / NTHR; ++it) {
+    int idx = tid + NTHR * it, row = idx >> 4, ch = idx & 15;
     *reinterpret_cast<uint4*>(lds + fa_off(row, ch)) = r[it];
   }
 }
@@ -89,66 +91,79 @@ __device__ __forceinline__ int fa_tile_row(int t, int i) { return 32 * (t >> 1) 
 // recomputing backward exact - delta = sum_d dO*O (from the fp32 copy of O) equals sum_k P dP, so the rows of dS sum to zero as
 // they do in exact arithmetic; with single-bf16 probabilities delta carries a per-row error of relative size 2^-9 that is
 // correlated over the keys and shows up 1.5x in dQ / dK (measured against fp64).  Cost: 32 extra MFMAs per 64 in the key loop.
-__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const FlashParams p) {
+template <int QT, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void flash_fwd_kernel(const FlashParams p) {
+  constexpr int NTHR = 64 * NW;             // QT = 16-query column tiles per wave, NW waves: 16*QT*NW queries per workgroup
   __shared__ __attribute__((aligned(16))) char lds_k[64 * 256];
   __shared__ __attribute__((aligned(16))) char lds_v[64 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   const int b = blockIdx.z, h = blockIdx.y, N = p.N;
   const int64_t ioff = (int64_t)b * N * p.ld + h * 128;
   const bf16_t *qb = p.q + ioff, *kb = p.k + ioff, *vb = p.v + ioff;
-  const int q0 = blockIdx.x * 128 + wv * 32;
+  const int q0 = blockIdx.x * (16 * QT * NW) + wv * 16 * QT;
 
-  bf16x8_t qf[2][4];
+  bf16x8_t qf[QT][4];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = fa_gload(qb, p.ld, q0 + qt * 16 + li, N, ks * 32 + 8 * g);
 
-  f32x4_t o[8][2];
+  f32x4_t o[8][QT];
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) o[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float m[2] = {FA_NEG, FA_NEG}, l[2] = {0.f, 0.f};
+    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m[QT], l[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) { m[qt] = FA_NEG; l[qt] = 0.f; }
 
   const int ntiles = (N + 63) >> 6;
-  uint4 rk[4], rv[4];
-  fa_load_tile(rk, kb, p.ld, 0, N, tid);
-  fa_load_tile(rv, vb, p.ld, 0, N, tid);
-  fa_store_tile(lds_k, rk, tid);
-  fa_store_tile(lds_v, rv, tid);
+  uint4 rk[1024 / NTHR], rv[1024 / NTHR];
+  fa_load_tile<NTHR>(rk, kb, p.ld, 0, N, tid);
+  fa_load_tile<NTHR>(rv, vb, p.ld, 0, N, tid);
+  fa_store_tile<NTHR>(lds_k, rk, tid);
+  fa_store_tile<NTHR>(lds_v, rv, tid);
   __syncthreads();
   for (int j = 0; j < ntiles; ++j) {
     const bool more = j + 1 < ntiles;
     if (more) {
-      fa_load_tile(rk, kb, p.ld, (j + 1) * 64, N, tid);
-      fa_load_tile(rv, vb, p.ld, (j + 1) * 64, N, tid);
+      fa_load_tile<NTHR>(rk, kb, p.ld, (j + 1) * 64, N, tid);
+      fa_load_tile<NTHR>(rv, vb, p.ld, (j + 1) * 64, N, tid);
     }
-    f32x4_t st[4][2];
+    f32x4_t st[4][QT];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      st[kt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      st[kt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) st[kt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const int krow = fa_tile_row(kt, li);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8_t kf = fa_row(lds_k, krow, ks, g);
-        st[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], st[kt][0], 0, 0, 0);
-        st[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], st[kt][1], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[kt][qt], 0, 0, 0);
       }
     }
     // lane holds keys j*64 + 32*(kt>>1) + 8g + 4*(kt&1) + r of query column qt*16 + li
     const bool tail = (j + 1) * 64 > N;
-    bf16x8_t ph[2][2], pl[2][2];
+    bf16x8_t ph[2][QT], pl[2][QT];
+    if (tail) {           // keys past N (last tile only): a uniform branch, not a select per element in every tile
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j * 64 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= N) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) st[kt][qt][r] = FA_NEG;
+          }
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
       float mx = FA_NEG;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float s = st[kt][qt][r] * p.scale_log2;
-          if (tail && j * 64 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= N) s = FA_NEG;
           st[kt][qt][r] = s;
           mx = fmaxf(mx, s);
         }
@@ -181,21 +196,22 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const FlashParams p) 
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         bf16x8_t vf = fa_tr(lds_v, c, dt, g, tq, tp);
-        o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph[c][0], o[dt][0], 0, 0, 0);
-        o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph[c][1], o[dt][1], 0, 0, 0);
-        o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl[c][0], o[dt][0], 0, 0, 0);
-        o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl[c][1], o[dt][1], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph[c][qt], o[dt][qt], 0, 0, 0);
+          o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl[c][qt], o[dt][qt], 0, 0, 0);
+        }
       }
     __syncthreads();
     if (more) {
-      fa_store_tile(lds_k, rk, tid);
-      fa_store_tile(lds_v, rv, tid);
+      fa_store_tile<NTHR>(lds_k, rk, tid);
+      fa_store_tile<NTHR>(lds_v, rv, tid);
     }
     __syncthreads();
   }
   // lane holds O[d = 16*dt + 4g + r][q = qt*16 + li]
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     float lt = l[qt];
     lt += __shfl_xor(lt, 16);
     lt += __shfl_xor(lt, 32);
@@ -222,20 +238,22 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const FlashParams p) 
 
 // ------------------------------------------------------------------------------------------------------------ backward: dQ
 // Same tiling as the forward.  Also writes delta[q] = sum_d dO[q][d] * O[q][d] for the dK/dV kernel (which runs after it).
-__global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashParams p) {
+template <int QT, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void flash_bwd_dq_kernel(const FlashParams p) {
+  constexpr int NTHR = 64 * NW;
   __shared__ __attribute__((aligned(16))) char lds_k[64 * 256];
   __shared__ __attribute__((aligned(16))) char lds_v[64 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   const int b = blockIdx.z, h = blockIdx.y, N = p.N;
   const int64_t ioff = (int64_t)b * N * p.ld + h * 128, ooff = (int64_t)b * N * p.ldo + h * 128;
   const bf16_t *qb = p.q + ioff, *kb = p.k + ioff, *vb = p.v + ioff, *ob = p.o + ooff, *dob = p.d_o + ooff;
-  const int q0 = blockIdx.x * 128 + wv * 32;
+  const int q0 = blockIdx.x * (16 * QT * NW) + wv * 16 * QT;
   const int64_t srow = ((int64_t)b * p.H + h) * N;
 
-  bf16x8_t qf[2][4], dof[2][4];
-  float lse[2], delta[2];
+  bf16x8_t qf[QT][4], dof[QT][4];
+  float lse[QT], delta[QT];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int q = q0 + qt * 16 + li;
     float dsum = 0.f;
 #pragma unroll
@@ -262,47 +280,49 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashParams 
     if (g == 0 && q < N) p.delta[srow + q] = dsum;
   }
 
-  f32x4_t acc[8][2];
+  f32x4_t acc[8][QT];
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) acc[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (N + 63) >> 6;
-  uint4 rk[4], rv[4];
-  fa_load_tile(rk, kb, p.ld, 0, N, tid);
-  fa_load_tile(rv, vb, p.ld, 0, N, tid);
-  fa_store_tile(lds_k, rk, tid);
-  fa_store_tile(lds_v, rv, tid);
+  uint4 rk[1024 / NTHR], rv[1024 / NTHR];
+  fa_load_tile<NTHR>(rk, kb, p.ld, 0, N, tid);
+  fa_load_tile<NTHR>(rv, vb, p.ld, 0, N, tid);
+  fa_store_tile<NTHR>(lds_k, rk, tid);
+  fa_store_tile<NTHR>(lds_v, rv, tid);
   __syncthreads();
   for (int j = 0; j < ntiles; ++j) {
     const bool more = j + 1 < ntiles;
     if (more) {
-      fa_load_tile(rk, kb, p.ld, (j + 1) * 64, N, tid);
-      fa_load_tile(rv, vb, p.ld, (j + 1) * 64, N, tid);
+      fa_load_tile<NTHR>(rk, kb, p.ld, (j + 1) * 64, N, tid);
+      fa_load_tile<NTHR>(rv, vb, p.ld, (j + 1) * 64, N, tid);
     }
     const bool tail = (j + 1) * 64 > N;
-    bf16x8_t dsb[2][2];
+    bf16x8_t dsb[2][QT];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      f32x4_t st[2][2], dp[2][2];
+      f32x4_t st[2][QT], dp[2][QT];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int kt = 2 * c + t;
-        st[t][0] = st[t][1] = dp[t][0] = dp[t][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) st[t][qt] = dp[t][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const int krow = fa_tile_row(kt, li);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           bf16x8_t kf = fa_row(lds_k, krow, ks, g);
           bf16x8_t vf = fa_row(lds_v, krow, ks, g);
-          st[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], st[t][0], 0, 0, 0);
-          st[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], st[t][1], 0, 0, 0);
-          dp[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[0][ks], dp[t][0], 0, 0, 0);
-          dp[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[1][ks], dp[t][1], 0, 0, 0);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            st[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[t][qt], 0, 0, 0);
+            dp[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt][ks], dp[t][qt], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -319,18 +339,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashParams 
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         bf16x8_t kf = fa_tr(lds_k, c, dt, g, tq, tp);
-        acc[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsb[c][0], acc[dt][0], 0, 0, 0);
-        acc[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsb[c][1], acc[dt][1], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsb[c][qt], acc[dt][qt], 0, 0, 0);
       }
     __syncthreads();
     if (more) {
-      fa_store_tile(lds_k, rk, tid);
-      fa_store_tile(lds_v, rv, tid);
+      fa_store_tile<NTHR>(lds_k, rk, tid);
+      fa_store_tile<NTHR>(lds_v, rv, tid);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int q = q0 + qt * 16 + li;
     if (q < N) {
       bf16_t* orow = p.out + ((int64_t)b * N + q) * p.ld_out + h * 128;
@@ -347,7 +367,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashParams 
 
 // -------------------------------------------------------------------------------------------------------- backward: dK, dV
 // grid (ceil(N/128), H, B): wave w owns keys k0 + 32w .. +31 (two 16-key column tiles) and walks all query tiles of 64.
-__global__ __launch_bounds__(256, 1) void flash_bwd_dkv_kernel(const FlashParams p) {
+template <int KT, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void flash_bwd_dkv_kernel(const FlashParams p) {
+  constexpr int NTHR = 64 * NW;
   __shared__ __attribute__((aligned(16))) char lds_q[64 * 256];
   __shared__ __attribute__((aligned(16))) char lds_do[64 * 256];
   __shared__ __attribute__((aligned(16))) float lds_lse[64], lds_delta[64];
@@ -355,25 +377,25 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkv_kernel(const FlashParams
   const int b = blockIdx.z, h = blockIdx.y, N = p.N;
   const int64_t ioff = (int64_t)b * N * p.ld + h * 128, ooff = (int64_t)b * N * p.ldo + h * 128;
   const bf16_t *qb = p.q + ioff, *kb = p.k + ioff, *vb = p.v + ioff, *dob = p.d_o + ooff;
-  const int k0 = blockIdx.x * 128 + wv * 32;
+  const int k0 = blockIdx.x * (16 * KT * NW) + wv * 16 * KT;
   const int64_t srow = ((int64_t)b * p.H + h) * N;
 
-  bf16x8_t kf[2][4], vf[2][4];
+  bf16x8_t kf[KT][4], vf[KT][4];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       kf[kt][ks] = fa_gload(kb, p.ld, k0 + kt * 16 + li, N, ks * 32 + 8 * g);
       vf[kt][ks] = fa_gload(vb, p.ld, k0 + kt * 16 + li, N, ks * 32 + 8 * g);
     }
-  f32x4_t adv[8][2], adk[8][2];
+  f32x4_t adv[8][KT], adk[8][KT];
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) adv[dt][kt] = adk[dt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt) adv[dt][kt] = adk[dt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (N + 63) >> 6;
-  uint4 rq[4], rd[4];
+  uint4 rq[1024 / NTHR], rd[1024 / NTHR];
   float rl = 0.f, rdl = 0.f;
   auto load_stats = [&](int row0) {
     if (tid < 64) {
@@ -382,38 +404,40 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkv_kernel(const FlashParams
       rdl = q < N ? p.delta[srow + q] : 0.f;
     }
   };
-  fa_load_tile(rq, qb, p.ld, 0, N, tid);
-  fa_load_tile(rd, dob, p.ldo, 0, N, tid);
+  fa_load_tile<NTHR>(rq, qb, p.ld, 0, N, tid);
+  fa_load_tile<NTHR>(rd, dob, p.ldo, 0, N, tid);
   load_stats(0);
-  fa_store_tile(lds_q, rq, tid);
-  fa_store_tile(lds_do, rd, tid);
+  fa_store_tile<NTHR>(lds_q, rq, tid);
+  fa_store_tile<NTHR>(lds_do, rd, tid);
   if (tid < 64) { lds_lse[tid] = rl; lds_delta[tid] = rdl; }
   __syncthreads();
   for (int j = 0; j < ntiles; ++j) {
     const bool more = j + 1 < ntiles;
     if (more) {
-      fa_load_tile(rq, qb, p.ld, (j + 1) * 64, N, tid);
-      fa_load_tile(rd, dob, p.ldo, (j + 1) * 64, N, tid);
+      fa_load_tile<NTHR>(rq, qb, p.ld, (j + 1) * 64, N, tid);
+      fa_load_tile<NTHR>(rd, dob, p.ldo, (j + 1) * 64, N, tid);
       load_stats((j + 1) * 64);
     }
     const bool tail = (j + 1) * 64 > N;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       // two 16-query row tiles (t = 0, 1) of chunk c: lane holds queries 32c + 8g + 4t + r, key column kt*16 + li
-      f32x4_t st[2][2], dp[2][2];
-      bf16x8_t pbf[2], dsb[2];
+      f32x4_t st[2][KT], dp[2][KT];
+      bf16x8_t pbf[KT], dsb[KT];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        st[t][0] = st[t][1] = dp[t][0] = dp[t][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) st[t][kt] = dp[t][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const int qrow = fa_tile_row(2 * c + t, li);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           bf16x8_t qa = fa_row(lds_q, qrow, ks, g);
           bf16x8_t da = fa_row(lds_do, qrow, ks, g);
-          st[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[0][ks], st[t][0], 0, 0, 0);
-          st[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[1][ks], st[t][1], 0, 0, 0);
-          dp[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[0][ks], dp[t][0], 0, 0, 0);
-          dp[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[1][ks], dp[t][1], 0, 0, 0);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], st[t][kt], 0, 0, 0);
+            dp[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[t][kt], 0, 0, 0);
+          }
         }
       }
       f32x4_t lq[2], dq[2];
@@ -423,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkv_kernel(const FlashParams
         dq[t] = *reinterpret_cast<const f32x4_t*>(&lds_delta[32 * c + 8 * g + 4 * t]);
       }
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+      for (int kt = 0; kt < KT; ++kt) {
         f32x4_t pt[2], dt_[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -441,23 +465,24 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkv_kernel(const FlashParams
       for (int dt = 0; dt < 8; ++dt) {
         bf16x8_t dot = fa_tr(lds_do, c, dt, g, tq, tp);
         bf16x8_t qt_ = fa_tr(lds_q, c, dt, g, tq, tp);
-        adv[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pbf[0], adv[dt][0], 0, 0, 0);
-        adv[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pbf[1], adv[dt][1], 0, 0, 0);
-        adk[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsb[0], adk[dt][0], 0, 0, 0);
-        adk[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsb[1], adk[dt][1], 0, 0, 0);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          adv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pbf[kt], adv[dt][kt], 0, 0, 0);
+          adk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsb[kt], adk[dt][kt], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
     if (more) {
-      fa_store_tile(lds_q, rq, tid);
-      fa_store_tile(lds_do, rd, tid);
+      fa_store_tile<NTHR>(lds_q, rq, tid);
+      fa_store_tile<NTHR>(lds_do, rd, tid);
       if (tid < 64) { lds_lse[tid] = rl; lds_delta[tid] = rdl; }
     }
     __syncthreads();
   }
   // lane holds dV[key = k0 + kt*16 + li][d = 16*dt + 4g + r]
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
+  for (int kt = 0; kt < KT; ++kt) {
     const int key = k0 + kt * 16 + li;
     if (key < N) {
       bf16_t* krow = p.dk + ((int64_t)b * N + key) * p.ld_out + h * 128;
@@ -477,6 +502,15 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkv_kernel(const FlashParams
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
+// Tiling (USSEG_FLASH_TILE, default automatic): 1 = 8 waves x 16 queries (keys), 128 per workgroup - two waves per SIMD, the VALU
+// softmax of one overlapping the MFMAs of the other (the kernels are VALU- and LDS-bound at head size 128): 44 / 118 us forward /
+// backward at 8 x 1024 tokens x 4 heads against 70 / 144 us for 2 = 4 waves x 32; 0 = 4 waves x 16, 64 per workgroup, when 128-query
+// workgroups would not fill the 256 CUs (16 images x 256 tokens: 13.8 / 30.5 us against 16.5 / 36.5).
+static int fa_variant(const UssegFlashDesc* d) {
+  static const int v = getenv("USSEG_FLASH_TILE") ? atoi(getenv("USSEG_FLASH_TILE")) : -1;
+  if (v >= 0) return v;
+  return (int64_t)d->B * d->H * ((d->N + 127) / 128) >= 256 ? 1 : 0;
+}
 static int fa_check(const UssegFlashDesc* d) {
   USSEG_CHECK_ARG(d != nullptr, "null descriptor");
   USSEG_CHECK_ARG(d->head_dim == 128, "fused attention is built for head size 128 (got %d)", d->head_dim);
@@ -499,8 +533,9 @@ extern "C" int usseg_flash_attn_fwd(const UssegFlashDesc* d, const void* q, cons
   USSEG_CHECK_ARG(q && k && v && o && lse, "null operand");
   FlashParams p = fa_params(d, q, k, v);
   p.out = (bf16_t*)o; p.ld_out = d->ld_o; p.lse = lse; p.o32 = o32;
-  dim3 grid((d->N + 127) / 128, d->H, d->B);
-  hipLaunchKernelGGL(flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  const int tv = fa_variant(d);
+#define FA_LAUNCH(K_, QT_, NW_) hipLaunchKernelGGL((K_<QT_, NW_>), dim3((d->N + 16 * QT_ * NW_ - 1) / (16 * QT_ * NW_), d->H, d->B), dim3(64 * NW_), 0, (hipStream_t)stream, p)
+  if (tv == 2) FA_LAUNCH(flash_fwd_kernel, 2, 4); else if (tv == 1) FA_LAUNCH(flash_fwd_kernel, 1, 8); else FA_LAUNCH(flash_fwd_kernel, 1, 4);
   return usseg_check_launch("flash_attn_fwd");
 }
 
@@ -511,9 +546,9 @@ extern "C" int usseg_flash_attn_bwd(const UssegFlashDesc* d, const void* q, cons
   FlashParams p = fa_params(d, q, k, v);
   p.o = (const bf16_t*)o; p.d_o = (const bf16_t*)d_o; p.lse = const_cast<float*>(lse); p.delta = delta; p.o32 = const_cast<float*>(o32);
   p.out = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.ld_out = d->ld_qkv;
-  dim3 grid((d->N + 127) / 128, d->H, d->B);
-  hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  const int tv = fa_variant(d);
+  if (tv == 2) FA_LAUNCH(flash_bwd_dq_kernel, 2, 4); else if (tv == 1) FA_LAUNCH(flash_bwd_dq_kernel, 1, 8); else FA_LAUNCH(flash_bwd_dq_kernel, 1, 4);
   if (int e = usseg_check_launch("flash_attn_bwd_dq")) return e;
-  hipLaunchKernelGGL(flash_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (tv == 2) FA_LAUNCH(flash_bwd_dkv_kernel, 2, 4); else if (tv == 1) FA_LAUNCH(flash_bwd_dkv_kernel, 1, 8); else FA_LAUNCH(flash_bwd_dkv_kernel, 1, 4);
   return usseg_check_launch("flash_attn_bwd_dkv");
 }
