@@ -19,7 +19,7 @@ fetch, nf = load(sys.argv[1], "FETCH_SIZE")
 write, nw = load(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3])
 arch = sys.argv[5] if len(sys.argv) > 5 else "B"
-batch = int(sys.argv[6]) if len(sys.argv) > 6 else {"B": 16, "A": 32, "T": 8}[arch]
+batch = int(sys.argv[6]) if len(sys.argv) > 6 else {"B": 16, "A": 32, "T": 8, "S": 16}[arch]
 fam = lambda k: k.startswith("igemm") or k.startswith("conv_halo") or k.startswith("conv_big") or k.startswith("conv_stream")
 out = {"arch": arch, "per_gpu_batch": batch, "hw": 256, "steps_profiled": steps, "kernels": {}}
 cb = cl = 0.0

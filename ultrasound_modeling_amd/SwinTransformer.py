@@ -69,11 +69,18 @@ class LayerNorm(nn.Module):
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
 
+    # Up to 512 channels the packed per-pixel LayerNorm of the conv path runs (several token rows per wave: at 96 channels a
+    # one-row-per-wave kernel keeps 12 of 64 lanes busy); wider rows (the merged 4C tokens, stage 4) use the wide kernel.
     def forward(self, x):
         self._x = x
+        if self.C <= 512:
+            return ops.norm_act_fwd(x, self.C, self.gamma.data, self.beta.data, torch.empty_like(x), 0, 1, self.eps)
         return ops.ln_wide_fwd(x, self.gamma.data, self.beta.data, self.eps, torch.empty_like(x))
 
     def backward(self, dy):
+        if self.C <= 512:
+            return ops.norm_act_bwd(self._x, dy, self.C, self.gamma.data, self.beta.data, torch.empty_like(self._x), self.gamma.grad, self.beta.grad,
+                                    0, 1, self.eps)
         return ops.ln_wide_bwd(self._x, dy, self.gamma.data, self.eps, torch.empty_like(self._x), self.gamma.grad, self.beta.grad)
 
 
