@@ -197,6 +197,9 @@ typedef struct UssegPackJob {
                           bias + activation epilogue with bias' = beta - mean*scale + scale*bias) */
 } UssegPackJob;
 int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t njobs, usseg_stream_t stream);
+/* Same packs, flat grid: tilemap = nblocks triples (job index, first 32x32 tile of that job, tile count) that cover every tile of
+ * every job exactly once (tiles of a job are numbered tap-major, then 32-row blocks of n, then 32-column blocks of k). */
+int usseg_pack_weights_flat(const UssegPackJob* jobs_dev, const int32_t* tilemap_dev, int32_t nblocks, usseg_stream_t stream);
 int usseg_unpack_wgrad(const float* scratch, int32_t Mrows, int32_t Ncols, int32_t T, int32_t Nn, int32_t Kk,
                        int32_t n_off, int32_t k_off, float* dst, int64_t sT, int64_t sN, int64_t sK,
                        float scale, int32_t accumulate, usseg_stream_t stream);

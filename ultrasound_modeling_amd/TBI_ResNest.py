@@ -310,7 +310,8 @@ class _ResModel(nn.Module):
         table = getattr(self, "_pack_table", None)
         if table is None:
             jobs = self.pack_jobs()
-            table = (ops.make_pack_table(jobs, next(self.parameters()).device), len(jobs))
+            dev = next(self.parameters()).device
+            table = (ops.make_pack_table(jobs, dev), len(jobs), ops.make_pack_tilemap(jobs, dev))
             object.__setattr__(self, "_pack_table", table)
         ops.pack_weights_batched(*table)
 

@@ -54,11 +54,12 @@ def repack_all(root: nn.Module):
         for m in root.modules():
             if isinstance(m, (ResNest, DecoderBlock)):
                 folds += m.bn_fold_jobs()
-        table = (ops.make_pack_table(jobs, dev), len(jobs), ops.make_bn_fold_table(folds, dev) if folds else None, len(folds))
+        table = (ops.make_pack_table(jobs, dev), len(jobs), ops.make_bn_fold_table(folds, dev) if folds else None, len(folds),
+                 ops.make_pack_tilemap(jobs, dev))
         object.__setattr__(root, "_pack_table", table)
     if table[3] and (_DEC._FOLD_BN or _ENC._FOLD_BN):
         ops.bn_fold_batched(table[2], table[3])     # folded inference BatchNorm constants FIRST: the packs below multiply them in
-    ops.pack_weights_batched(table[0], table[1])
+    ops.pack_weights_batched(table[0], table[1], table[4])
 
 
 class Embeddings(nn.Module):

@@ -112,6 +112,7 @@ _PROTOS = {
     "usseg_tconv2d_wgrad": (C.c_int, [P(ConvDesc), c_vp, c_vp, c_vp, c_vp]),
     "usseg_pack_weight": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "usseg_pack_weights_batched": (C.c_int, [c_vp, c_i32, c_vp]),
+    "usseg_pack_weights_flat": (C.c_int, [c_vp, c_vp, c_i32, c_vp]),
     "usseg_unpack_wgrad": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_i64,
                                      c_f32, c_i32, c_vp]),
     "usseg_unpack_wgrad_batched": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),

@@ -1083,19 +1083,24 @@ extern "C" int usseg_unpack_wgrad_batched(const UssegUnpackJob* jobs_dev, int32_
 }
 
 // ---- all operand packs of a model in ONE launch: blockIdx.y = job ---------------------------------------------
-__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const UssegPackJob* jobs) {
+// FLAT: blockIdx.x indexes a host-built (job, first tile, tile count) list covering every 32x32 tile of every job exactly once - no
+// empty workgroups (the 512 x njobs grid of the other form launches 87 000 workgroups for 12 000 tiles on Arch B).
+template <bool FLAT>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const UssegPackJob* jobs, const int32_t* tilemap) {
   // A pack is a (strided) transpose: 32x32 tiles through LDS, read along whichever of (n, k) is the faster source axis,
   // written along k (the destination's contiguous axis).  The element-per-thread version read the Keras [k,k,Cin,Cout]
   // variable with a stride of Cout floats per lane for one of the two operand layouts (0.8 TB/s on Arch A's 31 M parameters).
-  const UssegPackJob j = jobs[blockIdx.y];
+  const UssegPackJob j = jobs[FLAT ? tilemap[3 * blockIdx.x] : blockIdx.y];
   const int tilesN = (j.Nn + 31) >> 5, tilesK = (j.Kk + 31) >> 5;
-  const int ntile = j.T * tilesN * tilesK;
-  if ((int)blockIdx.x >= ntile) return;          // the grid is sized for the largest job
+  const int id_begin = FLAT ? tilemap[3 * blockIdx.x + 1] : (int)blockIdx.x;
+  const int ntile = FLAT ? id_begin + tilemap[3 * blockIdx.x + 2] : j.T * tilesN * tilesK;
+  const int id_step = FLAT ? 1 : (int)gridDim.x;
+  if (id_begin >= ntile) return;          // (grid form: sized for the largest job)
   __shared__ float tile[32][33];
   bf16_t* const dst = reinterpret_cast<bf16_t*>(j.dst);
   const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
   const bool k_fast = j.sK <= j.sN;
-  for (int id = blockIdx.x; id < ntile; id += gridDim.x) {
+  for (int id = id_begin; id < ntile; id += id_step) {
     const int t = id / (tilesN * tilesK), r = id - t * (tilesN * tilesK);
     const int n0 = (r / tilesK) << 5, k0 = (r % tilesK) << 5;
 #pragma unroll
@@ -1121,8 +1126,13 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const UssegPa
 extern "C" int usseg_pack_weights_batched(const UssegPackJob* jobs_dev, int32_t njobs, usseg_stream_t stream) {
   USSEG_CHECK_ARG(jobs_dev && njobs > 0 && njobs < 65536, "pack_weights_batched: bad args");
   // 512 x njobs workgroups; a workgroup past its job's last 32x32 tile exits at once, the others stride over the tiles
-  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(512, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  hipLaunchKernelGGL(pack_weights_batched_kernel<false>, dim3(512, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, nullptr);
   return usseg_check_launch("pack_weights_batched");
+}
+extern "C" int usseg_pack_weights_flat(const UssegPackJob* jobs_dev, const int32_t* tilemap_dev, int32_t nblocks, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(jobs_dev && tilemap_dev && nblocks > 0, "pack_weights_flat: bad args");
+  hipLaunchKernelGGL(pack_weights_batched_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, tilemap_dev);
+  return usseg_check_launch("pack_weights_flat");
 }
 
 // ---- the stride-2 3x3 head as a 2x2-tap convolution producing its four output parities as 16 channels ("quad" form):

@@ -396,7 +396,23 @@ def bn_fold_batched(table: torch.Tensor, njobs: int):
     L.check(L.load().usseg_bn_fold_batched(table.data_ptr(), njobs, _stream()), "bn_fold_batched")
 
 
-def pack_weights_batched(table: torch.Tensor, njobs: int):
+def make_pack_tilemap(jobs, device, tiles_per_block: int = 4):
+    """(job, first tile, count) triples covering every 32x32 tile of every pack job once -> (int32 device tensor, nblocks)."""
+    import numpy as np
+    trip = []
+    for ji, job in enumerate(jobs):
+        T, Nn, Kk = job[5], job[6], job[7]
+        n = T * ((Nn + 31) // 32) * ((Kk + 31) // 32)
+        for t0 in range(0, n, tiles_per_block):
+            trip.append((ji, t0, min(tiles_per_block, n - t0)))
+    arr = np.array(trip, dtype=np.int32).reshape(-1)
+    return torch.from_numpy(arr).to(device), len(trip)
+
+
+def pack_weights_batched(table: torch.Tensor, njobs: int, tilemap=None):
+    if tilemap is not None:
+        L.check(L.load().usseg_pack_weights_flat(table.data_ptr(), tilemap[0].data_ptr(), tilemap[1], _stream()), "pack_weights_flat")
+        return
     L.check(L.load().usseg_pack_weights_batched(table.data_ptr(), njobs, _stream()), "pack_weights_batched")
 
 
