@@ -601,7 +601,9 @@ extern "C" int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* l
   USSEG_CHECK_ARG(d->loss_kind == 0 || (d->loss_kind == 1 && scale), "loss_kind 1 needs scale");
   if (d->M <= 0) return USSEG_OK;
   USSEG_CHECK_ARG(d->HW > 0 && d->M % d->HW == 0, "softmax_loss: M must be a multiple of HW");
-  int64_t g = (y_true && d->loss_kind == 1) ? cdiv64(d->HW, 256) : cdiv64(d->M, 256 * 4);
+  // one pixel per thread up to the 2048 slots of the ordered sum (the per-pixel chain of dependent loads is latency-bound: 4 pixels per
+  // thread on 1024 workgroups took 36 us for 50 MB)
+  int64_t g = (y_true && d->loss_kind == 1) ? cdiv64(d->HW, 256) : cdiv64(d->M, 256);
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(softmax_loss_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *d, logits, y_true, scale, probs, loss,
                      (bf16_t*)dlogits);
