@@ -498,38 +498,41 @@ extern "C" int usseg_splitattn_apply_bwd_dy(const UssegSplitAttnDesc* d, const v
 
 // ------------------------------------------------------------------------------------------ head softmax + loss
 // One pixel: softmax, probabilities out, loss term (returned) and d(sum loss)/d logits.
-__device__ __forceinline__ float softmax_loss_pixel(const UssegLossDesc& d, int64_t m, const float* logits, const float* y_true,
-                                                    const float* scale, float* probs, bf16_t* dlogits) {
-  const int C = d.C;
+// CC = compile-time class count (0 = read d.C): with a run-time C the per-class register arrays are indexed through select chains
+// (600 v_cndmask + 480 s_cselect in the ISA, 36 us for 1M pixels); the reference's 3 classes get the unrolled form.
+template <int CC>
+__device__ __forceinline__ float softmax_loss_pixel(const UssegLossDesc& d, int b, int hw, const float* __restrict__ logits,
+                                                    const float* __restrict__ y_true, const float* __restrict__ scale, float* __restrict__ probs,
+                                                    bf16_t* __restrict__ dlogits) {
+  const int C = CC ? CC : d.C;
+  const int64_t m = (int64_t)b * d.HW + hw;      // (image, pixel) come from the grid: no 64-bit division per pixel
   float z[8], p[8], yt[8];
   float mx = -INFINITY;
   // quad (space-to-depth) layout of the head's output and its gradient: pixel (y, x) of the full-resolution map lives in
   // slot 4*((y&1)*2 + (x&1)) of the 16-channel pixel (y/2, x/2) - what the 2x2-tap form of the stride-2 head produces
   int64_t lbase = m * d.ldl, dbase = m * d.lddl;
   if (d.quad_w) {
-    const int hw = (int)(m % d.HW);
-    const int64_t b = m / d.HW;
-    const int y = hw / d.quad_w, x = hw - y * d.quad_w;
+    const int y = (d.quad_w & (d.quad_w - 1)) == 0 ? hw >> (31 - __clz(d.quad_w)) : hw / d.quad_w, x = hw - y * d.quad_w;
     const int64_t q = (b * (d.HW / d.quad_w / 2) + (y >> 1)) * (d.quad_w / 2) + (x >> 1);
     const int slot = 4 * ((y & 1) * 2 + (x & 1));
     lbase = q * d.ldl + slot;
     dbase = q * d.lddl + slot;
   }
-  for (int c = 0; c < C; ++c) { z[c] = logits[lbase + c]; mx = fmaxf(mx, z[c]); }
+  _Pragma("unroll") for (int c = 0; c < C; ++c) { z[c] = logits[lbase + c]; mx = fmaxf(mx, z[c]); }
   float sum = 0.f;
-  for (int c = 0; c < C; ++c) { p[c] = __expf(z[c] - mx); sum += p[c]; }
+  _Pragma("unroll") for (int c = 0; c < C; ++c) { p[c] = __expf(z[c] - mx); sum += p[c]; }
   float inv = 1.f / sum;
-  for (int c = 0; c < C; ++c) { p[c] *= inv; probs[m * C + c] = p[c]; }
+  _Pragma("unroll") for (int c = 0; c < C; ++c) { p[c] *= inv; probs[m * C + c] = p[c]; }
   if (!y_true) return 0.f;
-  for (int c = 0; c < C; ++c) yt[c] = y_true[m * C + c];
+  _Pragma("unroll") for (int c = 0; c < C; ++c) yt[c] = y_true[m * C + c];
   float dLdp[8];
   float l = 0.f;
   if (d.loss_kind == 0) {
     // CategoricalCrossentropy(label_smoothing) on probabilities (VisionTransformer.py:205)
     float S = 0.f;
-    for (int c = 0; c < C; ++c) S += p[c];
+    _Pragma("unroll") for (int c = 0; c < C; ++c) S += p[c];
     float u[8], ubar = 0.f;
-    for (int c = 0; c < C; ++c) {
+    _Pragma("unroll") for (int c = 0; c < C; ++c) {
       float ys = yt[c] * (1.f - d.label_smoothing) + d.label_smoothing / (float)C;
       float q = p[c] / S;
       float qc = fminf(fmaxf(q, d.clip_eps), 1.f - d.clip_eps);
@@ -538,11 +541,10 @@ __device__ __forceinline__ float softmax_loss_pixel(const UssegLossDesc& d, int6
       ubar += u[c] * q;
     }
     l *= d.inv_global_batch;
-    for (int c = 0; c < C; ++c) dLdp[c] = (u[c] - ubar) / S * d.inv_global_batch;
+    _Pragma("unroll") for (int c = 0; c < C; ++c) dLdp[c] = (u[c] - ubar) / S * d.inv_global_batch;
   } else {
     // my_loss_cat (TBI_ResNest.py:234-248): -sum_b y*log(p+1e-7)*scale[hw][c]; the [H,W] map is summed for the gradient
-    const int hw = (int)(m % d.HW);
-    for (int c = 0; c < C; ++c) {
+    _Pragma("unroll") for (int c = 0; c < C; ++c) {
       float sc = scale[(int64_t)hw * C + c];
       l -= yt[c] * __logf(p[c] + 1e-7f) * sc;
       dLdp[c] = -yt[c] * sc / (p[c] + 1e-7f);
@@ -550,7 +552,7 @@ __device__ __forceinline__ float softmax_loss_pixel(const UssegLossDesc& d, int6
   }
   if (dlogits) {
     float dot = 0.f;
-    for (int c = 0; c < C; ++c) dot += dLdp[c] * p[c];
+    _Pragma("unroll") for (int c = 0; c < C; ++c) dot += dLdp[c] * p[c];
     float o[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) o[c] = (c < C) ? p[c] * (dLdp[c] - dot) : 0.f;
@@ -567,26 +569,36 @@ __device__ __forceinline__ float softmax_loss_pixel(const UssegLossDesc& d, int6
 
 // Reproducible reductions: loss_kind 0 sums the workgroup totals in workgroup order (grid_ordered_sum, loss = [USSEG_ACC_FLOATS]);
 // loss_kind 1 gives every pixel of the [H,W] map to ONE thread that walks the batch in order (no atomics on the map).
-__global__ __launch_bounds__(256) void softmax_loss_kernel(const UssegLossDesc d, const float* logits, const float* y_true, const float* scale,
-                                                            float* probs, float* loss, bf16_t* dlogits) {
+template <int CC>
+__global__ __launch_bounds__(256) void softmax_loss_kernel(const UssegLossDesc d, const float* __restrict__ logits, const float* __restrict__ y_true,
+                                                            const float* __restrict__ scale, float* __restrict__ probs, float* loss,
+                                                            bf16_t* __restrict__ dlogits) {
   __shared__ float red[4];
   if (d.loss_kind == 1 && y_true) {
     const int nb = (int)(d.M / d.HW);
     for (int64_t hw = (int64_t)blockIdx.x * 256 + threadIdx.x; hw < d.HW; hw += (int64_t)gridDim.x * 256) {
       float l = 0.f;
-      for (int b = 0; b < nb; ++b) l += softmax_loss_pixel(d, (int64_t)b * d.HW + hw, logits, y_true, scale, probs, dlogits);
+      for (int b = 0; b < nb; ++b) l += softmax_loss_pixel<CC>(d, b, (int)hw, logits, y_true, scale, probs, dlogits);
       loss[hw] = l;
     }
     return;
   }
+  // grid (pixel blocks, images); four independent pixels in flight per thread (the per-pixel chain of dependent loads is latency-bound)
   float lsum = 0.f;
-  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < d.M; m += (int64_t)gridDim.x * 256)
-    lsum += softmax_loss_pixel(d, m, logits, y_true, scale, probs, dlogits);
+  const int b = blockIdx.y, stride = gridDim.x * 256;
+  int hw = blockIdx.x * 256 + threadIdx.x;
+  for (; hw + 3 * stride < d.HW; hw += 4 * stride) {
+    float l4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) l4[u] = softmax_loss_pixel<CC>(d, b, hw + u * stride, logits, y_true, scale, probs, dlogits);
+    lsum += (l4[0] + l4[1]) + (l4[2] + l4[3]);
+  }
+  for (; hw < d.HW; hw += stride) lsum += softmax_loss_pixel<CC>(d, b, hw, logits, y_true, scale, probs, dlogits);
   if (y_true) {
     for (int msk = 32; msk >= 1; msk >>= 1) lsum += __shfl_xor(lsum, msk, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
     __syncthreads();
-    grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), loss, gridDim.x);
+    grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), loss, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
   }
 }
 
@@ -601,12 +613,21 @@ extern "C" int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* l
   USSEG_CHECK_ARG(d->loss_kind == 0 || (d->loss_kind == 1 && scale), "loss_kind 1 needs scale");
   if (d->M <= 0) return USSEG_OK;
   USSEG_CHECK_ARG(d->HW > 0 && d->M % d->HW == 0, "softmax_loss: M must be a multiple of HW");
-  // one pixel per thread up to the 2048 slots of the ordered sum (the per-pixel chain of dependent loads is latency-bound: 4 pixels per
-  // thread on 1024 workgroups took 36 us for 50 MB)
-  int64_t g = (y_true && d->loss_kind == 1) ? cdiv64(d->HW, 256) : cdiv64(d->M, 256);
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(softmax_loss_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *d, logits, y_true, scale, probs, loss,
-                     (bf16_t*)dlogits);
+  USSEG_CHECK_ARG(d->HW < (1 << 30) && d->M / d->HW <= 65535, "softmax_loss: image too large");
+  const int nb = (int)(d->M / d->HW);
+  dim3 grid;
+  if (y_true && d->loss_kind == 1) {
+    int64_t g = cdiv64(d->HW, 256);
+    grid = dim3((unsigned)(g > 2048 ? 2048 : g));
+  } else {
+    static const int ppt = getenv("USSEG_LOSS_PPT") ? atoi(getenv("USSEG_LOSS_PPT")) : 4;
+    int64_t g = cdiv64(d->HW, 256 * ppt);          // <= 2048 workgroups in all: the slots of the ordered sum
+    if (g * nb > 2048) g = 2048 / nb > 0 ? 2048 / nb : 1;
+    USSEG_CHECK_ARG(g * nb <= 2048, "softmax_loss: more than 2048 images");
+    grid = dim3((unsigned)g, (unsigned)nb);
+  }
+  if (d->C == 3) hipLaunchKernelGGL(softmax_loss_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *d, logits, y_true, scale, probs, loss, (bf16_t*)dlogits);
+  else hipLaunchKernelGGL(softmax_loss_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, *d, logits, y_true, scale, probs, loss, (bf16_t*)dlogits);
   return usseg_check_launch("softmax_loss");
 }
 

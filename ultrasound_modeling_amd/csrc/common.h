@@ -59,11 +59,12 @@ __device__ __forceinline__ float act_grad(float v, int act, float alpha) {
 // instead: the partial is published with a RETURNING agent-scope atomic exchange (executed at the memory side), the ticket
 // increment consumes that return value, and the last workgroup reads the partials with agent-scope atomic loads.
 /* USSEG_ACC_FLOATS (usseg.h) = 2 + the largest grid of the kernels that use it */
-__device__ __forceinline__ bool grid_ordered_sum(float block_total /* thread 0 */, float* acc, int nblocks) {
+__device__ __forceinline__ bool grid_ordered_sum(float block_total /* thread 0 */, float* acc, int nblocks, int bid = -1) {
   __shared__ int s_last;
   __shared__ float s_w[4];
+  if (bid < 0) bid = blockIdx.x;        // (a 2-D grid passes its linear workgroup index)
   if (threadIdx.x == 0) {
-    const float old = __hip_atomic_exchange(acc + 2 + blockIdx.x, block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float old = __hip_atomic_exchange(acc + 2 + bid, block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned zero = 0u;
     asm volatile("; ticket after the partial is at the memory side" : "+v"(zero) : "v"(old));
     const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(acc + 1), 1u + zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
