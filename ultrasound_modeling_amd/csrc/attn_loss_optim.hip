@@ -153,13 +153,41 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// y[o] = sum_i x[i] * W[i*s_i + o*s_o] for o < No (<= 128), i < Ni, by all SA_THR threads: the input range is cut into
+// SA_THR / pow2(No) slices that run side by side (a 128-thread workgroup with one thread per output walked Ni dependent-latency
+// batches of L2 loads in a row: 5 us per matrix), partial sums land in part[slice][o] and are added in slice order by sa_mv_sum.
+#define SA_THR 256
+__device__ __forceinline__ int sa_mv(const float* __restrict__ W, int s_i, int s_o, const float* x, int Ni, int No, float* part /* [8][128] */) {
+  const int tid = threadIdx.x;
+  const int Np = No <= 32 ? 32 : (No <= 64 ? 64 : 128), parts = SA_THR / Np;
+  const int o = tid & (Np - 1), pt = tid / Np;
+  const int per = (Ni + parts - 1) / parts, i0 = pt * per, i1 = i0 + per < Ni ? i0 + per : Ni;
+  float v0 = 0.f, v1 = 0.f;
+  if (o < No) {
+    int i = i0;
+#pragma unroll 4
+    for (; i + 1 < i1; i += 2) {
+      v0 = fmaf(x[i], W[(int64_t)i * s_i + (int64_t)o * s_o], v0);
+      v1 = fmaf(x[i + 1], W[(int64_t)(i + 1) * s_i + (int64_t)o * s_o], v1);
+    }
+    if (i < i1) v0 = fmaf(x[i], W[(int64_t)i * s_i + (int64_t)o * s_o], v0);
+  }
+  part[pt * 128 + o] = v0 + v1;
+  return parts;
+}
+__device__ __forceinline__ float sa_mv_sum(const float* part, int parts, int o) {
+  float v = 0.f;
+  for (int q = 0; q < parts; ++q) v += part[q * 128 + o];
+  return v;
+}
+
 template <bool BWD>
-__global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
+__global__ __launch_bounds__(SA_THR) void sa_mlp_kernel(const SaMlp a) {
   const UssegSplitAttnDesc& d = a.d;
   const int b = blockIdx.x / d.P, p = blockIdx.x - b * d.P;
   const int tid = threadIdx.x;
   const int Cg = d.Cg, Hd = d.Hd, R = d.R;
-  __shared__ float gin[128], h1[64], xh[64], av[64], red[4], dz[4 * 128], da[64], dh[64];
+  __shared__ float gin[128], h1[64], xh[64], av[64], red[4], dz[4 * 128], da[64], dh[64], part[8 * 128];
   const int Cy = d.P * R * Cg;
   float* wsb = a.ws + (int64_t)(b * d.P + p) * (Cg + 2 * Hd);
   const float* w1 = a.p.w1 + (int64_t)p * Cg * Hd;
@@ -170,26 +198,31 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
   float* grow = BWD ? a.gws + ((int64_t)p * d.B + b) * a.Ctot : nullptr;
   float* g_w1 = grow, *g_b1 = g_w1 + Cg * Hd, *g_gamma = g_b1 + Hd, *g_beta = g_gamma + Hd, *g_w2 = g_beta + Hd, *g_b2 = g_w2 + R * Hd * Cg;
 
-  // gin[c] = mult/HW * sum_r g[b][(p*R+r)*Cg + c]     (ResNest.py:173-180)
-  for (int c = tid; c < Cg; c += 128) {
+  // gin[c] = mult/HW * sum_r g[b][(p*R+r)*Cg + c]     (ResNest.py:173-180); the partial rows of the pooled sums are split over
+  // SA_THR / pow2(Cg) thread slices and added in slice order
+  {
+    const int Np = Cg <= 32 ? 32 : (Cg <= 64 ? 64 : 128), parts = SA_THR / Np;
+    const int c = tid & (Np - 1), pt = tid / Np;
     float v = 0.f;
-    for (int r = 0; r < R; ++r) {
-      const float* gp = a.g + (int64_t)b * a.g_rows * a.g_stride + (p * R + r) * Cg + c;
-      float v0 = 0.f, v1 = 0.f;          // the rows are independent loads: two chains keep them in flight
-      int j = 0;
-      for (; j + 1 < a.g_rows; j += 2) { v0 += gp[(int64_t)j * a.g_stride]; v1 += gp[(int64_t)(j + 1) * a.g_stride]; }
-      if (j < a.g_rows) v0 += gp[(int64_t)j * a.g_stride];
-      v += v0 + v1;
-    }
-    gin[c] = v * gscale;
+    if (c < Cg)
+      for (int r = 0; r < R; ++r) {
+        const float* gp = a.g + (int64_t)b * a.g_rows * a.g_stride + (p * R + r) * Cg + c;
+        float v0 = 0.f, v1 = 0.f;          // the rows are independent loads: two chains keep them in flight
+        int jr = pt;
+        for (; jr + parts < a.g_rows; jr += 2 * parts) { v0 += gp[(int64_t)jr * a.g_stride]; v1 += gp[(int64_t)(jr + parts) * a.g_stride]; }
+        if (jr < a.g_rows) v0 += gp[(int64_t)jr * a.g_stride];
+        v += v0 + v1;
+      }
+    part[pt * 128 + c] = v;
+    __syncthreads();
+    if (tid < Cg) gin[tid] = sa_mv_sum(part, parts, tid) * gscale;
   }
   __syncthreads();
   // dense1 (ResNest.py:182)
-  for (int j = tid; j < Hd; j += 128) {
-    float v = a.p.b1[p * Hd + j];
-#pragma unroll 8
-    for (int c = 0; c < Cg; ++c) v += gin[c] * w1[c * Hd + j];
-    h1[j] = v;
+  {
+    const int parts = sa_mv(w1, Hd, 1, gin, Cg, Hd, part);
+    __syncthreads();
+    if (tid < Hd) h1[tid] = a.p.b1[p * Hd + tid] + sa_mv_sum(part, parts, tid);
   }
   __syncthreads();
   // norm (LN over Hd <= 64, ResNest.py:183 / BN inference, TBI_ResNest.py:190) + act
@@ -201,7 +234,7 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
     if (tid == 0) { red[0] = mu; red[1] = rsqrtf(var + d.eps); }
   }
   __syncthreads();
-  for (int j = tid; j < Hd; j += 128) {
+  for (int j = tid; j < Hd; j += SA_THR) {
     float x;
     if (d.norm_mode == 0) x = (h1[j] - red[0]) * red[1];
     else x = (h1[j] - a.p.mean[p * Hd + j]) * rsqrtf(a.p.var[p * Hd + j] + d.eps);
@@ -211,17 +244,15 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
   __syncthreads();
 
   if (!BWD) {
-    for (int c = tid; c < Cg; c += 128) wsb[c] = gin[c];
-    for (int j = tid; j < Hd; j += 128) { wsb[Cg + j] = h1[j]; wsb[Cg + Hd + j] = av[j]; }
+    for (int c = tid; c < Cg; c += SA_THR) wsb[c] = gin[c];
+    for (int j = tid; j < Hd; j += SA_THR) { wsb[Cg + j] = h1[j]; wsb[Cg + Hd + j] = av[j]; }
     // dense2 per radix branch + softmax over channels (ResNest.py:187-192; TBI_ResNest.py:194-200)
     for (int r = 0; r < R; ++r) {
       float* z = dz;  // reuse as scratch
-      for (int c = tid; c < Cg; c += 128) {
-        float v = a.p.b2[(p * R + r) * Cg + c];
-        const float* w = w2 + (int64_t)r * Hd * Cg;
-#pragma unroll 8
-        for (int j = 0; j < Hd; ++j) v += av[j] * w[j * Cg + c];
-        z[c] = v;
+      {
+        const int parts = sa_mv(w2 + (int64_t)r * Hd * Cg, Cg, 1, av, Hd, Cg, part);
+        __syncthreads();
+        if (tid < Cg) z[tid] = a.p.b2[(p * R + r) * Cg + tid] + sa_mv_sum(part, parts, tid);
       }
       __syncthreads();
       if (tid < 64) {   // Cg <= 128: two channels per lane
@@ -231,7 +262,7 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
         if (tid == 0) { red[2] = mx; red[3] = 1.f / sum; }
       }
       __syncthreads();
-      for (int c = tid; c < Cg; c += 128) {
+      for (int c = tid; c < Cg; c += SA_THR) {
         float sv = d.use_sigmoid ? 1.f / (1.f + __expf(-z[c])) : __expf(z[c] - red[2]) * red[3];
         a.s[((int64_t)(b * d.P + p) * R + r) * Cg + c] = sv;
       }
@@ -249,7 +280,7 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
         if (tid == 0) red[2] = dot;
       }
       __syncthreads();
-      for (int c = tid; c < Cg; c += 128) {
+      for (int c = tid; c < Cg; c += SA_THR) {
         float v = d.use_sigmoid ? dsv[c] * sv[c] * (1.f - sv[c]) : sv[c] * (dsv[c] - red[2]);
         dz[r * 128 + c] = v;
         g_b2[r * Cg + c] = v;
@@ -257,22 +288,25 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
       __syncthreads();
     }
     // dW2[p][r][j][c] += a[j]*dz[r][c];  da[j] = sum_{r,c} w2*dz
-    for (int idx = tid; idx < R * Hd * Cg; idx += 128) {
+    for (int idx = tid; idx < R * Hd * Cg; idx += SA_THR) {
       int c = idx % Cg;
       int j = (idx / Cg) % Hd;
       int r = idx / (Cg * Hd);
       g_w2[idx] = av[j] * dz[r * 128 + c];
     }
-    for (int j = tid; j < Hd; j += 128) {
+    {
       float v = 0.f;
-      for (int r = 0; r < R; ++r)
-#pragma unroll 8
-        for (int c = 0; c < Cg; ++c) v += w2[((int64_t)r * Hd + j) * Cg + c] * dz[r * 128 + c];
-      da[j] = v;
+      for (int r = 0; r < R; ++r) {          // da[j] = sum_{r,c} w2[r][j][c] * dz[r][c]
+        const int parts = sa_mv(w2 + (int64_t)r * Hd * Cg, 1, Cg, dz + r * 128, Cg, Hd, part);
+        __syncthreads();
+        if (tid < Hd) v += sa_mv_sum(part, parts, tid);
+        __syncthreads();
+      }
+      if (tid < Hd) da[tid] = v;
     }
     __syncthreads();
     // act + norm backward
-    for (int j = tid; j < Hd; j += 128) {
+    for (int j = tid; j < Hd; j += SA_THR) {
       float ga = a.p.gamma[p * Hd + j];
       float pre = ga * xh[j] + a.p.beta[p * Hd + j];
       float dpre = da[j] * act_grad(pre, d.act, d.alpha);
@@ -288,23 +322,24 @@ __global__ __launch_bounds__(128) void sa_mlp_kernel(const SaMlp a) {
         if (tid == 0) { red[2] = s1 / (float)Hd; red[3] = s2 / (float)Hd; }
       }
       __syncthreads();
-      for (int j = tid; j < Hd; j += 128) dh[j] = red[1] * (dh[j] - red[2] - xh[j] * red[3]);
+      for (int j = tid; j < Hd; j += SA_THR) dh[j] = red[1] * (dh[j] - red[2] - xh[j] * red[3]);
     } else {
-      for (int j = tid; j < Hd; j += 128) dh[j] = dh[j] * rsqrtf(a.p.var[p * Hd + j] + d.eps);
+      for (int j = tid; j < Hd; j += SA_THR) dh[j] = dh[j] * rsqrtf(a.p.var[p * Hd + j] + d.eps);
     }
     __syncthreads();
-    for (int j = tid; j < Hd; j += 128) g_b1[j] = dh[j];
-    for (int idx = tid; idx < Cg * Hd; idx += 128) {
+    for (int j = tid; j < Hd; j += SA_THR) g_b1[j] = dh[j];
+    for (int idx = tid; idx < Cg * Hd; idx += SA_THR) {
       int j = idx % Hd, c = idx / Hd;
       g_w1[idx] = gin[c] * dh[j];
     }
     // d g_sum[b][(p*R+r)*Cg + c] = mult/HW * sum_j w1[c][j] dh[j]
-    for (int c = tid; c < Cg; c += 128) {
-      float v = 0.f;
-#pragma unroll 8
-      for (int j = 0; j < Hd; ++j) v += w1[c * Hd + j] * dh[j];
-      v *= gscale;
-      for (int r = 0; r < R; ++r) a.dg[(int64_t)b * Cy + (p * R + r) * Cg + c] = v;
+    {
+      const int parts = sa_mv(w1, 1, Hd, dh, Hd, Cg, part);
+      __syncthreads();
+      if (tid < Cg) {
+        const float v = sa_mv_sum(part, parts, tid) * gscale;
+        for (int r = 0; r < R; ++r) a.dg[(int64_t)b * Cy + (p * R + r) * Cg + tid] = v;
+      }
     }
   }
 }
@@ -318,7 +353,7 @@ extern "C" int usseg_splitattn_mlp_fwd(const UssegSplitAttnDesc* d, const float*
   USSEG_CHECK_ARG(g_rows >= 1 && g_stride >= d->P * d->R * d->Cg, "splitattn_mlp: bad pooled-row layout");
   SaMlp a = {};
   a.d = *d; a.p = *p; a.g = g; a.s = s; a.ws = ws; a.g_rows = g_rows; a.g_stride = g_stride;
-  hipLaunchKernelGGL(sa_mlp_kernel<false>, dim3(d->B * d->P), dim3(128), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sa_mlp_kernel<false>, dim3(d->B * d->P), dim3(SA_THR), 0, (hipStream_t)stream, a);
   return usseg_check_launch("splitattn_mlp_fwd");
 }
 
@@ -341,7 +376,7 @@ extern "C" int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float*
   const int Cg = d->Cg, Hd = d->Hd, R = d->R;
   a.Ctot = Cg * Hd + 3 * Hd + R * Hd * Cg + R * Cg;
   a.gws = usseg_defer_reduce_ws((hipStream_t)stream, grad_ws, (int64_t)d->B * d->P * a.Ctot);   // a private region while finishes are deferred
-  hipLaunchKernelGGL(sa_mlp_kernel<true>, dim3(d->B * d->P), dim3(128), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sa_mlp_kernel<true>, dim3(d->B * d->P), dim3(SA_THR), 0, (hipStream_t)stream, a);
   // per parameter: rows (path, image) of Ctot floats -> the path's variable (per-path variables are adjacent: [P][numel])
   const int sizes[6] = {Cg * Hd, Hd, Hd, Hd, R * Hd * Cg, R * Cg};
   float* dst[6] = {grads->w1, grads->b1, grads->gamma, grads->beta, grads->w2, grads->b2};
