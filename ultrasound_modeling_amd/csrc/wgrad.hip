@@ -323,20 +323,25 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
   p.ntaps = ntaps;
   int64_t tiles = (int64_t)p.mtiles * p.ntiles * ntaps;
   // enough splits to give every CU a few workgroups, but at least 256 pixels of work per split
-  int64_t want = (2048 + tiles - 1) / tiles;
+  // swept on the four bench configurations (target 2048/1024/512/384/256/128 x slab cap 8/4/2): the round-1 setting (2048, 8) made
+  // 16-32 splits of the big dense gradients of the ViT / Swin layers, whose slabs then dominate (wgrad_finish 580 us per cfg4 step);
+  // (512, 4): Arch B 3.735 -> 3.70 ms, cfg4 11.52 -> 11.11, cfg5 12.44 -> 11.87, Arch A unchanged; 128 is 2-10 % slower everywhere
+  static const int wg_target = getenv("USSEG_WGD_TARGET") ? atoi(getenv("USSEG_WGD_TARGET")) : 512;
+  static const int slab_cap = getenv("USSEG_WGD_CAP") ? atoi(getenv("USSEG_WGD_CAP")) : 4;
+  int64_t want = (wg_target + tiles - 1) / tiles;
   int64_t max_splits = cdiv64(p.M, 256);
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
   // With a workspace every split stores its partial [ntaps][Ma][Nb] slab and wgrad_finish_kernel sums (and scatters)
   // them: fp32 atomics from ~1000 workgroups into the few cache lines of a small gradient serialise at the L2 (the
-  // 32x16 cardinal conv1 gradient took 35-120 us that way).  Slab traffic is kept within ~8x the operand bytes.
+  // 32x16 cardinal conv1 gradient took 35-120 us that way).  Slab traffic is kept within ~4x the operand bytes (USSEG_WGD_CAP).
   const int64_t slab = (int64_t)ntaps * p.Ma * p.Nb;
   p.ws = nullptr;
   int64_t cap_splits = 1;
   if (ws) ws = usseg_defer_wgrad_ws(s, ws, ws_floats, &ws_floats);
   if (ws && want > 1) {
     const int64_t in_bytes = p.M * (p.Ma + p.Nb) * 2;
-    int64_t cap = 8 * in_bytes / (slab * 4);
+    int64_t cap = slab_cap * in_bytes / (slab * 4);
     if (cap < 4) cap = 4;
     if (cap > ws_floats / slab) cap = ws_floats / slab;
     if (want > cap) want = cap;
