@@ -419,8 +419,9 @@ __global__ __launch_bounds__(64) void window_attn_kernel(const WinAttn p) {
 // key tile t is key 32*(t>>1) + 8*(i>>2) + 4*(t&1) + (i&3), which makes two tiles fill the 32 contraction slots in natural order.
 // Relative-position bias, shifted-window mask and the softmax run on the accumulators (a query column lives in 4 lanes: two
 // shuffles per reduction).  Probabilities and dS enter the second GEMMs as hi + lo bf16 pairs (relative error 2^-17), so the
-// results match the fp32 scalar kernel to rounding.  Backward: P^T and dS^T are parked in LDS as fp32 [key][query] matrices, from
-// which the dK / dV GEMMs read their B operands (8 consecutive queries per lane) and the bias-table bins are summed in a fixed order.
+// results match the fp32 scalar kernel to rounding.  Backward: P^T, then dS^T, are parked in ONE fp32 [key][query] LDS matrix from
+// which the dV / dK GEMMs read their B operands (8 consecutive queries per lane); dS^T summed over the block's windows stays in
+// registers and goes through the same matrix once at the end, where the bias-table bins are summed in a fixed order (42 KB of LDS).
 #define WM_VS 48
 #define WM_PS 68
 __device__ __forceinline__ bf16x8_t wm_row(const bf16_t* tile, int row, int g) {
@@ -479,16 +480,18 @@ __global__ __launch_bounds__(64) void window_attn_mfma_kernel(const WinAttn p, c
   constexpr int WS = 8, N = 64, T = 15;
   __shared__ __attribute__((aligned(16))) bf16_t s_q[N * WM_VS], s_k[N * WM_VS], s_v[N * WM_VS];
   __shared__ __attribute__((aligned(16))) bf16_t s_do[BWD ? N * WM_VS : 8];
-  __shared__ __attribute__((aligned(16))) float s_pT[BWD ? N * WM_PS : 4], s_dsT[BWD ? N * WM_PS : 4];   // [key][query]
-  __shared__ __attribute__((aligned(16))) float s_acc[BWD ? N * WM_PS : 4];   // dS summed over the block's windows (same layout)
+  __shared__ __attribute__((aligned(16))) float s_mT[BWD ? N * WM_PS : 4];   // [key][query]: P^T, then dS^T, at the end the summed dS^T
   __shared__ float s_tab[T * T];
   __shared__ int s_reg[N];
   const int nwx = p.W / WS, nW = (p.H / WS) * nwx;
   const int h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x, g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   for (int i = lane; i < T * T; i += 64) s_tab[i] = p.table[i * p.heads + h];
-  if (BWD)
-    for (int i = lane; i < N * WM_PS; i += 64) s_acc[i] = 0.f;
+  f32x4_t accd[BWD ? 4 : 1][4];          // backward: dS^T summed over the block's windows, in the accumulator layout (registers: LDS is what limits occupancy)
+#pragma unroll
+  for (int kt = 0; kt < (BWD ? 4 : 1); ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) accd[kt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // a block walks wpb consecutive windows of one (image, head): the next window's rows are loaded while this one computes
   uint4 rq0, rq1, rq2, rq3, rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3, rd0, rd1, rd2, rd3;
   rd0 = rd1 = rd2 = rd3 = make_uint4(0, 0, 0, 0);
@@ -618,9 +621,8 @@ __global__ __launch_bounds__(64) void window_attn_mfma_kernel(const WinAttn p, c
         const int kj = 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
         const float pr = st[kt][qt][r], ds = pr * (dpt[kt][qt][r] - delta);
         dpt[kt][qt][r] = ds;
-        s_pT[kj * WM_PS + qi] = pr;
-        s_dsT[kj * WM_PS + qi] = ds;
-        s_acc[kj * WM_PS + qi] += ds;          // one owner lane per element: a fixed summation order
+        accd[kt][qt][r] += ds;
+        s_mT[kj * WM_PS + qi] = pr;
       }
   }
 #pragma unroll
@@ -651,34 +653,46 @@ __global__ __launch_bounds__(64) void window_attn_mfma_kernel(const WinAttn p, c
     }
   }
   __syncthreads();
-  // ---- dV^T[d][key] = sum_q dO^T[d][q] P[q][key],  dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
-  //      B operand [slot q = 32c + 8g + j][col key = kt*16 + li]: 8 consecutive floats of row `key` of the [key][query] matrices
+  // ---- dV^T[d][key] = sum_q dO^T[d][q] P[q][key],  then (same LDS matrix rewritten with dS^T) dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
+  //      B operand [slot q = 32c + 8g + j][col key = kt*16 + li]: 8 consecutive floats of row `key` of the [key][query] matrix
   f32x4_t dvv[2][4], dkk[2][4];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) dvv[dt][kt] = dkk[dt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    bf16x8_t dot[2] = {wm_tr(s_do, c, 0, g, tq, tp), wm_tr(s_do, c, 1, g, tq, tp)};
-    bf16x8_t qtr[2] = {wm_tr(s_q, c, 0, g, tq, tp), wm_tr(s_q, c, 1, g, tq, tp)};
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      __syncthreads();
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const float* pr = &s_pT[(kt * 16 + li) * WM_PS + 32 * c + 8 * g];
-      const float* dr = &s_dsT[(kt * 16 + li) * WM_PS + 32 * c + 8 * g];
-      const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(pr), p1 = *reinterpret_cast<const f32x4_t*>(pr + 4);
-      const f32x4_t d0 = *reinterpret_cast<const f32x4_t*>(dr), d1 = *reinterpret_cast<const f32x4_t*>(dr + 4);
-      const float pv[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-      const float dv[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-      bf16x8_t ph, pl, dh, dl;
-      wm_split(pv, ph, pl);
-      wm_split(dv, dh, dl);
+      for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        dvv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], ph, dvv[dt][kt], 0, 0, 0);
-        dvv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], pl, dvv[dt][kt], 0, 0, 0);
-        dkk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dh, dkk[dt][kt], 0, 0, 0);
-        dkk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dl, dkk[dt][kt], 0, 0, 0);
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_mT[(32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r) * WM_PS + qt * 16 + li] = dpt[kt][qt][r];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bf16_t* at = pass == 0 ? s_do : s_q;
+      bf16x8_t atr[2] = {wm_tr(at, c, 0, g, tq, tp), wm_tr(at, c, 1, g, tq, tp)};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const float* pr = &s_mT[(kt * 16 + li) * WM_PS + 32 * c + 8 * g];
+        const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(pr), p1 = *reinterpret_cast<const f32x4_t*>(pr + 4);
+        const float pv[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+        bf16x8_t ph, pl;
+        wm_split(pv, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          if (pass == 0) {
+            dvv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr[dt], ph, dvv[dt][kt], 0, 0, 0);
+            dvv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr[dt], pl, dvv[dt][kt], 0, 0, 0);
+          } else {
+            dkk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr[dt], ph, dkk[dt][kt], 0, 0, 0);
+            dkk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr[dt], pl, dkk[dt][kt], 0, 0, 0);
+          }
+        }
       }
     }
   }
@@ -699,6 +713,13 @@ __global__ __launch_bounds__(64) void window_attn_mfma_kernel(const WinAttn p, c
   __syncthreads();
   }   // windows
   if (!BWD) return;
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_mT[(32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r) * WM_PS + qt * 16 + li] = accd[kt][qt][r];
+  __syncthreads();
   // relative-position bias gradient: bin (dr, dc) collects dS_ij over the pairs with r_i - r_j = dr, c_i - c_j = dc (fixed order),
   // once per block from the sum over its windows
   float* row = p.dtab_ws + ((int64_t)b * (nW / wpb) + blockIdx.x) * (T * T) * p.heads;
@@ -708,7 +729,7 @@ __global__ __launch_bounds__(64) void window_attn_mfma_kernel(const WinAttn p, c
     for (int ii = 0; ii < N; ++ii) {
       const int ri = ii >> 3, ci = ii & 7;
       const int rj = ri - dr, cj = ci - dc;
-      if ((unsigned)rj < (unsigned)WS && (unsigned)cj < (unsigned)WS) s += s_acc[(rj * WS + cj) * WM_PS + ii];
+      if ((unsigned)rj < (unsigned)WS && (unsigned)cj < (unsigned)WS) s += s_mT[(rj * WS + cj) * WM_PS + ii];
     }
     row[bin * p.heads + h] = s;
   }
