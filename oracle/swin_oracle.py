@@ -134,6 +134,8 @@ def swin_forward(x: Tensor, P, cfg: dict):
     res = (H // ps, W // ps)
     t = t.reshape(B, res[0] * res[1], E)
     t = layer_norm(t, P["patch_embed/norm/gamma"], P["patch_embed/norm/beta"])   # patch_norm=True (:380,398)
+    if cfg.get("ape"):
+        t = t + P["absolute_pos_embed"]                                     # [1, L, E] (:401-408,442-443)
     feats = []
     for il, depth in enumerate(depths):
         pre = f"layers{il}/"
@@ -175,6 +177,10 @@ def init_swin_params(cfg: dict, in_chans: int = 1, seed: int = 0, dtype=torch.fl
     glorot("patch_embed/proj/kernel", ps, ps, in_chans, E, fan_in=ps * ps * in_chans, fan_out=ps * ps * E)
     vec("patch_embed/proj/bias", E, 0.0, 0.1)
     ln("patch_embed/norm", E)
+    if cfg.get("ape"):       # Zeros initialiser (:403-407); perturbed so that the term is exercised
+        res = cfg["img_size"][0] // ps, cfg["img_size"][1] // ps
+        P["absolute_pos_embed"] = ((0.3 * torch.randn(1, res[0] * res[1], E, generator=g, dtype=torch.float64)) if perturb
+                                   else torch.zeros(1, res[0] * res[1], E, dtype=torch.float64)).to(dtype)
     for il, depth in enumerate(depths):
         C = E * 2 ** il
         for i in range(depth):

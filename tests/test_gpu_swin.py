@@ -124,12 +124,13 @@ def _load(net, P):
     net.repack()
 
 
-def test_small_swin_model_against_the_oracle():
+@pytest.mark.parametrize("ape", [False, True])
+def test_small_swin_model_against_the_oracle(ape):
     from ultrasound_modeling_amd.SwinTransformer import SwinTransformerModel
-    cfg = dict(patch_size=4, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4)
+    cfg = dict(patch_size=4, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4, ape=ape, img_size=(64, 64))
     P = {k: v.float().double() for k, v in S.init_swin_params(cfg, in_chans=1, seed=5).items()}
     net = SwinTransformerModel(model_name="tiny_test", img_size=(64, 64), patch_size=(4, 4), in_chans=1, embed_dim=32, depths=[2, 2], num_heads=[2, 4],
-                               window_size=4)
+                               window_size=4, ape=ape)
     assert set(_name_map(net).values()) == set(P)
     _load(net, P)
     g = torch.Generator().manual_seed(6)

@@ -20,8 +20,7 @@ row-major), so:
 As the reference is driven, Dropout and DropPath are the identity (no ``training`` argument reaches them, :25,144-155).
 Deviations, on purpose: only SQUARE windows are accepted - ``window_reverse`` (:53-58) mixes window_size[0] and [1] and is an
 inverse of ``window_partition`` only for square windows, and every entry of CFGS is square (the constructor default [4, 5] of :376
-would scramble the tensor in the reference); window sides 2, 4 or 8 (the CFGS use 4 and 8); ``ape`` (absolute position embedding,
-off by default) is not built; the factory ``SwinTransformer()`` (:458-486, broken as committed and tied to a download) builds the
+would scramble the tensor in the reference); window sides 2, 4 or 8 (the CFGS use 4 and 8); the factory ``SwinTransformer()`` (:458-486, broken as committed and tied to a download) builds the
 named configuration without weights.  ``self.features`` does not accumulate across calls (:434,449 appends forever).
 The storage type is bf16 (the build's choice for every path; BASELINE quotes fp16 for this configuration).
 """
@@ -274,12 +273,15 @@ class SwinTransformerModel(TrainStepDriver, nn.Module):
         super().__init__()
         if seed is not None:
             torch.manual_seed(seed)
-        assert not ape, "absolute position embedding (off by default, :378) is not built"
         self.include_top, self.num_classes, self.num_layers, self.embed_dim = include_top, num_classes, len(depths), embed_dim
         self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
         self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, norm_layer=patch_norm)
         self.patches_resolution = self.patch_embed.patches_resolution
         res = self.patches_resolution
+        # absolute position embedding (:401-408, off by default): [1, L, E], Zeros initialiser; its bf16 copy is rebuilt with the operands
+        self.ape = bool(ape)
+        if self.ape:
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, res[0] * res[1], embed_dim))
         self.basic_layers = nn.ModuleList([
             BasicLayer(dim=int(embed_dim * 2 ** i), input_resolution=(res[0] // 2 ** i, res[1] // 2 ** i), depth=depths[i], num_heads=num_heads[i],
                        window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
@@ -298,6 +300,8 @@ class SwinTransformerModel(TrainStepDriver, nn.Module):
         """Every bf16 GEMM operand rebuilt from the fp32 masters in ONE batched launch (device-resident job table)."""
         from .VisionTransformer import repack_all
         repack_all(self)
+        if self.ape:
+            self._ape_bf16 = self.absolute_pos_embed.data.to(BF16).reshape(1, *self.patches_resolution, self.embed_dim)
 
     # ---- the shared step driver (step.TrainStepDriver): zero -> forward -> backward -> [per-replica clip -> exchange] -> Adam -> repack.
     # The reference defines no loss for this file (nothing imports it), so the "label" of a step is the upstream gradient of the
@@ -343,6 +347,9 @@ class SwinTransformerModel(TrainStepDriver, nn.Module):
         if x.dtype not in (torch.float32, torch.float64):
             x = x.float()
         t = self.patch_embed.forward(x)
+        if self.ape:                                   # x + absolute_pos_embed (:442-443), broadcast over the batch
+            for b in range(t.shape[0]):
+                ops.copy_channels(self._ape_bf16, t[b:b + 1], accumulate=True)
         self.features = []
         for i, layer in enumerate(self.basic_layers):
             t, f = layer.forward(t)
@@ -377,6 +384,8 @@ class SwinTransformerModel(TrainStepDriver, nn.Module):
                     r = self.basic_layers[i].input_resolution
                     df = d_features[i].reshape(d.shape[0], r[0], r[1], -1)
                 d = self.basic_layers[i].backward(d, df)
+            if self.ape:                               # sum over the batch (an off-by-default option: host-side reduction of the fp32 cast)
+                self.absolute_pos_embed.grad += ops.to_f32(d).sum(0).reshape(self.absolute_pos_embed.shape)
             self.patch_embed.backward(d)
 
     def __call__(self, x, *args, **kwargs):
