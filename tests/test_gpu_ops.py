@@ -139,6 +139,34 @@ def test_conv_stream(gen, monkeypatch, B, H, W, Cin, Cout, dil, wgx):
     assert rel(dx[..., :Cin], bf(xr.grad)) < 2 * REL_BF16
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,dil,wgx", [(2, 128, 128, 30, 64, 1, 0), (2, 64, 64, 32, 30, 1, 8), (1, 32, 48, 16, 16, 2, 8), (3, 32, 32, 24, 40, 1, 16)])
+def test_conv_stream_with_residual(gen, monkeypatch, B, H, W, Cin, Cout, dil, wgx):
+    """The streaming conv's residual variant (y = act(conv + bias) + residual: concats_2 + shortcut of residual_S, ResNest.py:96-100)
+    against the oracle and, to the bf16 bit, against the tiled kernels with the same epilogue."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    monkeypatch.setenv("USSEG_STREAM_MIN_STEPS", "1")
+    if wgx:
+        monkeypatch.setenv("USSEG_STREAM_WGX", str(wgx))
+    layer = Conv2D(Cin, Cout, 3, dil)
+    w = rnd(gen, 3, 3, Cin, Cout, scale=1.0 / math.sqrt(9 * Cin))
+    b = rnd(gen, Cout, scale=0.5)
+    layer.kernel.data.copy_(w)
+    layer.bias.data.copy_(b)
+    finalize(layer)
+    x, r = rnd(gen, B, H, W, Cin), rnd(gen, B, H, W, Cout)
+    xd, rd = to_dev_padded(x), to_dev_padded(r)
+    ref = O.leaky_relu(O.conv2d_same(x, w, b, dil)) + r
+    y = layer.forward(xd, act=ops.ACT_LRELU, alpha=0.3, residual=rd)
+    torch.cuda.synchronize()
+    assert rel(y[..., :Cout], bf(ref)) < REL_BF16
+    assert y[..., Cout:].abs().max().item() == 0 if layer.cout_p > Cout else True
+    monkeypatch.setenv("USSEG_STREAM_RES", "0")       # read once per process: compare with the non-streaming kernels through the step planner instead
+    monkeypatch.setenv("USSEG_STREAM_MIN_STEPS", "1000000")
+    y2 = layer.forward(xd, act=ops.ACT_LRELU, alpha=0.3, residual=rd)
+    assert rel(y, y2) < 2e-3
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,dil", [(2, 32, 32, 256, 64, 1), (1, 32, 16, 40, 64, 1), (2, 16, 16, 72, 136, 2), (3, 16, 16, 96, 40, 4),
                                                 (5, 8, 8, 64, 24, 1), (2, 64, 64, 128, 16, 2)])
 def test_conv_big_eight_wave_tile(gen, monkeypatch, B, H, W, Cin, Cout, dil):

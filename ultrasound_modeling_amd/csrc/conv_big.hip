@@ -201,7 +201,10 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
 // One patch per pixel group (NV == 1): the group's geometry is four scalars read from a small LDS table.
 // Walk: XCD x (= blockIdx.x % 8) owns a contiguous eighth of the groups and its workgroups take adjacent groups at the
 // same time, so concurrently staged halo tiles are neighbours in memory and shared halo columns hit in that XCD's L2.
-template <int NT, int NS>
+// RES: y = act(conv + bias) + residual.  The residual tile of a group is loaded into registers at the top of the group's LAST
+// chunk step - before that step's MFMAs and in program order before the next step's DMA, so its latency hides under the MFMAs -
+// and the compiler's own wait before the adds drains (only then, once per group) the prefetch DMA issued after it.
+template <int NT, int NS, bool RES = false>
 __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigJob p, const int fast_wait) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BN = 16 * NT;
@@ -314,6 +317,19 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigJob p, con
     if (fast_wait && s > 0 && ck == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NS * NT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // ... for every wave, and everyone is done reading the other buffer
+    uint2 rr[RES ? NS : 1][RES ? NT : 1];
+    if constexpr (RES) {
+      if (ck == p.nchunks - 1) {
+        const int ob = s_grp[gl][1];
+#pragma unroll
+        for (int a = 0; a < NS; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b) {
+            const int n = nbase + b * 16;
+            rr[a][b] = *reinterpret_cast<const uint2*>(p.res + (int64_t)(ob + orel[a]) * p.ldr + (n < p.Nout ? n : 0));
+          }
+      }
+    }
     if (s + 1 < total) issue_a(s + 1);
     if (ck == 0) {
 #pragma unroll
@@ -345,7 +361,29 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigJob p, con
     const int obase = s_grp[gl][1];
 #pragma unroll
     for (int a = 0; a < NS; ++a) { opix[a] = obase + orel[a]; ovalid[a] = true; }
-    conv_epilogue<NS, NT, true>(e, ec, acc, opix, ovalid, nbase);
+    if constexpr (RES) {
+      const float alpha = p.alpha;
+      const int act = p.act;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        bf16_t* const yrow = reinterpret_cast<bf16_t*>(p.y) + opix[a] * p.ldy;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          const int n = nbase + b * 16;
+          if (n >= p.Nout) continue;
+          const float v0 = apply_act(acc[a][b][0] + ec.bb[b].x, act, alpha) + __uint_as_float(rr[a][b].x << 16);
+          const float v1 = apply_act(acc[a][b][1] + ec.bb[b].y, act, alpha) + __uint_as_float(rr[a][b].x & 0xffff0000u);
+          const float v2 = apply_act(acc[a][b][2] + ec.bb[b].z, act, alpha) + __uint_as_float(rr[a][b].y << 16);
+          const float v3 = apply_act(acc[a][b][3] + ec.bb[b].w, act, alpha) + __uint_as_float(rr[a][b].y & 0xffff0000u);
+          uint2 o;
+          o.x = pack2bf(v0, v1);
+          o.y = pack2bf(v2, v3);
+          *reinterpret_cast<uint2*>(yrow + n) = o;
+        }
+      }
+    } else {
+      conv_epilogue<NS, NT, true>(e, ec, acc, opix, ovalid, nbase);
+    }
   }
 #endif
 }
@@ -438,14 +476,14 @@ struct BigGeom {   // what big_fill_job needs, so that a job can be re-filled fo
   int B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act; float alpha; int out_f32, accumulate, flip;
 };
 
-template <int NT, int NS>
+template <int NT, int NS, bool RES = false>
 static void stream_launch_t(const BigJob& p, dim3 grid, size_t dyn, int fast_wait, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_stream_kernel<NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);   // + 1 KB static
+    (void)hipFuncSetAttribute((const void*)conv_stream_kernel<NT, NS, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);   // + 1 KB static
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_stream_kernel<NT, NS>), grid, dim3(256), dyn, s, p, fast_wait);
+  hipLaunchKernelGGL((conv_stream_kernel<NT, NS, RES>), grid, dim3(256), dyn, s, p, fast_wait);
 }
 
 // Streaming kernel for one job whose weights fit in LDS and whose launch has enough pixel groups to amortise them.
@@ -458,8 +496,10 @@ static int stream_plan_and_launch(const BigGeom& g, const float* epi_scale, int 
   const int min_steps = ms_env ? atoi(ms_env) : 1;
   static const int occ_env = getenv("USSEG_STREAM_OCC") ? atoi(getenv("USSEG_STREAM_OCC")) : 0;
   if (!mode || usseg_tap_mask.group_ch) return 0;
-  // its epilogue is bias + activation + bf16 store only (no loads inside the streaming loop)
-  if (g.out_f32 || g.res || g.accumulate || (!g.flip && epi_scale)) return 0;
+  // its epilogue is bias + activation + bf16 store (no loads inside the streaming loop), or the RES variant with a preloaded residual
+  static const int res_env = getenv("USSEG_STREAM_RES") ? atoi(getenv("USSEG_STREAM_RES")) : 1;
+  if (g.out_f32 || g.accumulate || (!g.flip && epi_scale)) return 0;
+  if (g.res && (!res_env || (g.ldr & 3))) return 0;
   const int nt = nt_for(g.Nout);
   const int nchunks = (g.Cin + 31) / 32;
   const size_t wbytes = (size_t)nchunks * 9 * 16 * nt * 64;
@@ -485,11 +525,21 @@ static int stream_plan_and_launch(const BigGeom& g, const float* epi_scale, int 
     if (per_wg * nchunks < min_steps && !px_env) continue;   // too few steps to amortise the weights: the tiled kernels win
     if (per_wg > 64) { wgx = ((gpx + 63) / 64) * 8; per_wg = 64; }
     // the in-order wait on "all but the youngest NS*NT operations" needs every step to issue exactly that many stores
-    const int fast_wait = g.Nout % (16 * nt) == 0;
+    const int fast_wait = g.Nout % (16 * nt) == 0 && !g.res;   // (the residual variant's own loads are in the queue too)
     if (dry) return 1;
     const dim3 grid(wgx, gy, 1);
     const int slot = usseg_prof_start(1, s);
-    if (PX == 256) {
+    if (g.res) {
+      if (PX == 256) {
+        if (nt == 1) stream_launch_t<1, 4, true>(p, grid, dyn, fast_wait, s);
+        else if (nt == 2) stream_launch_t<2, 4, true>(p, grid, dyn, fast_wait, s);
+        else stream_launch_t<4, 4, true>(p, grid, dyn, fast_wait, s);
+      } else {
+        if (nt == 1) stream_launch_t<1, 2, true>(p, grid, dyn, fast_wait, s);
+        else if (nt == 2) stream_launch_t<2, 2, true>(p, grid, dyn, fast_wait, s);
+        else stream_launch_t<4, 2, true>(p, grid, dyn, fast_wait, s);
+      }
+    } else if (PX == 256) {
       if (nt == 1) stream_launch_t<1, 4>(p, grid, dyn, fast_wait, s);
       else if (nt == 2) stream_launch_t<2, 4>(p, grid, dyn, fast_wait, s);
       else stream_launch_t<4, 4>(p, grid, dyn, fast_wait, s);
