@@ -594,9 +594,17 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
         usseg_prof_stop(1, slot, s);
         return usseg_check_launch("igemm_dma_persist");
       }
+      // 128-channel tiles: two stages (64 KB, two workgroups per CU) by default; a launch that puts at most one workgroup on a CU
+      // anyway and has a long K loop (the dense layers of the ViT / Swin: 8192 tokens x 2048 -> 512 is 256 workgroups x 32 steps)
+      // is bound by the DMA latency of its single prefetched stage: it gets a deeper ring instead
+      static const int st8 = getenv("USSEG_IGEMM_STAGES8") ? atoi(getenv("USSEG_IGEMM_STAGES8")) : 4;   // 4 stages: cfg4 11.01 -> 10.92 ms, the others unchanged (2 = off)
+      static const int st8_wg = getenv("USSEG_IGEMM_STAGES8_WG") ? atoi(getenv("USSEG_IGEMM_STAGES8_WG")) : 256;
+      const bool deep = nt == 8 && st8 > 2 && (int64_t)gx * gy * gz <= st8_wg && nks >= 8;
       if (nt == 1) igemm_dma_launch_t<1, 3>(p, grid, s);
       else if (nt == 2) igemm_dma_launch_t<2, 3>(p, grid, s);
       else if (nt == 4) igemm_dma_launch_t<4, 3>(p, grid, s);
+      else if (deep && st8 == 3) igemm_dma_launch_t<8, 3>(p, grid, s);
+      else if (deep) igemm_dma_launch_t<8, 4>(p, grid, s);
       else igemm_dma_launch_t<8, 2>(p, grid, s);
       usseg_prof_stop(1, slot, s);
       return usseg_check_launch("igemm_dma");
