@@ -61,7 +61,8 @@ def unfused(qkv, d_out, nh, scale):
 
 
 @pytest.mark.parametrize("with_o32", [True, False])
-@pytest.mark.parametrize("B,N,nh", [(2, 32, 4), (1, 48, 2), (2, 200, 4), (2, 256, 4), (1, 1024, 2), (3, 129, 1)])
+# (8, 1024, 4) and (16, 2048, 1) fill the chip with 128-query workgroups: the 8-wave tiling; the others run the 4-wave one
+@pytest.mark.parametrize("B,N,nh", [(2, 32, 4), (1, 48, 2), (2, 200, 4), (2, 256, 4), (1, 1024, 2), (3, 129, 1), (8, 1024, 4), (16, 2000, 1)])
 def test_flash_attention_matches_fp64(B, N, nh, with_o32):
     from ultrasound_modeling_amd import ops
     torch.manual_seed(N + nh)
