@@ -28,6 +28,7 @@ def dev(t):
 
 
 @pytest.mark.parametrize("B,H,W,C,heads,ws,shift", [(2, 8, 8, 64, 2, 4, 0), (2, 8, 16, 64, 2, 4, 2), (1, 16, 16, 96, 3, 8, 4), (2, 16, 16, 32, 2, 8, 0), (2, 32, 24, 64, 2, 8, 3), (1, 24, 16, 128, 4, 8, 0),
+                                                     (8, 128, 128, 32, 1, 8, 3), (4, 128, 128, 64, 2, 8, 0),   # >= 1024 blocks of 2 windows: the multi-window backward
                                                      (3, 4, 4, 32, 4, 2, 1), (1, 8, 8, 128, 2, 4, 2)])
 def test_window_attention_kernel(B, H, W, C, heads, ws, shift):
     from ultrasound_modeling_amd import ops
