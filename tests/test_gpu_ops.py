@@ -571,19 +571,23 @@ def test_act_bwd_with_column_sums(gen):
 
 
 # ------------------------------------------------------------------------------------------------ loss / optimiser
-def test_softmax_cce_loss_fwd_bwd(gen):
+@pytest.mark.parametrize("C", [3, 2, 4])       # 3: the unrolled kernel of the reference's class count; others: the run-time class loop
+def test_softmax_cce_loss_fwd_bwd(gen, C):
     from ultrasound_modeling_amd import ops
-    B, H, W, C = 2, 9, 11, 3
+    B, H, W = 2, 9, 11
     logits = torch.randn(B, H, W, C, generator=gen, dtype=torch.float64).float().double() * 3
-    logits[0, 0, 0] = torch.tensor([40.0, -40.0, 0.0])   # forces the 1e-7 clip branch
-    x_, y = O.synthetic_batch(B, 16, 16, 1, seed=3)
-    y = y[:, :H, :W].float().double()
+    logits[0, 0, 0] = torch.tensor([40.0, -40.0, 0.0, 0.0][:C])   # forces the 1e-7 clip branch
+    if C == 3:
+        x_, y = O.synthetic_batch(B, 16, 16, 1, seed=3)
+        y = y[:, :H, :W].float().double()
+    else:
+        y = torch.softmax(2 * torch.randn(B, H, W, C, generator=gen, dtype=torch.float64), -1).float().double()
     lr = logits.clone().requires_grad_(True)
     probs_ref = O.softmax_lastaxis(lr)
     loss_ref = O.compute_loss(y, probs_ref, global_batch_size=4)
     loss_ref.backward()
     lg = torch.zeros(B, H, W, 4)
-    lg[..., :3] = logits.float()
+    lg[..., :C] = logits.float()
     lg = lg.to(DEV)
     probs = torch.empty(B, H, W, C, device=DEV)
     loss = torch.zeros(ops.ACC_FLOATS, device=DEV)            # reproducible accumulator: [0] is the scalar
@@ -592,8 +596,8 @@ def test_softmax_cce_loss_fwd_bwd(gen):
     assert rel(probs, probs_ref.detach()) < 1e-5
     assert abs(loss[0].item() - loss_ref.item()) / abs(loss_ref.item()) < 1e-5
     assert loss[1].item() == 0                                # the ticket counter is back at zero
-    assert rel(dl[..., :3], bf(lr.grad)) < REL_BF16
-    assert dl[..., 3:].abs().max().item() == 0
+    assert rel(dl[..., :C], bf(lr.grad)) < REL_BF16
+    assert dl[..., C:].abs().max().item() == 0
 
 
 def test_clip_adam_matches_oracle(gen):
