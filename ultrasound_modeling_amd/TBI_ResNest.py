@@ -139,8 +139,13 @@ class _SlabA:
         key = self.br[0][0].kernel.grad.data_ptr()
         if getattr(self, "_unp_key", None) != key:
             T = self.k * self.k
-            s1 = torch.zeros(self.cin_p * self.Up, dtype=torch.float32, device=dev)
-            s2 = torch.zeros(T * self.Up * self.Vp, dtype=torch.float32, device=dev)
+            n1, n2 = self.cin_p * self.Up, T * self.Up * self.Vp
+            pool = getattr(self, "_scratch_pool", None)        # (buffer, offset): slices of the model's ONE scratch (zeroed by one launch)
+            if pool is not None:
+                s1, s2 = pool[0][pool[1]:pool[1] + n1], pool[0][pool[1] + n1:pool[1] + n1 + n2]
+            else:
+                s1 = torch.zeros(n1, dtype=torch.float32, device=dev)
+                s2 = torch.zeros(n2, dtype=torch.float32, device=dev)
             sT = self.cv11 * self.cvkk
             j1 = [ops.unpack_job(s1, self.cin_p, self.Up, 1, self.cv11, self.cin, gi * self.cv11, 0, c1.kernel.grad, 0, 1, self.cv11)
                   for gi, (c1, _, c2, _) in enumerate(self.br)]
@@ -162,13 +167,15 @@ class _SlabA:
         s1, s2, tab1, tab2 = self._unpack_tables(dev)
         # 12 (path, radix) blocks > the 4 of a mapped destination: the dense gradient goes through this slab's private scratch and
         # its diagonal blocks are scattered (one launch) once the deferred split-K finishes have run at the end of the backward pass
-        ops.fill_f32(s2, 0.0)
+        if getattr(self, "_scratch_pool", None) is None:
+            ops.fill_f32(s2, 0.0)
         ops.conv2d_wgrad(u, dv, self.k, 1, s2)
         ops.after_flush(lambda: ops.unpack_wgrad_batched(tab2))
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, 1, torch.empty_like(u))
         du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, 1, 1, e, ACT_ELU, 1.0,
                                   self.m1, self.v1, dbias=self.db1)
-        ops.fill_f32(s1, 0.0)
+        if getattr(self, "_scratch_pool", None) is None:
+            ops.fill_f32(s1, 0.0)
         ops.conv2d_wgrad(x, du_raw, 1, 1, s1)
         ops.after_flush(lambda: ops.unpack_wgrad_batched(tab1))
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
@@ -389,6 +396,16 @@ class _ResModel(nn.Module):
             d = self._qt[name].backward(draw, bias_grad=False) if name in self._qt else self._tconv_backward(g(name + "_t_conv"), draw)
         # d = gradient w.r.t. pool6 (the input of upsample_0); pool5..pool1 also feed the decoder concats (dpool)
         stages = self._build()
+        # the grouped convs' dense weight gradients go through private scratch (zero before each backward pass): one buffer, one fill
+        if getattr(self, "_wscratch", None) is None or self._wscratch.device != d.device:
+            sizes = [(sl, sl.cin_p * sl.Up + sl.k * sl.k * sl.Up * sl.Vp) for st in stages for sl in st.slabs]
+            buf = torch.zeros(sum(n for _, n in sizes), dtype=torch.float32, device=d.device)
+            off = 0
+            for sl, n in sizes:
+                sl._scratch_pool, sl._unp_key = (buf, off), None
+                off += n
+            object.__setattr__(self, "_wscratch", buf)
+        ops.fill_f32(self._wscratch, 0.0)
         for i in reversed(range(5)):
             d = stages[i].backward(self._pools[i + 1].backward(d))   # through pool_{i+2} and stage i -> w.r.t. pool_{i+1}
             d = self._add(d, dpool[i])                               # + the skip branch of the decoder concat
