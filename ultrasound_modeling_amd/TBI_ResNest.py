@@ -152,6 +152,7 @@ class _SlabA:
             j2 = [ops.unpack_job(s2, self.Up, self.Vp, T, self.cvkk, self.cv11, gi * self.cvkk, gi * self.cv11, c2.kernel.grad, sT, 1, self.cvkk)
                   for gi, (c1, _, c2, _) in enumerate(self.br)]
             self._unp = (s1, s2, ops.make_unpack_table(j1, dev), ops.make_unpack_table(j2, dev))
+            self._unp_jobs = j1 + j2
             self._unp_key = key
         return self._unp
 
@@ -170,14 +171,16 @@ class _SlabA:
         if getattr(self, "_scratch_pool", None) is None:
             ops.fill_f32(s2, 0.0)
         ops.conv2d_wgrad(u, dv, self.k, 1, s2)
-        ops.after_flush(lambda: ops.unpack_wgrad_batched(tab2))
+        if not getattr(self, "_unpack_merged", False):       # (the model scatters every slab's blocks in ONE launch after the final flush)
+            ops.after_flush(lambda: ops.unpack_wgrad_batched(tab2))
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, 1, torch.empty_like(u))
         du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, 1, 1, e, ACT_ELU, 1.0,
                                   self.m1, self.v1, dbias=self.db1)
         if getattr(self, "_scratch_pool", None) is None:
             ops.fill_f32(s1, 0.0)
         ops.conv2d_wgrad(x, du_raw, 1, 1, s1)
-        ops.after_flush(lambda: ops.unpack_wgrad_batched(tab1))
+        if not getattr(self, "_unpack_merged", False):
+            ops.after_flush(lambda: ops.unpack_wgrad_batched(tab1))
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
 
 
@@ -406,6 +409,17 @@ class _ResModel(nn.Module):
                 off += n
             object.__setattr__(self, "_wscratch", buf)
         ops.fill_f32(self._wscratch, 0.0)
+        slabs = [sl for st in stages for sl in st.slabs]
+        key = tuple(sl.br[0][0].kernel.grad.data_ptr() for sl in slabs)
+        if getattr(self, "_unp_all_key", None) != key:       # one job table for the diagonal-block scatter of every slab
+            jobs = []
+            for sl in slabs:
+                sl._unpack_tables(d.device)
+                sl._unpack_merged = True
+                jobs += sl._unp_jobs
+            object.__setattr__(self, "_unp_all", ops.make_unpack_table(jobs, d.device))
+            object.__setattr__(self, "_unp_all_key", key)
+        ops.after_flush(lambda: ops.unpack_wgrad_batched(self._unp_all))
         for i in reversed(range(5)):
             d = stages[i].backward(self._pools[i + 1].backward(d))   # through pool_{i+2} and stage i -> w.r.t. pool_{i+1}
             d = self._add(d, dpool[i])                               # + the skip branch of the decoder concat
