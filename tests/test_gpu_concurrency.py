@@ -1,0 +1,79 @@
+"""Results must not depend on what else the GPU is doing.  Found in round 2: with the compiler's packed-fp32 code (v_pk_fma_f32 /
+v_pk_add_f32) the grouped per-pixel LayerNorm kernel returned wrong group sums for some pixels whenever ANOTHER stream kept the GPU busy
+(35-40 % of its launches; never when alone) - the training step was timing-dependent, and running the decoder's weight gradients on
+the side stream made the encoder's gradients nondeterministic.  pointwise.hip is built without packed-fp32 code since
+(csrc/Makefile); these tests keep it that way: one launch and the whole step are repeated beside a GEMM + a streaming kernel on a
+second stream and must repeat bit for bit."""
+import pytest
+import torch
+
+import usseg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class _Load:
+    """An unrelated stream of MFMA + HBM work (own tensors, own stream)."""
+
+    def __init__(self):
+        self.s = torch.cuda.Stream()
+        self.a = torch.randn(2048, 2048, device=DEV, dtype=torch.bfloat16)
+        self.big = torch.empty(32 << 20, device=DEV)
+
+    def kick(self, n=4):
+        with torch.cuda.stream(self.s):
+            for _ in range(n):
+                self.c = self.a @ self.a
+                self.big.add_(1.0)
+
+
+@pytest.mark.parametrize("C,G", [(30, 3), (24, 3), (32, 1), (87, 3)])
+def test_grouped_layernorm_under_foreign_load(C, G):
+    from ultrasound_modeling_amd import ops
+    torch.manual_seed(C)
+    Cp = (C + 7) // 8 * 8
+    x = torch.zeros(16, 128, 128, Cp, dtype=torch.bfloat16, device=DEV)
+    x[..., :C] = torch.randn(16, 128, 128, C, device=DEV).to(torch.bfloat16)
+    gamma, beta = (1 + 0.1 * torch.randn(C, device=DEV)).float(), (0.1 * torch.randn(C, device=DEV)).float()
+    dy = torch.zeros_like(x)
+    dy[..., :C] = torch.randn(16, 128, 128, C, device=DEV).to(torch.bfloat16)
+
+    def run():
+        y = ops.norm_act_fwd(x, C, gamma, beta, torch.empty_like(x), 0, G, 1e-3, ops.ACT_LRELU, 0.3)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx = ops.norm_act_bwd(x, dy, C, gamma, beta, torch.empty_like(x), dg, db, 0, G, 1e-3, ops.ACT_LRELU, 0.3)
+        return y, dx, dg, db
+    ref = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    load = _Load()
+    for _ in range(12):
+        load.kick()
+        outs = [run() for _ in range(6)]
+        torch.cuda.synchronize()
+        for o in outs:
+            for t, r, name in zip(o, ref, ("y", "dx", "dgamma", "dbeta")):
+                assert torch.equal(t, r), f"{name} changed under concurrent load: {(t != r).sum().item()} elements"
+
+
+def test_training_step_under_foreign_load():
+    """Arch B at the bench size, learning rate 0 (every step has identical inputs): gradients and probabilities must repeat bit for bit
+    while a second stream keeps the GPU busy - HIP-graph replay, i.e. with the decoder's weight gradients on the side stream."""
+    from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
+    net = VisionTransformer(batch_size=16, img_size=(256, 256), in_channels=1, seed=0, learning_rate=0.0)
+    x, y = O.synthetic_batch(16, 256, 256, 1, seed=40)
+    x, y = x.to(DEV), y.float().to(DEV)
+    net.capture_graph(x, y)
+    load = _Load()
+    ref = None
+    for i in range(16):
+        load.kick(6)
+        loss, probs = net.train_step(x, y)
+        torch.cuda.synchronize()
+        cur = (net.flat.grad.clone(), probs.clone(), loss.clone())
+        if ref is None:
+            ref = cur
+            continue
+        assert torch.equal(cur[1], ref[1]), f"step {i}: probabilities changed under concurrent load"
+        assert torch.equal(cur[0], ref[0]), f"step {i}: {(cur[0] != ref[0]).sum().item()} gradient entries changed under concurrent load"
+        assert cur[2].item() == ref[2].item()

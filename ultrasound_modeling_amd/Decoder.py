@@ -157,8 +157,7 @@ class DecoderBlock(nn.Module):
         q = self.out_channels // 4
         convs = [getattr(self, f"conv{st}_{j}") for j in range(4)]
         dys = [draw[..., j * q:(j + 1) * q] for j in range(4)]
-        with ops.side_stream(convs[1]._x, draw):
-            ops.conv2d_wgrad_multi([convs[j].wgrad_job(dys[j]) for j in (1, 2, 3)])
+        ops.wgrad_later(lambda: ops.conv2d_wgrad_multi([convs[j].wgrad_job(dys[j]) for j in (1, 2, 3)]), convs[1]._x, draw)
         convs[0].backward(dys[0], need_dx=False, skip_bias=True)
         if _FUSED_DGRAD:
             ops.conv2d_dgrad_branches(draw, self._wd_cat[st], [c.k for c in convs], [c.dil for c in convs], [j * q for j in range(4)], q, dx)

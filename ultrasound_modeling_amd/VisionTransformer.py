@@ -434,7 +434,8 @@ class VisionTransformer(TrainStepDriver, nn.Module):
     def _forward_backward(self, x, y):
         probs, dlogits = self._forward_loss(x, y, with_grad=True)                      # :240-241
         with ops.overlap_region():              # finishing reductions deferred and batched until the optimiser needs them
-            d_hidden, d_feats = self.decoder.backward(dlogits)                         # :243
+            with ops.lazy_wgrads():             # the decoder's weight gradients run on the side stream beside the encoder's backward pass
+                d_hidden, d_feats = self.decoder.backward(dlogits)                     # :243
             self.transformer.backward(d_hidden, d_feats)
         return probs
 

@@ -178,11 +178,12 @@ class Conv2D(nn.Module):
         ``skip_wgrad``: the caller runs the weight gradient itself (a multi-job launch with its sibling branches)."""
         x = self._x
         if not (skip_wgrad and skip_bias):
-            with ops.side_stream(x, dy):          # parameter gradients: beside the backward-data chain
+            def params():                         # parameter gradients: beside the backward-data chain
                 if not skip_wgrad:
                     self._wgrad(x, dy)
                 if not skip_bias:
                     ops.colsum(dy, self.bias.grad, self.cout)
+            ops.wgrad_later(params, x, dy)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)
@@ -233,9 +234,10 @@ class Conv2DTranspose(Conv2D):
     def backward(self, dy, need_dx=True, dx=None, dx_residual=None, accumulate_dx=False):
         x = self._x
         T = self.k * self.k
-        with ops.side_stream(x, dy):
+        def params():
             ops.tconv2d_wgrad_mapped(x, dy, self.k, self._wgrad_map())
             ops.colsum(dy, self.bias.grad, self.cout)
+        ops.wgrad_later(params, x, dy)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)

@@ -141,6 +141,45 @@ def side_stream(*keep):
         yield
 
 
+# Lazy weight gradients (USSEG_LAZY_WGRAD, default on): inside ``lazy_wgrads()`` the weight-gradient launches handed to
+# ``wgrad_later`` are only collected; at the end of the block they all run on the side stream behind ONE fork, beside whatever the
+# main stream does next (the encoder's backward pass), and join at the end of the overlap region.  The per-layer fork of
+# ``side_stream`` (USSEG_SIDE_STREAM=1) costs a cross-stream edge per launch, which made it slower than a single stream.
+_LAZY = os.environ.get("USSEG_LAZY_WGRAD", "1") != "0"
+_lazy_q = None
+
+
+@contextlib.contextmanager
+def lazy_wgrads():
+    global _lazy_q
+    if not _LAZY or _Side.depth == 0 or _lazy_q is not None:
+        yield
+        return
+    _lazy_q = []
+    try:
+        yield
+    finally:
+        q, _lazy_q = _lazy_q, None
+        if q:
+            enabled, _Side.enabled = _Side.enabled, True
+            try:
+                with side_stream(*[t for _, keep in q for t in keep]):
+                    for fn, _ in q:
+                        fn()
+            finally:
+                _Side.enabled = enabled
+
+
+def wgrad_later(fn, *keep):
+    """Run ``fn`` (weight-gradient launches reading the tensors ``keep``) now - on the side stream if that is enabled - or, inside
+    ``lazy_wgrads()``, at the end of that block."""
+    if _lazy_q is not None:
+        _lazy_q.append((fn, keep))
+        return
+    with side_stream(*keep):
+        fn()
+
+
 def side_join():
     if _Side.dirty:
         with torch.cuda.stream(_Side.stream):
