@@ -26,6 +26,8 @@ The storage type is bf16 (the build's choice for every path; BASELINE quotes fp1
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from typing import List, Optional
 
 import torch
@@ -36,6 +38,8 @@ from . import ops
 from .flat import AdamClip, FlatParams
 from .layers import Conv2D
 from .ops import ACT_GELU, ACT_NONE, BF16, roundup
+
+_LAZY_BLOCK = os.environ.get("USSEG_SWIN_LAZY", "1") != "0"     # per-block lazy weight gradients (ops.lazy_wgrads)
 
 CFGS = {   # SwinTransformer.py:8-21
     "swin_tiny_224": dict(input_size=(224, 224), window_size=4, embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24]),
@@ -231,7 +235,8 @@ class BasicLayer(nn.Module):
             if dfeature is not None:
                 ops.copy_channels(dfeature, dy, accumulate=True)
         for blk in reversed(self.blocks):
-            dy = blk.backward(dy)
+            with ops.lazy_wgrads() if _LAZY_BLOCK else contextlib.nullcontext():    # this block's weight gradients run beside the next block's backward pass
+                dy = blk.backward(dy)
         return dy
 
 

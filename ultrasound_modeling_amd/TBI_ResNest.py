@@ -385,9 +385,14 @@ class _ResModel(nn.Module):
         return self.out_hw[1] if self._quad is not None else 0
 
     def backward(self, dlogits):
+        dpool = [None] * 6                    # gradients w.r.t. pool1..pool6 outputs coming from the decoder skips
+        with ops.lazy_wgrads():               # the up-convolutions' weight gradients run on the side stream beside the stages' backward pass
+            d = self._decoder_backward(dlogits, dpool)
+        return self._stages_backward(d, dpool)
+
+    def _decoder_backward(self, dlogits, dpool):
         g = lambda n: getattr(self, n)
         d = self._quad.backward(dlogits) if self._quad is not None else g("f_tran").backward(dlogits)
-        dpool = [None] * 6                    # gradients w.r.t. pool1..pool6 outputs coming from the decoder skips
         for i in reversed(range(5)):
             name, oc, drop = self.UPS[i]
             dpool[4 - i] = d[..., oc:]        # skip branch of the concat
@@ -397,7 +402,10 @@ class _ResModel(nn.Module):
                                     1, 1, KERAS_BN_EPS, ACT_RELU, 0.0, bn.moving_mean_p, bn.moving_variance_p,
                                     dbias=g(name + "_t_conv").bias.grad, mask=self._masks[i])
             d = self._qt[name].backward(draw, bias_grad=False) if name in self._qt else self._tconv_backward(g(name + "_t_conv"), draw)
-        # d = gradient w.r.t. pool6 (the input of upsample_0); pool5..pool1 also feed the decoder concats (dpool)
+        return d                              # w.r.t. pool6 (the input of upsample_0); pool5..pool1 also feed the decoder concats (dpool)
+
+    def _stages_backward(self, d, dpool):
+        g = lambda n: getattr(self, n)
         stages = self._build()
         # the grouped convs' dense weight gradients go through private scratch (zero before each backward pass): one buffer, one fill
         if getattr(self, "_wscratch", None) is None or self._wscratch.device != d.device:
@@ -445,8 +453,8 @@ class _ResModel(nn.Module):
     def _tconv_backward(layer, dy):
         # Conv2DTranspose.backward computes the bias gradient itself; here it came from the BN backward (dbias)
         x = layer._x
-        with ops.side_stream(x, dy):           # straight into the Keras [k,k,Cout,Cin] variable, slabs instead of atomics
-            ops.tconv2d_wgrad_mapped(x, dy, layer.k, layer._wgrad_map())
+        # straight into the Keras [k,k,Cout,Cin] variable, slabs instead of atomics
+        ops.wgrad_later(lambda: ops.tconv2d_wgrad_mapped(x, dy, layer.k, layer._wgrad_map()), x, dy)
         B, H, W, _, _ = ops.geom(x)
         return ops.tconv2d_dgrad(dy, layer.wp_d, layer.k, ops.new_act(B, H, W, layer.cin_p, dy.device))
 

@@ -13,6 +13,7 @@ actually build; its variables carry the reference's attribute paths (``transform
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Optional
 
@@ -30,6 +31,7 @@ from .ops import BF16, roundup
 from .step import TrainStepDriver
 
 input_size = (256, 80)   # VisionTransformer.py:7
+_VIT_LAZY = os.environ.get("USSEG_VIT_LAZY", "enc")              # ops.lazy_wgrads over the whole encoder ("enc"), per block, or "0"
 _FUSED_ATTN = os.environ.get("USSEG_FUSED_ATTN", "1") != "0"   # train-step attention on csrc/flash_attn.hip (head size 128)
 
 
@@ -167,8 +169,10 @@ class Attention(nn.Module):
         # fused projection backward: the [hidden, 3*hidden] gradient is scattered straight into the three Dense kernels
         # (one destination block each) - no shared scratch that a deferred split-K finish would still be filling
         B, N, _, hs = xn.shape
-        ops.conv2d_wgrad_mapped(xn, dqkv, 1, 1, self._qkv_map())
-        ops.colsum(dqkv, self.db_qkv, 3 * hs)
+        def params():
+            ops.conv2d_wgrad_mapped(xn, dqkv, 1, 1, self._qkv_map())
+            ops.colsum(dqkv, self.db_qkv, 3 * hs)
+        ops.wgrad_later(params, xn, dqkv)
         return ops.conv2d_dgrad(dqkv, self.w_d, 1, 1, ops.new_act(B, N, 1, hs, xn.device))
 
     def backward(self, d_out):
@@ -262,7 +266,8 @@ class Encoder(nn.Module):
     def backward(self, d):
         d = self.encoder_norm.backward(d)
         for blk in reversed(self.Transformer_layers):
-            d = blk.backward(d)
+            with ops.lazy_wgrads() if _VIT_LAZY == "block" else contextlib.nullcontext():
+                d = blk.backward(d)
         return d
 
 
@@ -285,7 +290,9 @@ class Transformer(nn.Module):
     def backward(self, d_hidden, d_feats):
         if self.encoder is not None:
             B, N, hs = d_hidden.shape
-            d_hidden = self.encoder.backward(d_hidden.reshape(B, N, 1, hs).contiguous()).reshape(B, N, hs)
+            # the blocks' weight gradients run beside the hybrid embedding's (ResNeSt) backward pass
+            with ops.lazy_wgrads() if _VIT_LAZY == "enc" else contextlib.nullcontext():
+                d_hidden = self.encoder.backward(d_hidden.reshape(B, N, 1, hs).contiguous()).reshape(B, N, hs)
         self.embeddings.backward(d_hidden, d_feats)
 
 

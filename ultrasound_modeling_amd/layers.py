@@ -292,7 +292,7 @@ class QuadHead:
     def backward(self, dl4, need_dx=True):
         """dl4: bf16 [B,h,w,16] gradient of the quad-form logits -> dx [B,h,w,cin]."""
         h, x = self.head, self._x
-        with ops.side_stream(x, dl4):
+        def params():
             ops.fill_f32(self._dq16, 0.0)
             ops.conv2d_wgrad(x, dl4, 3, 1, self.dq)
             ops.colsum(dl4, self.d16, 16)
@@ -301,6 +301,7 @@ class QuadHead:
                 ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, 4, h.k, h.kernel.grad)
                 ops.quad_bias_fold(self.d16, h.cout, h.bias.grad)
             ops.after_flush(fold)
+        ops.wgrad_later(params, x, dl4)
         if not need_dx:
             return None
         B, H, W, _, _ = ops.geom(x)
@@ -359,13 +360,14 @@ class QuadTConv:
         B, H, W, _, _ = ops.geom(x)
         dy4 = ops.new_act(B, H, W, 4 * self.Np, x.device)
         ops.space_to_depth2(dy, dy4, self.Np, to_quad=True)
-        with ops.side_stream(x, dy4, dy):
+        def params():
             ops.fill_f32(self.dq, 0.0)
             ops.tconv_quad_wgrad(x, dy4, h.k, self.Np, self.dq)
             ops.defer_flush()                                      # dq is read right away
             ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, self.Np, h.k, h.kernel.grad)
             if bias_grad:
                 ops.colsum(dy, h.bias.grad, h.cout)
+        ops.wgrad_later(params, x, dy4, dy)
         if not need_dx:
             return None
         return ops.tconv_quad_dgrad(dy4, self.wq_d, h.k, self.Np, ops.new_act(B, H, W, h.cin_p, x.device))
