@@ -17,6 +17,7 @@ How a ``residual_S`` stage is executed (ResNest.py:89-104):
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List
 
@@ -31,6 +32,9 @@ from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 
 # see Decoder._FOLD_BN: convtmp_1bn's scale is folded into convtmp_1's packed forward operand (convtmp_2bn stays unfolded: it is
 # already fused with the pool that follows it)
+# per-stage lazy weight gradients in the encoder's backward pass: off - the side stream already carries the decoder's (and the ViT
+# blocks') weight gradients beside this encoder, and more forks made Arch B 1 % and cfg4 3 % slower
+_STAGE_LAZY = os.environ.get("USSEG_ENC_LAZY", "0") != "0"
 _FOLD_BN = os.environ.get("USSEG_FOLD_BN", "1") != "0"
 
 
@@ -250,13 +254,11 @@ class _CardinalGroup:
                                  KERAS_LN_EPS, ACT_LRELU, a, sa_s, sa_dg, float(self.radix), *self.st2, dbias=self.db2)
         # grouped 3x3: dense wgrad into scratch, keep the diagonal blocks
         # grouped 3x3: the dense [T][Up][Vp] gradient is never materialised - only the diagonal blocks are scattered
-        with ops.side_stream(u, dv):
-            ops.conv2d_wgrad_mapped(u, dv, self.k, self.dil, self._maps()[1])
+        ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(u, dv, self.k, self.dil, self._maps()[1]), u, dv)
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, self.dil, torch.empty_like(u))
         du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, self.nmode, self.ngroups,
                                   KERAS_LN_EPS, ACT_LRELU, a, *self.st1, dbias=self.db1)
-        with ops.side_stream(x, du_raw):
-            ops.conv2d_wgrad_mapped(x, du_raw, 1, 1, self._maps()[0])
+        ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(x, du_raw, 1, 1, self._maps()[0]), x, du_raw)
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
 
 
@@ -365,13 +367,19 @@ class ResNest(nn.Module):
         """Gradients w.r.t. (x_4, [x_3, x_2, x_1]) -> accumulates all parameter gradients (input gradient not needed)."""
         d_x3, d_x2, d_x1 = d_feats
         # the pool backward in front of a stage also sums its output over the pixels: that stage's concats_2 bias gradient
-        d = self.conv_4.backward(d_x4)
+        # each stage's weight gradients run on the side stream beside the next stage's backward-data chain (ops.lazy_wgrads)
+        lazy = ops.lazy_wgrads if _STAGE_LAZY else contextlib.nullcontext
+        with lazy():
+            d = self.conv_4.backward(d_x4)
         d = self.conv4_pool.backward(d, add=d_x3, db=self.conv_3.concats_2.bias.grad)
-        d = self.conv_3.backward(d, bias_done=True)
+        with lazy():
+            d = self.conv_3.backward(d, bias_done=True)
         d = self.conv3_pool.backward(d, add=d_x2, db=self.conv_2.concats_2.bias.grad)
-        d = self.conv_2.backward(d, bias_done=True)
+        with lazy():
+            d = self.conv_2.backward(d, bias_done=True)
         d = self.conv2_pool.backward(d, add=d_x1, db=self.conv_1.concats_2.bias.grad)
-        d = self.conv_1.backward(d, bias_done=True)
+        with lazy():
+            d = self.conv_1.backward(d, bias_done=True)
         a = KERAS_LRELU_ALPHA
         if self._pool_fused:
             d = self.convtmp_2bn.backward_pool(d, dbias=self.convtmp_2.bias.grad)
