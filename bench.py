@@ -335,12 +335,13 @@ def main():
         P = args.profile_steps
         from ultrasound_modeling_amd import ops as _ops
         side_saved, _ops._Side.enabled = _ops._Side.enabled, False   # per-kernel durations: no weight-gradient launches running beside them
+        lazy_saved, _ops._LAZY = _ops._LAZY, False
         xp, yp = net._prep_x(x), net._prep_y(y)
         _lib.check(lib.usseg_prof_enable(3, 4096 * P), "prof_enable")
         for _ in range(P):
             net._train_body(xp, yp)
         torch.cuda.synchronize()
-        _ops._Side.enabled = side_saved
+        _ops._Side.enabled, _ops._LAZY = side_saved, lazy_saved
         ms, n = ctypes.c_double(), ctypes.c_int64()
         _lib.check(lib.usseg_prof_read(1, ctypes.byref(ms), ctypes.byref(n)), "prof_read")
         ig_ms, ig_n = ms.value / P, n.value // P

@@ -7,9 +7,13 @@ R=${1:-r02}; V=${2:-v1}; ARCH=${3:-B}
 TAG=${R}_${V}_arch${ARCH}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out profiles
-rocprofv3 --kernel-trace --stats -d gpurun_out/stats_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > gpurun_out/stats_$TAG.log 2>&1
+# per-kernel statistics on ONE stream (USSEG_LAZY_WGRAD=0: no weight-gradient launches running beside the kernel being timed - what bench.py's
+# roofline leg measures too), then the step as shipped (lazy weight gradients on the side stream) for the timeline
+USSEG_LAZY_WGRAD=0 rocprofv3 --kernel-trace --stats -d gpurun_out/stats_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > gpurun_out/stats_$TAG.log 2>&1
 cp gpurun_out/stats_$TAG/r_kernel_stats.csv profiles/${R}_kernel_stats_${V}_arch${ARCH}.csv
-python3 tools/step_timeline.py gpurun_out/stats_$TAG/r_kernel_trace.csv profiles/${R}_step_timeline_${V}_arch${ARCH}.txt
+python3 tools/step_timeline.py gpurun_out/stats_$TAG/r_kernel_trace.csv profiles/${R}_step_timeline_1stream_${V}_arch${ARCH}.txt
+rocprofv3 --kernel-trace --stats -d gpurun_out/stats2_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > gpurun_out/stats2_$TAG.log 2>&1
+python3 tools/step_timeline.py gpurun_out/stats2_$TAG/r_kernel_trace.csv profiles/${R}_step_timeline_${V}_arch${ARCH}.txt
 # eager run (--no-graph): 1 warm-up + 3 timed = 4 steps in the process
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_f_$TAG.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_w_$TAG.log 2>&1
