@@ -360,6 +360,27 @@ def test_layernorm_grouped_fwd_bwd(gen, B, H, W, C, G):
     assert rel(dbet[:C], br.grad) < REL_F32
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 6, 5, 96), (1, 32, 32, 512), (3, 7, 9, 40), (1, 2, 2, 8)])
+def test_layernorm_backward_with_residual(gen, B, H, W, C):
+    """usseg_norm_act_bwd_res (the residual branch of a pre-norm transformer block, VisionTransformer.py:137-146 /
+    SwinTransformer.py:224-257) == usseg_norm_act_bwd + an accumulating copy, bit for bit; and LN'(dy) + dres against autograd."""
+    from ultrasound_modeling_amd import ops
+    x, dy, dres = rnd(gen, B, H, W, C), rnd(gen, B, H, W, C), rnd(gen, B, H, W, C)
+    gamma = (1 + 0.3 * torch.randn(C, generator=gen, dtype=torch.float64)).float().double()
+    beta = (0.2 * torch.randn(C, generator=gen, dtype=torch.float64)).float().double()
+    xd, dyd, drd = to_dev_padded(x), to_dev_padded(dy), to_dev_padded(dres)
+    g, b = gamma.float().to(DEV), beta.float().to(DEV)
+    dg1, db1, dg2, db2 = (torch.zeros(C, device=DEV) for _ in range(4))
+    sep = ops.norm_act_bwd(xd, dyd, C, g, b, torch.empty_like(xd), dg1, db1, 0, 1, 1e-5)
+    ops.copy_channels(drd, sep, accumulate=True)
+    fused = ops.norm_act_bwd_res(xd, dyd, C, g, b, drd, torch.full_like(xd, float("nan")), dg2, db2, 1e-5)
+    assert torch.equal(fused, sep) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    (O.layer_norm(xr, gr, br, eps=1e-5) * dy).sum().backward()
+    assert rel(fused[..., :C], bf(bf(xr.grad) + dres)) < 2 * REL_BF16      # two roundings, as the separate launches
+    assert rel(dg2, gr.grad) < REL_F32 and rel(db2, br.grad) < REL_F32
+
+
 @pytest.mark.parametrize("C,act", [(32, 1), (16, 1), (64, 3), (24, 2)])
 def test_batchnorm_inference_fwd_bwd(gen, C, act):
     from ultrasound_modeling_amd import ops

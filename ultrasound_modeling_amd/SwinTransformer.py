@@ -36,7 +36,7 @@ import torch.nn as nn
 from .step import TrainStepDriver
 from . import ops
 from .flat import AdamClip, FlatParams
-from .layers import Conv2D
+from .layers import _FUSE_LN_RES, Conv2D
 from .ops import ACT_GELU, ACT_NONE, BF16, roundup
 
 _LAZY_BLOCK = os.environ.get("USSEG_SWIN_LAZY", "1") != "0"     # per-block lazy weight gradients (ops.lazy_wgrads)
@@ -85,6 +85,15 @@ class LayerNorm(nn.Module):
             return ops.norm_act_bwd(self._x, dy, self.C, self.gamma.data, self.beta.data, torch.empty_like(self._x), self.gamma.grad, self.beta.grad,
                                     0, 1, self.eps)
         return ops.ln_wide_bwd(self._x, dy, self.gamma.data, self.eps, torch.empty_like(self._x), self.gamma.grad, self.beta.grad)
+
+    def backward_residual(self, dy, dres):
+        """Backward of x + f(norm(x)) w.r.t. x; one pass up to 512 channels (the bits of backward() + an accumulating copy)."""
+        if self.C <= 512 and _FUSE_LN_RES:
+            return ops.norm_act_bwd_res(self._x, dy, self.C, self.gamma.data, self.beta.data, dres, torch.empty_like(self._x), self.gamma.grad,
+                                        self.beta.grad, self.eps)
+        dx = self.backward(dy)
+        ops.copy_channels(dres, dx, accumulate=True)
+        return dx
 
 
 class Dense(Conv2D):
@@ -176,11 +185,8 @@ class SwinTransformerBlock(nn.Module):
         return self.mlp.forward(self.norm2.forward(a), residual=a)                      # :257 x + mlp(norm2(x))
 
     def backward(self, dy):
-        da = self.norm2.backward(self.mlp.backward(dy))
-        ops.copy_channels(dy, da, accumulate=True)                                      # residual branch of :257
-        dx = self.norm1.backward(self.attn.backward(da))
-        ops.copy_channels(da, dx, accumulate=True)                                      # residual branch of :256
-        return dx
+        da = self.norm2.backward_residual(self.mlp.backward(dy), dy)                    # + the residual branch of :257
+        return self.norm1.backward_residual(self.attn.backward(da), da)                 # + the residual branch of :256
 
 
 class PatchMerging(nn.Module):

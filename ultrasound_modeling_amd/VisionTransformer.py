@@ -240,11 +240,8 @@ class Block(nn.Module):
         return self.ffn.forward(self.ffn_norm.forward(a), residual=a), weights                            # :142-146
 
     def backward(self, d):
-        da = self.ffn_norm.backward(self.ffn.backward(d))
-        ops.copy_channels(d, da, accumulate=True)               # residual branch of x = x + h (:145)
-        dx = self.attention_norm.backward(self.attn.backward(da))
-        ops.copy_channels(da, dx, accumulate=True)              # residual branch (:140)
-        return dx
+        da = self.ffn_norm.backward_residual(self.ffn.backward(d), d)              # + the residual branch of x = x + h (:145)
+        return self.attention_norm.backward_residual(self.attn.backward(da), da)    # + the residual branch (:140)
 
 
 class Encoder(nn.Module):

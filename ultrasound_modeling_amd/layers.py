@@ -11,6 +11,7 @@ Activations are bf16 ``[B,H,W,Cphys]`` with Cphys = roundup(C, 8) and zero pad c
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -18,6 +19,8 @@ import torch.nn as nn
 
 from . import ops
 from .ops import ACT_ELU, ACT_LRELU, ACT_NONE, ACT_RELU, BF16, roundup
+
+_FUSE_LN_RES = os.environ.get("USSEG_FUSE_LN_RES", "1") != "0"    # LayerNorm backward + residual add in one pass (transformer blocks)
 
 KERAS_LRELU_ALPHA = 0.3   # tf.keras.layers.LeakyReLU() default
 KERAS_ELU_ALPHA = 1.0
@@ -401,6 +404,17 @@ class LayerNormalization(nn.Module):
         mean, var = self._stats()
         return ops.norm_act_bwd(x, dy, self.C, self.gamma.data, self.beta.data, dx, self.gamma.grad, self.beta.grad, self.mode,
                                 1, self.eps, act, alpha, mean, var, dbias)
+
+
+    def backward_residual(self, dy, dres):
+        """Backward of x + f(norm(x)) w.r.t. x: LN'(dy) + dres in one pass (the bits of backward() followed by an accumulating copy)."""
+        x = self._x
+        assert self.mode == 0 and self._act[0] == ACT_NONE
+        if not _FUSE_LN_RES:
+            dx = self.backward(dy)
+            ops.copy_channels(dres, dx, accumulate=True)
+            return dx
+        return ops.norm_act_bwd_res(x, dy, self.C, self.gamma.data, self.beta.data, dres, torch.empty_like(x), self.gamma.grad, self.beta.grad, self.eps)
 
 
 class BatchNormalization(LayerNormalization):
