@@ -247,9 +247,11 @@ int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const void* dy, co
                        float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
 /* LayerNormalization backward (mode 0, G = 1) + the residual branch around a pre-norm transformer block in one pass
  * (VisionTransformer.py:137-146, SwinTransformer.py:224-257: x = x + f(norm(x))): dx = bf16(bf16(LN backward) + dres) - the bits of
- * usseg_norm_act_bwd followed by usseg_copy_channels(accumulate).  dres: bf16 [M][lddres]. */
+ * usseg_norm_act_bwd followed by usseg_copy_channels(accumulate).  dres: bf16 [M][lddres].  dbias (may be NULL) += the column sums
+ * of the STORED dx: the bias gradient of the Dense layer whose output (plus a shortcut) this gradient belongs to (attention
+ * projection / the previous block's fc2) - no usseg_colsum pass for it. */
 int usseg_norm_act_bwd_res(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma, const float* beta,
-                           const void* dres, int32_t lddres, void* dx, float* dgamma, float* dbeta, float* ws,
+                           const void* dres, int32_t lddres, void* dx, float* dgamma, float* dbeta, float* dbias, float* ws,
                            usseg_stream_t stream);
 /* The split attention of a residual_S stage (ResNest.py:171-199) folded into the norms on either side of it:
  *  - usseg_norm_act_fwd_gap: the norm + activation that produces the cardinal output ALSO writes, per image and workgroup, the

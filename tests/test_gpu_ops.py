@@ -370,11 +370,14 @@ def test_layernorm_backward_with_residual(gen, B, H, W, C):
     beta = (0.2 * torch.randn(C, generator=gen, dtype=torch.float64)).float().double()
     xd, dyd, drd = to_dev_padded(x), to_dev_padded(dy), to_dev_padded(dres)
     g, b = gamma.float().to(DEV), beta.float().to(DEV)
-    dg1, db1, dg2, db2 = (torch.zeros(C, device=DEV) for _ in range(4))
+    dg1, db1, dg2, db2, dbias, cs = (torch.zeros(C, device=DEV) for _ in range(6))
     sep = ops.norm_act_bwd(xd, dyd, C, g, b, torch.empty_like(xd), dg1, db1, 0, 1, 1e-5)
     ops.copy_channels(drd, sep, accumulate=True)
-    fused = ops.norm_act_bwd_res(xd, dyd, C, g, b, drd, torch.full_like(xd, float("nan")), dg2, db2, 1e-5)
+    ops.colsum(sep, cs, C)
+    fused = ops.norm_act_bwd_res(xd, dyd, C, g, b, drd, torch.full_like(xd, float("nan")), dg2, db2, 1e-5, dbias)
     assert torch.equal(fused, sep) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    # the column sums of the stored result (a Dense bias gradient) without a pass over it
+    assert rel(dbias, sep[..., :C].double().sum((0, 1, 2))) < REL_F32 and rel(dbias, cs) < REL_F32
     xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     (O.layer_norm(xr, gr, br, eps=1e-5) * dy).sum().backward()
     assert rel(fused[..., :C], bf(bf(xr.grad) + dres)) < 2 * REL_BF16      # two roundings, as the separate launches

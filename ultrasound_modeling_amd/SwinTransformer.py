@@ -86,13 +86,16 @@ class LayerNorm(nn.Module):
                                     0, 1, self.eps)
         return ops.ln_wide_bwd(self._x, dy, self.gamma.data, self.eps, torch.empty_like(self._x), self.gamma.grad, self.beta.grad)
 
-    def backward_residual(self, dy, dres):
-        """Backward of x + f(norm(x)) w.r.t. x; one pass up to 512 channels (the bits of backward() + an accumulating copy)."""
+    def backward_residual(self, dy, dres, dbias=None):
+        """Backward of x + f(norm(x)) w.r.t. x; one pass up to 512 channels (the bits of backward() + an accumulating copy).
+        ``dbias`` (optional) += the column sums of the result: the bias gradient of the Dense layer that produced x's last term."""
         if self.C <= 512 and _FUSE_LN_RES:
             return ops.norm_act_bwd_res(self._x, dy, self.C, self.gamma.data, self.beta.data, dres, torch.empty_like(self._x), self.gamma.grad,
-                                        self.beta.grad, self.eps)
+                                        self.beta.grad, self.eps, dbias)
         dx = self.backward(dy)
         ops.copy_channels(dres, dx, accumulate=True)
+        if dbias is not None:
+            ops.colsum(dx, dbias, self.C)
         return dx
 
 
@@ -128,8 +131,8 @@ class Mlp(nn.Module):
         g = ops.act_fwd(self._h, torch.empty_like(self._h), ACT_GELU, 0.0)              # :34
         return self.fc2.forward(g, residual=residual)                                   # :36
 
-    def backward(self, dy):
-        dg = self.fc2.backward(dy)
+    def backward(self, dy, fc2_bias_done=False):
+        dg = Conv2D.backward(self.fc2, dy, skip_bias=fc2_bias_done)
         # GELU backward + fc1's bias gradient (column sums of its output) in one pass
         dh = ops.act_bwd_colsum(self._h, dg, torch.empty_like(dg), ACT_GELU, 0.0, self.fc1.bias.grad, self.fc1.cout)
         return Conv2D.backward(self.fc1, dh, skip_bias=True)
@@ -156,8 +159,8 @@ class WindowAttention(nn.Module):
                                   ops.new_act(B, H, W, C, x.device))                    # :110-136
         return self.proj.forward(ctx, residual=residual)                                # :137 (+ shortcut, :256)
 
-    def backward(self, dy):
-        dctx = self.proj.backward(dy)
+    def backward(self, dy, proj_bias_done=False):
+        dctx = Conv2D.backward(self.proj, dy, skip_bias=proj_bias_done)
         dqkv = ops.window_attn_bwd(self._qkv, dctx, self.relative_position_bias_table.data, self.num_heads, self.window_size, self._shift,
                                    torch.empty_like(self._qkv), self.relative_position_bias_table.grad)
         return self.qkv.backward(dqkv)
@@ -184,9 +187,12 @@ class SwinTransformerBlock(nn.Module):
         a = self.attn.forward(self.norm1.forward(x), self.shift_size, residual=x)       # :224-256 shortcut + attention
         return self.mlp.forward(self.norm2.forward(a), residual=a)                      # :257 x + mlp(norm2(x))
 
-    def backward(self, dy):
-        da = self.norm2.backward_residual(self.mlp.backward(dy), dy)                    # + the residual branch of :257
-        return self.norm1.backward_residual(self.attn.backward(da), da)                 # + the residual branch of :256
+    def backward(self, dy, fc2_bias_done=False, prev_fc2_bias=None):
+        """``fc2_bias_done``: the kernel that produced dy also summed it into this block's fc2 bias gradient; ``prev_fc2_bias``: the
+        bias gradient of the fc2 whose output (+ shortcut) is this block's input - summed by the kernel that produces dx."""
+        # + the residual branch of :257; the same pass sums da over the tokens = the attention projection's bias gradient
+        da = self.norm2.backward_residual(self.mlp.backward(dy, fc2_bias_done), dy, dbias=self.attn.proj.bias.grad)
+        return self.norm1.backward_residual(self.attn.backward(da, proj_bias_done=True), da, dbias=prev_fc2_bias)   # + the residual branch of :256
 
 
 class PatchMerging(nn.Module):
@@ -240,9 +246,12 @@ class BasicLayer(nn.Module):
             dy = self.downsample.backward(dy)
             if dfeature is not None:
                 ops.copy_channels(dfeature, dy, accumulate=True)
-        for blk in reversed(self.blocks):
+        done = False
+        for i in reversed(range(len(self.blocks))):
+            prev = self.blocks[i - 1].mlp.fc2.bias.grad if i > 0 else None
             with ops.lazy_wgrads() if _LAZY_BLOCK else contextlib.nullcontext():    # this block's weight gradients run beside the next block's backward pass
-                dy = blk.backward(dy)
+                dy = self.blocks[i].backward(dy, fc2_bias_done=done, prev_fc2_bias=prev)
+            done = prev is not None
         return dy
 
 

@@ -175,11 +175,11 @@ class Attention(nn.Module):
         ops.wgrad_later(params, xn, dqkv)
         return ops.conv2d_dgrad(dqkv, self.w_d, 1, 1, ops.new_act(B, N, 1, hs, xn.device))
 
-    def backward(self, d_out):
+    def backward(self, d_out, out_bias_done=False):
         if len(self._saved) == 5 and self._saved[3].dim() == 2:      # fused forward: probabilities recomputed from the log-sum-exp
             xn, qkv, ctx, lse, ctx32 = self._saved
             B, N, _, hs = xn.shape
-            dctx = self.out.backward(d_out)
+            dctx = self.out.backward(d_out, skip_bias=out_bias_done)
             dqkv = ops.new_act(B, N, 1, 3 * hs, xn.device)
             ops.flash_attn_bwd(qkv, self.num_heads, 1.0 / (float(self.num_heads) ** 0.5), ctx, dctx, lse, torch.empty_like(lse), dqkv, ctx32)
             return self._backward_tail(xn, dqkv)
@@ -187,7 +187,7 @@ class Attention(nn.Module):
         B, N, _, hs = xn.shape
         nh, dh, dev = self.num_heads, self.qkv_size, xn.device
         q, k, v = qkv[..., :hs], qkv[..., hs:2 * hs], qkv[..., 2 * hs:]
-        dctx = self.out.backward(d_out)
+        dctx = self.out.backward(d_out, skip_bias=out_bias_done)
         dqkv = ops.new_act(B, N, 1, 3 * hs, dev)
         s_pp, s_qkv, s_ctx, s_hd = (nh * N * N, N * N), (N * 3 * hs, dh), (N * hs, dh), (nh * N * dh, N * dh)
         dV = torch.zeros((B, nh, N, dh), dtype=torch.float32, device=dev)
@@ -217,8 +217,8 @@ class Mlp(nn.Module):
         g = ops.act_fwd(self._raw, torch.empty_like(self._raw), ops.ACT_GELU, 0.0)                       # :71
         return self.fc2.forward(g, residual=residual)                                                     # :72 (+ h, :145)
 
-    def backward(self, d):
-        dg = self.fc2.backward(d)
+    def backward(self, d, fc2_bias_done=False):
+        dg = self.fc2.backward(d, skip_bias=fc2_bias_done)
         # GELU backward + fc1's bias gradient (column sums of its output) in one pass
         dr = ops.act_bwd_colsum(self._raw, dg, torch.empty_like(dg), ops.ACT_GELU, 0.0, self.fc1.bias.grad, self.fc1.cout)
         return self.fc1.backward(dr, skip_bias=True)
@@ -239,9 +239,12 @@ class Block(nn.Module):
         a, weights = self.attn.forward(self.attention_norm.forward(x), residual=x, need_weights=need_weights)   # :137-140
         return self.ffn.forward(self.ffn_norm.forward(a), residual=a), weights                            # :142-146
 
-    def backward(self, d):
-        da = self.ffn_norm.backward_residual(self.ffn.backward(d), d)              # + the residual branch of x = x + h (:145)
-        return self.attention_norm.backward_residual(self.attn.backward(da), da)    # + the residual branch (:140)
+    def backward(self, d, fc2_bias_done=False, prev_fc2_bias=None):
+        """``fc2_bias_done``: the kernel that produced d also summed it into this block's fc2 bias gradient; ``prev_fc2_bias``: the bias
+        gradient of the fc2 whose output (+ shortcut) is this block's input - summed by the kernel that produces dx."""
+        # + the residual branch of x = x + h (:145); the same pass sums da over the tokens = the output projection's bias gradient
+        da = self.ffn_norm.backward_residual(self.ffn.backward(d, fc2_bias_done), d, dbias=self.attn.out.bias.grad)
+        return self.attention_norm.backward_residual(self.attn.backward(da, out_bias_done=True), da, dbias=prev_fc2_bias)   # + the residual branch (:140)
 
 
 class Encoder(nn.Module):
@@ -262,9 +265,12 @@ class Encoder(nn.Module):
 
     def backward(self, d):
         d = self.encoder_norm.backward(d)
-        for blk in reversed(self.Transformer_layers):
+        blocks, done = self.Transformer_layers, False
+        for i in reversed(range(len(blocks))):
+            prev = blocks[i - 1].ffn.fc2.bias.grad if i > 0 else None
             with ops.lazy_wgrads() if _VIT_LAZY == "block" else contextlib.nullcontext():
-                d = blk.backward(d)
+                d = blocks[i].backward(d, fc2_bias_done=done, prev_fc2_bias=prev)
+            done = prev is not None
         return d
 
 

@@ -342,7 +342,8 @@ __global__ __launch_bounds__(256, norm_occ(BWD, MODE, NG, FUSE, POOL)) void norm
         for (int j = 0; j < 8; ++j) o[j] = dxh[j] * rs_c[j];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dbi[j] += o[j];   // sum of dx = gradient of the producing conv's bias
+      for (int j = 0; j < 8; ++j)
+        if (!RES) dbi[j] += o[j];   // sum of dx = gradient of the producing conv's bias
       uint4 packed = pack8(o);
       if (RES && valid) {     // + the residual branch, on the bf16-rounded value: the bits of this kernel followed by an accumulating copy
         float a8[8], r8[8];
@@ -351,6 +352,9 @@ __global__ __launch_bounds__(256, norm_occ(BWD, MODE, NG, FUSE, POOL)) void norm
 #pragma unroll
         for (int j = 0; j < 8; ++j) a8[j] += r8[j];
         packed = pack8(a8);
+        unpack8(packed, a8);  // column sums of the STORED gradient: the bias gradient of the Dense layer whose output (+ a residual) it is the gradient of
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbi[j] += a8[j];
       }
       if (valid) *reinterpret_cast<uint4*>(p.dx + m * p.lddx + c0) = packed;
     }
@@ -437,7 +441,7 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
 // LayerNormalization backward + the residual branch around a pre-norm transformer block in one pass
 // (VisionTransformer.py:137-146, SwinTransformer.py:224-257: x = x + f(norm(x))  =>  dx = LN'(f'(dy)) + dy): dx = bf16(bf16(LN backward) + dres).
 extern "C" int usseg_norm_act_bwd_res(const UssegNormDesc* d, const void* x, const void* dy, const float* gamma, const float* beta,
-                                      const void* dres, int32_t lddres, void* dx, float* dgamma, float* dbeta, float* ws,
+                                      const void* dres, int32_t lddres, void* dx, float* dgamma, float* dbeta, float* dbias, float* ws,
                                       usseg_stream_t stream) {
   NormParams p = {};
   int rc = norm_common(d, p);
@@ -446,7 +450,7 @@ extern "C" int usseg_norm_act_bwd_res(const UssegNormDesc* d, const void* x, con
   USSEG_CHECK_ARG(d->mode == 0 && p.G == 1, "norm bwd res: plain LayerNormalization only (mode 0, one group)");
   USSEG_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "norm: gamma/beta must be 16-byte aligned (and readable up to Cphys floats)");
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.gamma = gamma; p.beta = beta;
-  p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = nullptr; p.ws = ws;
+  p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias; p.ws = ws;
   p.dres = (const bf16_t*)dres; p.lddres = lddres;
   p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->lddx > 0 ? d->lddx : d->ldx;
   USSEG_CHECK_ARG(p.lddx % 8 == 0 && p.lddx >= d->Cphys && lddres % 8 == 0 && lddres >= d->Cphys, "norm bwd res: bad dx / residual stride");
@@ -455,7 +459,7 @@ extern "C" int usseg_norm_act_bwd_res(const UssegNormDesc* d, const void* x, con
   unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
   p.ws = ws = usseg_defer_reduce_ws((hipStream_t)stream, ws, (int64_t)grid * 3 * p.Cphys);
   hipLaunchKernelGGL((norm_act_kernel<true, 0, 1, false, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, nullptr, (hipStream_t)stream);
+  usseg_launch_reduce_finish(ws, 1, (int)grid, 3, p.Cphys, p.C, 1.f, dgamma, dbeta, dbias, (hipStream_t)stream);
   return usseg_check_launch("norm_act_bwd_res");
 }
 

@@ -406,15 +406,19 @@ class LayerNormalization(nn.Module):
                                 1, self.eps, act, alpha, mean, var, dbias)
 
 
-    def backward_residual(self, dy, dres):
-        """Backward of x + f(norm(x)) w.r.t. x: LN'(dy) + dres in one pass (the bits of backward() followed by an accumulating copy)."""
+    def backward_residual(self, dy, dres, dbias=None):
+        """Backward of x + f(norm(x)) w.r.t. x: LN'(dy) + dres in one pass (the bits of backward() followed by an accumulating copy).
+        ``dbias`` (optional) += the column sums of the result: the bias gradient of the Dense layer that produced x's last term."""
         x = self._x
         assert self.mode == 0 and self._act[0] == ACT_NONE
         if not _FUSE_LN_RES:
             dx = self.backward(dy)
             ops.copy_channels(dres, dx, accumulate=True)
+            if dbias is not None:
+                ops.colsum(dx, dbias, self.C)
             return dx
-        return ops.norm_act_bwd_res(x, dy, self.C, self.gamma.data, self.beta.data, dres, torch.empty_like(x), self.gamma.grad, self.beta.grad, self.eps)
+        return ops.norm_act_bwd_res(x, dy, self.C, self.gamma.data, self.beta.data, dres, torch.empty_like(x), self.gamma.grad, self.beta.grad,
+                                    self.eps, dbias)
 
 
 class BatchNormalization(LayerNormalization):

@@ -529,12 +529,13 @@ def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, ep
     return dx
 
 
-def norm_act_bwd_res(x, dy, C_logical, gamma, beta, dres, dx, dgamma, dbeta, eps):
-    """Plain LayerNormalization backward + the residual branch of a pre-norm block: dx = bf16(bf16(LN'(dy)) + dres) in one pass."""
+def norm_act_bwd_res(x, dy, C_logical, gamma, beta, dres, dx, dgamma, dbeta, eps, dbias=None):
+    """Plain LayerNormalization backward + the residual branch of a pre-norm block: dx = bf16(bf16(LN'(dy)) + dres) in one pass;
+    ``dbias`` += the column sums of the stored dx."""
     B, H, W, Cphys, ldx = geom(x)
     d = NormDesc(B * H * W, C_logical, Cphys, ldx, geom(dy)[4], 1, 0, eps, ACT_NONE, 0.0, geom(dx)[4])
     L.check(L.load().usseg_norm_act_bwd_res(C.byref(d), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dres.data_ptr(),
-                                            geom(dres)[4], dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                            geom(dres)[4], dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias),
                                             reduce_ws(x.device).data_ptr(), _stream()), "norm_act_bwd_res")
     return dx
 
