@@ -213,6 +213,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // wave-instruction (8 rows x 8 slots, lane -> row lane/8, slot lane%8) keeps a fixed chunk per lane.
 typedef __attribute__((address_space(3))) void* igemm_lds_ptr_t;
 #define IGEMM_OOB 0x80000000u
+// The tap-table entry of a K step, read by inline assembly.  As a C++ load it is an LDS read that follows LDS-DMA writes the
+// compiler cannot tell apart from it, and SIInsertWaitcnts then puts `s_waitcnt vmcnt(0)` in front of it: every K step waited
+// for ALL stages in flight before issuing the next one - the ring never held more than one stage in flight, whatever NSTAGE
+// (the table lives in its own static array; the DMA only ever writes the dynamic stage ring).  Worth 3-5 % on the long-K launches.
+typedef int igemm_i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ igemm_i32x4_t igemm_tap_read(const int* entry) {
+  igemm_i32x4_t e;
+  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int*)entry;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(addr) : "memory");
+  return e;
+}
 
 template <int NT, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) {
@@ -283,8 +294,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   auto issue = [&](int stage) {
     char* const sb = lds_raw + stage * STAGE;
     const bool tv = ti < ntaps;
-    int4 e = *reinterpret_cast<const int4*>(s_tap4[tbase + (tv ? ti : 0)]);
-    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one table read, here (not sunk under the selects below)
+    const igemm_i32x4_t e = igemm_tap_read(s_tap4[tbase + (tv ? ti : 0)]);
     const int da = e.z + c8 * 8, dw = e.w + c8 * 8;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -322,7 +332,11 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   for (int ks = 0; ks < nks; ++ks) {
     // step ks has landed once at most the pieces of the younger steps are outstanding (vmcnt retires in issue order);
     // bare s_barrier: __syncthreads() would prepend a vmcnt(0)
-    if (D >= 2 && ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * NI) : "memory");
+    // (min(D-1, steps issued after ks) stages may stay in flight: near the end of the K loop fewer younger stages exist, and a wait
+    // sized for D-1 of them would let pieces of stage ks itself be outstanding)
+    static_assert(D <= 3, "the wait ladder below covers up to three stages in flight");
+    if (D >= 3 && ks + 2 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NI) : "memory");
+    else if (D >= 2 && ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // everyone is also done reading stage (ks-1) % NSTAGE, which the next issue overwrites
     if (ks + D < nks) issue((ks + D) % NSTAGE);
@@ -438,8 +452,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
   auto issue = [&](int stage) {
     char* const sb = lds_raw + stage * STAGE;
     const bool tv = ti < ntaps;
-    int4 e = *reinterpret_cast<const int4*>(s_tap4[tv ? ti : 0]);
-    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));
+    const igemm_i32x4_t e = igemm_tap_read(s_tap4[tv ? ti : 0]);
     const int da = e.z + c8 * 8, dw = e.w + c8 * 8;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -483,7 +496,9 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
   int c_ks = 0, c_tile = 0;
   for (int gs = 0; gs < G; ++gs) {
     // at most the pieces of the younger steps (and, right after a tile end, that tile's stores - younger still) outstanding
-    if (D >= 2 && gs + 1 < G) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * NI) : "memory");
+    static_assert(D <= 3, "the wait ladder below covers up to three stages in flight");
+    if (D >= 3 && gs + 2 < G) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NI) : "memory");
+    else if (D >= 2 && gs + 1 < G) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (gs + D < G) issue((gs + D) % NSTAGE);
     if (c_ks == 0) {

@@ -147,6 +147,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // map of a DMA wave-instruction keeps one source channel offset per lane.
 typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
 #define WGRAD_OOB 0x80000000u
+// One LDS-DMA piece (buffer_load_dwordx4 ... lds: 16 B per lane, 1 KB per wave) issued by inline assembly.  Issued through the
+// builtin, the compiler knows that LDS is being written behind its back and - unable to tell the stage being filled from the
+// stage being read - puts `s_waitcnt vmcnt(0)` in front of the first transposed fragment read (a builtin with an LDS memory
+// operand) that follows: every K step then waited for the piece it had just issued, DMA and MFMAs strictly in sequence.  The
+// kernel orders the ring itself (vmcnt(pieces of the younger steps) + barrier at the top of a step), so the compiler must not
+// see the DMA at all.  No other vector memory LOAD may be added to the loop of a kernel that uses this: the compiler's own vmcnt
+// bookkeeping does not count these pieces.
+typedef int wg_i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wg_i32x4_t wg_rsrc(const void* base) {   // stride 0, no range limit, raw dword addressing: as make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000)
+  const uint64_t a = (uint64_t)base;
+  return (wg_i32x4_t){(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+}
+__device__ __forceinline__ void wg_dma16(const wg_i32x4_t rsrc, char* lds_dst, uint32_t voff) {
+  const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rsrc) : "memory");
+}
 
 template <int TM, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, const float rcp_hw, const float rcp_w) {
@@ -176,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
   const int ady = p.ady[t], adx = p.adx[t], bdy = p.bdy[t], bdx = p.bdx[t];
   const int HWg = p.Hg * p.Wg;
 
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + bz1 * p.as1 + bz2 * p.as2), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + bz1 * p.bs1 + bz2 * p.bs2), 0, 0x7fffffff, 0x00020000);
+  const wg_i32x4_t ra = wg_rsrc(p.a + bz1 * p.as1 + bz2 * p.as2);
+  const wg_i32x4_t rb = wg_rsrc(p.b + bz1 * p.bs1 + bz2 * p.bs2);
 
   // ---- this lane's DMA pieces: row lrow of instruction wv + 4*it, one fixed 16-byte channel slot
   const int lrow = TM == 1 ? (lane >> 3) : (lane >> 4);
@@ -214,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
       const bool okb = pv & in_b & b_cok;
       const uint32_t offa = (uint32_t)(((b * p.Ha + ay) * p.Wa + ax) * p.lda + a_c) * 2u;
       const uint32_t offb = (uint32_t)(((b * p.Hb + by) * p.Wb + bx) * p.ldb + b_c) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (wg_lds_ptr_t)(sa + j * 1024), 16, oka ? offa : WGRAD_OOB, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (wg_lds_ptr_t)(sb + j * 1024), 16, okb ? offb : WGRAD_OOB, 0, 0, 0);
+      wg_dma16(ra, sa + j * 1024, oka ? offa : WGRAD_OOB);
+      wg_dma16(rb, sb + j * 1024, okb ? offb : WGRAD_OOB);
     }
     kpos += 64;
   };
@@ -247,7 +263,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
   for (int s = 0; s < D; ++s)
     if (s < nks) issue(s);
   for (int ks = 0; ks < nks; ++ks) {
-    if (D >= 2 && ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * NI) : "memory");
+    // stage ks has landed once only the pieces of the younger ISSUED stages are outstanding: min(D-1, nks-1-ks) of them
+    static_assert(D <= 3, "the wait ladder below covers up to three stages in flight");
+    if (D >= 3 && ks + 2 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NI) : "memory");
+    else if (D >= 2 && ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ks + D < nks) issue((ks + D) % NSTAGE);
     const char* const LA = lds_raw + (ks % NSTAGE) * STAGE;
