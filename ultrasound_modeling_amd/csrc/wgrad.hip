@@ -203,6 +203,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
   const bool a_cok = (m0 + ch) < p.Ma, b_cok = (n0 + ch) < p.Nb;
   const int a_c = m0 + ch, b_c = n0 + ch;
 
+  // (uniform) both operands are read at the grid pixel itself: the per-piece pixel decode (two reciprocal divisions with their
+  // corrections, four range checks, two address polynomials: ~40 VALU instructions per piece, 4 pieces per wave and step at the
+  // 128-channel tile - more issue time than the step's 32 MFMAs) collapses to one multiply-add per operand
+  const bool linear = p.asy == 1 && p.asx == 1 && p.bsy == 1 && p.bsx == 1 && ady == 0 && adx == 0 && bdy == 0 && bdx == 0 &&
+                      p.Ha == p.Hg && p.Wa == p.Wg && p.Hb == p.Hg && p.Wb == p.Wg;
   int kpos = 0;   // pixel offset (within the split) of the step being issued
   auto issue = [&](int stage) {
     char* const sa = lds_raw + stage * STAGE;
@@ -213,6 +218,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
       const int64_t m = k_begin + kpos + RPI * j + lrow;
       const bool pv = m < k_end;
       const int mm = pv ? (int)m : 0;
+      if (linear) {   // dense layers / 1x1 at stride 1: grid pixel == operand pixel for both operands, nothing out of range
+        wg_dma16(ra, sa + j * 1024, (pv & a_cok) ? (uint32_t)(mm * p.lda + a_c) * 2u : WGRAD_OOB);
+        wg_dma16(rb, sb + j * 1024, (pv & b_cok) ? (uint32_t)(mm * p.ldb + b_c) * 2u : WGRAD_OOB);
+        continue;
+      }
       // (image, row, column) of grid pixel mm: float-reciprocal quotients corrected by one step either way (mm < 2^24)
       int b = (int)((float)mm * rcp_hw);
       int rem = mm - b * HWg;
