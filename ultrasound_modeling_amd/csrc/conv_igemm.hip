@@ -290,12 +290,21 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   int c8 = q - ti * p.cpt;
   const int adv_t = 8 / p.cpt, adv_c = 8 - adv_t * p.cpt;
   __syncthreads();  // tap table visible
+  // dense layers / 1x1 convs: ONE tap at the pixel itself - its table entry stays in registers (no LDS round trip in front of
+  // every step's pieces) and no piece can fall outside the image
+  const igemm_i32x4_t e0 = igemm_tap_read(s_tap4[tbase]);
+  const bool dense = __builtin_amdgcn_readfirstlane((ntaps == 1) & (e0.x == 0) & (e0.y == 0)) != 0;
 
   auto issue = [&](int stage) {
     char* const sb = lds_raw + stage * STAGE;
     const bool tv = ti < ntaps;
-    const igemm_i32x4_t e = igemm_tap_read(s_tap4[tbase + (tv ? ti : 0)]);
+    const igemm_i32x4_t e = dense ? e0 : igemm_tap_read(s_tap4[tbase + (tv ? ti : 0)]);
     const int da = e.z + c8 * 8, dw = e.w + c8 * 8;
+    if (dense) {     // one unshifted tap: no table read, no range checks
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (igemm_lds_ptr_t)(sb + (wv + 4 * it) * 1024), 16, (tv & pv[it]) ? (uint32_t)(abase[it] + da) * 2u : IGEMM_OOB, 0, 0, 0);
+    } else
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int iy = py[it] + e.x, ix = px[it] + e.y;
@@ -448,12 +457,19 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
   };
   decode_rows(0);
   __syncthreads();  // tap table visible
+  const igemm_i32x4_t e0 = igemm_tap_read(s_tap4[0]);      // (see igemm_dma_kernel)
+  const bool dense = __builtin_amdgcn_readfirstlane((ntaps == 1) & (e0.x == 0) & (e0.y == 0)) != 0;
 
   auto issue = [&](int stage) {
     char* const sb = lds_raw + stage * STAGE;
     const bool tv = ti < ntaps;
-    const igemm_i32x4_t e = igemm_tap_read(s_tap4[tv ? ti : 0]);
+    const igemm_i32x4_t e = dense ? e0 : igemm_tap_read(s_tap4[tv ? ti : 0]);
     const int da = e.z + c8 * 8, dw = e.w + c8 * 8;
+    if (dense) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (igemm_lds_ptr_t)(sb + (wv + 4 * it) * 1024), 16, (tv & pv[it]) ? (uint32_t)(abase[it] + da) * 2u : IGEMM_OOB, 0, 0, 0);
+    } else
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int iy = py[it] + e.x, ix = px[it] + e.y;
