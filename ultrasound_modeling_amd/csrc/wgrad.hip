@@ -224,22 +224,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
         continue;
       }
       // (image, row, column) of grid pixel mm: float-reciprocal quotients corrected by one step either way (mm < 2^24)
+      // 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24: full rate; v_mul_lo_u32 issues at a quarter of it and there were twelve
+      // per piece - more issue time than the step's MFMAs): every factor here is a pixel index or a count below 2^23 (the launcher
+      // checks the pixel counts), the last products are taken modulo 2^32 like the 32-bit form
       int b = (int)((float)mm * rcp_hw);
-      int rem = mm - b * HWg;
+      int rem = mm - __mul24(b, HWg);
       if (rem < 0) { --b; rem += HWg; }
       if (rem >= HWg) { ++b; rem -= HWg; }
       int gy = (int)((float)rem * rcp_w);
-      int gx = rem - gy * p.Wg;
+      int gx = rem - __mul24(gy, p.Wg);
       if (gx < 0) { --gy; gx += p.Wg; }
       if (gx >= p.Wg) { ++gy; gx -= p.Wg; }
-      const int ay = gy * p.asy + ady, ax = gx * p.asx + adx;
-      const int by = gy * p.bsy + bdy, bx = gx * p.bsx + bdx;
+      const int ay = __mul24(gy, p.asy) + ady, ax = __mul24(gx, p.asx) + adx;
+      const int by = __mul24(gy, p.bsy) + bdy, bx = __mul24(gx, p.bsx) + bdx;
       const bool in_a = ((unsigned)ay < (unsigned)p.Ha) & ((unsigned)ax < (unsigned)p.Wa);
       const bool in_b = ((unsigned)by < (unsigned)p.Hb) & ((unsigned)bx < (unsigned)p.Wb);
       const bool oka = pv & in_a & in_b & a_cok;   // a product with a zero operand contributes nothing: one zero suffices
       const bool okb = pv & in_b & b_cok;
-      const uint32_t offa = (uint32_t)(((b * p.Ha + ay) * p.Wa + ax) * p.lda + a_c) * 2u;
-      const uint32_t offb = (uint32_t)(((b * p.Hb + by) * p.Wb + bx) * p.ldb + b_c) * 2u;
+      const uint32_t offa = (__umul24((uint32_t)(__mul24(__mul24(b, p.Ha) + ay, p.Wa) + ax), (uint32_t)p.lda) + (uint32_t)a_c) * 2u;
+      const uint32_t offb = (__umul24((uint32_t)(__mul24(__mul24(b, p.Hb) + by, p.Wb) + bx), (uint32_t)p.ldb) + (uint32_t)b_c) * 2u;
       wg_dma16(ra, sa + j * 1024, oka ? offa : WGRAD_OOB);
       wg_dma16(rb, sb + j * 1024, okb ? offb : WGRAD_OOB);
     }
@@ -339,7 +342,8 @@ static void wgrad_dma_launch_t(const WgradParams& p, dim3 grid, hipStream_t s) {
 static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats, hipStream_t s) {
   // LDS-DMA variant: unbatched launches whose operands fit 32-bit byte offsets and whose pixel count fits the float division
   static const int dma_env = getenv("USSEG_WGRAD_DMA") ? atoi(getenv("USSEG_WGRAD_DMA")) : 1;
-  const bool dma = dma_env && p.nb2 <= 0 && p.M < (1 << 24) && (int64_t)p.B * p.Ha * p.Wa * p.lda * 2 < 0x7fff0000ll &&
+  const bool dma = dma_env && p.nb2 <= 0 && p.M < (1 << 24) && (int64_t)p.Hg * p.Wg < (1 << 23) && (int64_t)p.B * p.Ha * p.Wa < (1 << 24) && (int64_t)p.B * p.Hb * p.Wb < (1 << 24) &&   // (24-bit multiplies in the pixel decode)
+                   (int64_t)p.B * p.Ha * p.Wa * p.lda * 2 < 0x7fff0000ll &&
                    (int64_t)p.B * p.Hb * p.Wb * p.ldb * 2 < 0x7fff0000ll && p.lda % 8 == 0 && p.ldb % 8 == 0;
   // 128x128 tiles when both channel counts exceed one 64-wide tile (split-K supplies the workgroups if the tiles are few)
   static const int tm_env = getenv("USSEG_WGRAD_TM") ? atoi(getenv("USSEG_WGRAD_TM")) : 0;
@@ -539,7 +543,7 @@ extern "C" int usseg_gemm_tn_batched(const UssegGemmDesc* d, const void* a, cons
   p.ntaps = 1;
   const int slot = usseg_prof_start(2, (hipStream_t)stream);
   static const int dma_env = getenv("USSEG_WGRAD_DMA") ? atoi(getenv("USSEG_WGRAD_DMA")) : 1;
-  const bool dma = dma_env && d->K < (1 << 24) && (int64_t)d->K * d->ldx * 2 < 0x7fff0000ll && (int64_t)d->K * d->ldw * 2 < 0x7fff0000ll &&
+  const bool dma = dma_env && d->K < (1 << 23) && (int64_t)d->K * d->ldx * 2 < 0x7fff0000ll && (int64_t)d->K * d->ldw * 2 < 0x7fff0000ll &&
                    (d->xs1 | d->xs2 | d->ws1 | d->ws2) % 8 == 0;
   const dim3 grid(1, (unsigned)(p.mtiles * p.ntiles), (unsigned)(d->nb1 * d->nb2));
   if (dma) wgrad_dma_launch_t<1, 3>(p, grid, (hipStream_t)stream);
