@@ -54,7 +54,12 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
   constexpr int X_IT = (MAXHP * XCH + NTHR - 1) / NTHR, Y_IT = (128 * YCH + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) bf16_t lds_x[MAXHP * XS];
   __shared__ __attribute__((aligned(16))) bf16_t lds_y[128 * YS];
-  __shared__ __attribute__((aligned(16))) int s_patch[8][8];  // per patch: x origin, dy origin, ly0 - 1, lx0 - 1, valid
+  // per (pixel group of the current batch, patch): x origin, dy origin, ly0 - 1, lx0 - 1, valid.  One thread per entry fills the
+  // table for TB groups at a time: computed per group by the first NV lanes of wave 0 (130 VALU instructions, 30 of them
+  // quarter-rate integer multiplies of four divisions, every group, with the other waves waiting at the barrier) it cost that
+  // wave more issue time than the group's MFMAs
+  constexpr int TB = NTHR / 8;
+  __shared__ __attribute__((aligned(16))) int s_tab[TB][8][8];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, tg = tid >> 8;   // tile wave, tap group
   const int t0 = tg * TPG;
@@ -139,10 +144,13 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
   int g_end = g_begin + p.groups_per_block;
   if (g_end > p.ngroups) g_end = p.ngroups;
 
-  auto patch_fill = [&](int grp, int (*tab)[8]) {
-    if (tid < p.NV) {
-      int gp = grp * p.NV + tid;
-      int valid = gp < p.npatches;
+  auto fill_batch = [&](int grp0) {     // entries of groups grp0 .. grp0 + TB - 1 (past g_end: marked invalid, never read)
+    const int gi = tid >> 3, pi = tid & 7;
+    int (*tab)[8] = s_tab[gi];
+    if (pi < p.NV) {
+      const int tid = pi;               // (the body below is the per-patch code: "tid" is the patch slot)
+      int gp = (grp0 + gi) * p.NV + pi;
+      int valid = gp < p.npatches && (grp0 + gi) < g_end;
       int gpc = valid ? gp : 0;
       int v = gpc / p.tiles_per_v, tt = gpc - v * p.tiles_per_v;
       int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
@@ -246,10 +254,11 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
 
   if (!PF) {
     for (int grp = g_begin; grp < g_end; ++grp) {
-      patch_fill(grp, s_patch);
+      const int rel = grp - g_begin;
+      if ((rel & (TB - 1)) == 0) fill_batch(grp);
       __syncthreads();  // patch table ready; also: previous iteration's LDS reads are done
       uint4 rx[X_IT], ry[Y_IT];
-      load_xy(s_patch, rx, ry);
+      load_xy(s_tab[rel & (TB - 1)], rx, ry);
 #pragma unroll
       for (int it = 0; it < X_IT; ++it)
         if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = rx[it];
@@ -260,16 +269,15 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       compute();
     }
   } else {
-    __shared__ __attribute__((aligned(16))) int s_patch2[8][8];
     uint4 rx[X_IT], ry[Y_IT];
     if (g_begin < g_end) {
-      patch_fill(g_begin, s_patch);
+      fill_batch(g_begin);
       __syncthreads();
-      load_xy(s_patch, rx, ry);
+      load_xy(s_tab[0], rx, ry);
     }
-    int par = 0;
-    for (int grp = g_begin; grp < g_end; ++grp, par ^= 1) {
-      int (*nxt)[8] = par ? s_patch : s_patch2;
+    for (int grp = g_begin; grp < g_end; ++grp) {
+      const int rel1 = grp + 1 - g_begin;                 // the next group's slot; a new batch overwrites entries whose last
+      int (*nxt)[8] = s_tab[rel1 & (TB - 1)];             // readers finished before the barrier that ended the previous group
 #pragma unroll
       for (int it = 0; it < X_IT; ++it)
         if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = rx[it];
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       for (int it = 0; it < Y_IT; ++it)
         if (tid + NTHR * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = ry[it];
       const bool more = grp + 1 < g_end;
-      if (more) patch_fill(grp + 1, nxt);
+      if (more && (rel1 & (TB - 1)) == 0) fill_batch(grp + 1);
       __syncthreads();      // this group's tile and the next group's patch table are visible
       if (more) {
         load_xy(nxt, rx, ry);
