@@ -408,6 +408,10 @@ int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, cons
  * loss_kind 1 = ResNest.my_loss_cat(y_true, y_pred) (TBI_ResNest.py:234-248: loss map [HW] -= y*log(p+1e-7)*scale[hw][c]).
  * probs, y_true fp32 [M][C]; only M, HW, C, loss_kind, label_smoothing, clip_eps, inv_global_batch of the descriptor are read.
  * loss is overwritten (loss_kind 0: a USSEG_ACC_FLOATS accumulator, [0] = the scalar). */
+/* Accuracy metric of a step (TBI_ResNest.py:48-51; VisionTransformer.py:256-262): acc[0] = fraction of the M pixels whose
+ * argmax(probs) equals argmax(y_true) (first maximum, as tf.argmax); probs, y_true fp32 [M][C].  acc is a USSEG_ACC_FLOATS
+ * accumulator (zeroed once by the caller), [0] OVERWRITTEN.  One pass instead of the reference's four framework reductions. */
+int usseg_accuracy(const float* probs, const float* y_true, int64_t M, int32_t C, float* acc, usseg_stream_t stream);
 int usseg_loss_from_probs(const UssegLossDesc* d, const float* probs, const float* y_true, const float* scale, float* loss,
                           usseg_stream_t stream);
 /* The <= 4-class head Conv2DTranspose(k x k, stride 2, 'same') (Decoder.py:120 k=3; TBI_ResNest.py:124 k=4) in "quad" form: a

@@ -600,8 +600,9 @@ class ResNest(TrainStepDriver):
             probs = self._graph_replay(x, y)
         else:
             probs = self._train_body(x, y)                                                     # :43-46 (no clipping: clip_norm None)
-        pred = probs.argmax(dim=-1)                                                            # :48-51 (metric only)
-        accuracy = (pred == y.argmax(dim=-1)).float().mean()
+        if getattr(self, "_acc", None) is None or self._acc.device != probs.device:
+            self._acc = torch.zeros(ops.ACC_FLOATS, dtype=torch.float32, device=probs.device)
+        accuracy = ops.accuracy(probs, y, self._acc).clone()                                   # :48-51 (metric only): one pass, one count
         return self._loss_map.clone().reshape(self.height, self.width), accuracy, probs
 
     def modules(self):

@@ -140,6 +140,7 @@ _PROTOS = {
     "usseg_splitattn_ws_floats": (c_i64, [P(SplitAttnDesc)]),
     "usseg_splitattn_mlp_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_i32, P(SplitAttnParams), c_vp, c_vp, c_vp]),
     "usseg_norm_act_fwd_gap": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_accuracy": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "usseg_norm_act_bwd_res": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_norm_act_bwd_sa": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_splitattn_apply_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp, c_vp]),

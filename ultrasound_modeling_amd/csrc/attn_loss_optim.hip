@@ -719,6 +719,39 @@ extern "C" int usseg_loss_from_probs(const UssegLossDesc* d, const float* probs,
   return usseg_check_launch("loss_from_probs");
 }
 
+// Accuracy metric of a step (TBI_ResNest.py:48-51: mean over the pixels of argmax(probs) == argmax(y_true); tf.argmax takes the
+// FIRST maximum): one pass, one count - the reference's four reductions (two argmax, a comparison, a mean) were four framework
+// launches over intermediate tensors.  acc[0] = matching pixels / M (fixed-order block sums: reproducible); acc needs
+// USSEG_ACC_FLOATS floats (grid_ordered_sum slots).
+__global__ __launch_bounds__(256) void accuracy_kernel(const float* probs, const float* y, int64_t M, int C, float inv_m, float* acc) {
+  __shared__ float red[4];
+  float cnt = 0.f;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    const float* p = probs + m * C;
+    const float* t = y + m * C;
+    int ip = 0, it = 0;
+    float bp = p[0], bt = t[0];
+    for (int c = 1; c < C; ++c) {
+      const float vp = p[c], vt = t[c];
+      if (vp > bp) { bp = vp; ip = c; }
+      if (vt > bt) { bt = vt; it = c; }
+    }
+    cnt += ip == it ? 1.f : 0.f;
+  }
+  for (int msk = 32; msk >= 1; msk >>= 1) cnt += __shfl_xor(cnt, msk, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  grid_ordered_sum(((red[0] + red[1]) + (red[2] + red[3])) * inv_m, acc, gridDim.x);
+}
+extern "C" int usseg_accuracy(const float* probs, const float* y_true, int64_t M, int32_t C, float* acc, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(probs && y_true && acc && C >= 1 && C <= 64, "accuracy: bad arguments");
+  if (M <= 0) return USSEG_OK;
+  int64_t g = cdiv64(M, 256 * 4);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(accuracy_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, probs, y_true, M, (int)C, 1.f / (float)M, acc);
+  return usseg_check_launch("accuracy");
+}
+
 __global__ __launch_bounds__(256) void loss_cat_scale_kernel(const float* y, int B, int HW, int C, float* scale) {
   int64_t total = (int64_t)HW * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {

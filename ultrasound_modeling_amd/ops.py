@@ -529,6 +529,14 @@ def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, ep
     return dx
 
 
+def accuracy(probs, y_true, acc):
+    """acc[0] = mean over the pixels of argmax(probs) == argmax(y_true) (TBI_ResNest.py:48-51); ``acc``: fp32 [ACC_FLOATS], zeroed once."""
+    assert acc.numel() >= ACC_FLOATS and probs.is_contiguous() and y_true.is_contiguous() and probs.dtype == y_true.dtype == torch.float32
+    C_ = probs.shape[-1]
+    L.check(L.load().usseg_accuracy(probs.data_ptr(), y_true.data_ptr(), probs.numel() // C_, C_, acc.data_ptr(), _stream()), "accuracy")
+    return acc[0]
+
+
 def norm_act_bwd_res(x, dy, C_logical, gamma, beta, dres, dx, dgamma, dbeta, eps, dbias=None):
     """Plain LayerNormalization backward + the residual branch of a pre-norm block: dx = bf16(bf16(LN'(dy)) + dres) in one pass;
     ``dbias`` += the column sums of the stored dx."""
