@@ -20,15 +20,23 @@ dy = torch.randn(B, H, W, layer.cout_p).to(torch.bfloat16).cuda()
 
 
 def t(fn):
+    """GPU time per call: ``reps`` calls captured into one HIP graph (no host launch gaps), replayed three times."""
     for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3
 
 
 fl = 2.0 * B * H * W * Cin * Cout * 9
