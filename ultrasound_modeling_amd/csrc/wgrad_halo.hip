@@ -166,20 +166,30 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       tab[tid][4] = valid;
     }
   };
+  const bool nv1 = p.NV == 1;
   // two passes so that the table reads of every item are in flight together, then the global loads back to back
   auto load_xy = [&](int (*tab)[8], uint4 (&rx)[X_IT], uint4 (&ry)[Y_IT]) {
     int4 ex[X_IT];
     int yorg[Y_IT], yval[Y_IT];
+    if (nv1) {      // one patch per group (every image at least 16 pixels wide and 8 high): one entry for all items
+      const int4 e = *reinterpret_cast<const int4*>(tab[0]);
+      const int v = tab[0][4];
 #pragma unroll
-    for (int it = 0; it < X_IT; ++it) {
-      const int geo = x_geo[it] < 0 ? 0 : x_geo[it];
-      ex[it] = *reinterpret_cast<const int4*>(tab[geo >> 16]);
-    }
+      for (int it = 0; it < X_IT; ++it) ex[it] = e;
 #pragma unroll
-    for (int it = 0; it < Y_IT; ++it) {
-      const int* pt = tab[y_geo[it] >> 16];
-      yorg[it] = pt[1];
-      yval[it] = pt[4];
+      for (int it = 0; it < Y_IT; ++it) { yorg[it] = e.y; yval[it] = v; }
+    } else {
+#pragma unroll
+      for (int it = 0; it < X_IT; ++it) {
+        const int geo = x_geo[it] < 0 ? 0 : x_geo[it];
+        ex[it] = *reinterpret_cast<const int4*>(tab[geo >> 16]);
+      }
+#pragma unroll
+      for (int it = 0; it < Y_IT; ++it) {
+        const int* pt = tab[y_geo[it] >> 16];
+        yorg[it] = pt[1];
+        yval[it] = pt[4];
+      }
     }
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) asm volatile("" : "+v"(ex[it].x), "+v"(ex[it].z), "+v"(ex[it].w));   // pin the reads above the loads
