@@ -10,7 +10,12 @@ repack) on a synthetic batch of 256x256x1 tiles that is already resident in HBM.
   --scaling weak (default)  the per-GPU batch is fixed, the global batch (which divides Arch B's loss) is batch*N;
   --scaling strong          the GLOBAL batch is fixed at 16 (B) / 32 (A) and split over the N replicas (MainParallel.py:127-128).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N>1 under torch.distributed.run (RANK / WORLD_SIZE in the environment): this process is one rank.
+      N>1 WITHOUT that environment: this process only launches `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+      as a child (before anything touches the GPU - no exec of a GPU process), relays its output and exits with its code.
+  --dry-run   plumbing rehearsal without a GPU: a 6-parameter per-pixel stand-in model on the CPU driven through the SAME
+              step.TrainStepDriver / MainParallel.MirroredTrainer code over gloo; its `value` measures nothing ("dry_run": true).
 
 Prints ONE JSON line on rank 0 (see the keys below).  Extra objects:
   roofline     - the dominant kernel family (the conv kernels that run every conv / tconv forward and
@@ -235,6 +240,87 @@ def cpu_baseline(arch, seconds_budget: float = 25.0):
                       f"{torch.get_num_threads()} threads; TensorFlow (the reference) is not installable here"}
 
 
+def launch_ranks(n: int) -> int:
+    """`bench.py --gpus N` started by hand (no torchrun environment): start the N ranks as a child torch.distributed.run and
+    relay its stdout / stderr / exit code.  Called before any torch.cuda / library call, so no GPU process is ever exec'd."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def make_dry_net(global_batch, dev):
+    """--dry-run: a per-pixel 1->3 affine + softmax + the Arch B loss on the CPU behind the product's step driver.  It exists to
+    rehearse bench.py's rank launch, batch split, exchange, timing and JSON line where there is no GPU (tests/test_cpu_host.py)."""
+    from ultrasound_modeling_amd.step import TrainStepDriver
+
+    class _Flat:
+        def __init__(self):
+            self.flat = torch.tensor([0.3, -0.2, 0.1, 0.0, 0.1, -0.1], device=dev)
+            self.grad = torch.zeros(6, device=dev)
+            self.total = self.n_trainable = 6
+
+    class _Adam:
+        def __init__(self, flat):
+            self.flat, self.m, self.v, self.t = flat, torch.zeros(6), torch.zeros(6), 0
+
+        def _scale(self):
+            return 1.0 / max(float(self.flat.grad.norm()), 1.0)
+
+        def clip_local(self):
+            self.flat.grad.mul_(self._scale())
+
+        def advance(self):
+            self.t += 1
+
+        def apply_range(self, lo, hi, clip=0.0):
+            g = self.flat.grad[lo:hi] * (self._scale() if clip > 0 else 1.0)
+            self.m[lo:hi].mul_(0.9).add_(g, alpha=0.1)
+            self.v[lo:hi].mul_(0.999).addcmul_(g, g, value=0.001)
+            lr_t = 1e-3 * (1 - 0.999 ** self.t) ** 0.5 / (1 - 0.9 ** self.t)
+            self.flat.flat[lo:hi].sub_(lr_t * self.m[lo:hi] / (self.v[lo:hi].sqrt() + 1e-7))
+
+        def apply(self, already_clipped=False):
+            self.advance()
+            self.apply_range(0, 6, 0.0 if already_clipped else 1.0)
+
+    class DryNet(TrainStepDriver):
+        def __init__(self):
+            self.flat = _Flat()
+            self.optimizer = _Adam(self.flat)
+            self._buffers = {}
+
+        def modules(self):
+            return [self]
+
+        def _zero_grad(self):
+            self.flat.grad.zero_()
+
+        def _forward_backward(self, x, y):
+            p = self.flat.flat.clone().requires_grad_(True)
+            probs = torch.softmax(x * p[:3] + p[3:], dim=-1)
+            ys = 0.9 * y + 0.1 / 3
+            self.loss = -(ys * probs.clamp(1e-7, 1 - 1e-7).log()).sum() / global_batch
+            self.flat.grad.add_(torch.autograd.grad(self.loss, p)[0])
+            return probs.detach()
+
+        def _repack(self):
+            pass
+
+        def train_step(self, x, y):
+            probs = self._train_body(x, y)
+            return self.loss.detach(), probs
+    return DryNet()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,13 +334,24 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path (RCCL all-reduce around the update) even at N=1")
     ap.add_argument("--dp-chunks", type=int, default=0, help="pieces the gradient exchange is pipelined in (0 = automatic)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra eager steps with per-launch HIP events (roofline leg)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the launch + exchange + reporting plumbing with a stand-in model")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # started by hand: become the launcher (nothing has touched the GPU yet)
+        sys.exit(launch_ranks(args.gpus))
+
     from ultrasound_modeling_amd.MainParallel import MirroredTrainer, init_distributed
-    rank, world, local = init_distributed()
+    dry = args.dry_run
+    rank, world, local = init_distributed("gloo" if dry else None)
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if os.environ.get("USSEG_BENCH_FAIL_RANK") == str(rank):       # test hook: a rank that dies must fail the whole launch
+        raise SystemExit(3)
+    if dry:
+        dev = torch.device("cpu")
+        args.no_graph, args.profile_steps, args.no_cpu_baseline = True, 0, True
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     arch = args.arch
     base = BASE_BATCH[arch]
     global H, W
@@ -269,7 +366,9 @@ def main():
     global_batch = per_gpu * world
 
     from ultrasound_modeling_amd import _lib
-    if arch == "B":
+    if dry:
+        net = make_dry_net(global_batch, dev)
+    elif arch == "B":
         from ultrasound_modeling_amd.VisionTransformer import VisionTransformer
         net = VisionTransformer(batch_size=global_batch, img_size=(H, W), in_channels=C_IN, device=str(dev), seed=0)
     elif arch == "T":
@@ -299,6 +398,8 @@ def main():
     if arch == "S":      # the reference defines no loss for SwinTransformer.py: the step is driven by a fixed upstream gradient of the pooled output
         y = torch.full((per_gpu, 768), 1.0 / (768 * global_batch), device=dev)
     use_graph = not args.no_graph                    # N > 1: the step up to the per-replica clip is one graph, then the RCCL exchange, then the update
+    if dry:
+        x, y = x[..., :1].float(), y.float()
     log(f"rank {rank}/{world}: Arch {arch} built ({net.flat.n_trainable} params), {per_gpu} images per GPU, warming up (graph={use_graph})")
     for _ in range(max(args.warmup, 1) if not use_graph else 1):
         trainer.train_step(x, y)
@@ -308,10 +409,12 @@ def main():
             trainer.train_step(x, y)
 
     def sync():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
 
     sync()
     t0 = time.perf_counter()
@@ -376,11 +479,14 @@ def main():
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"{names[arch]}, {H}x{W}x1, {per_gpu} images per GPU, bf16 MFMA / fp32 accumulate, fp32 master weights + Adam",
+               "config": {"workload": f"{names[arch]}, {H}x{W}x1, {per_gpu} images per GPU, bf16 MFMA / fp32 accumulate"
+                                      f"{' (BASELINE names fp16 for this config; the reference itself is fp32)' if arch == 'S' else ''}, fp32 master weights + Adam",
                           "arch": arch, "per_gpu_batch": per_gpu, "global_batch": global_batch, "parallelism": f"dp{world}",
                           "hip_graph": bool(use_graph), "dp_exchange_chunks": getattr(net.grad_sync, "nchunks", 0) if net.grad_sync is not None else 0,
                           "final_loss": round(loss_val, 4)},
                "roofline": roofline}
+        if dry:
+            out.update({"dry_run": True, "data": "synthetic (dry run: CPU stand-in model over gloo, the value measures nothing)", "dtype": "f32"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arch)
         print(json.dumps(out), flush=True)

@@ -181,6 +181,11 @@ def _make_cpu_net():
         def train_step(self, x, y):
             probs = self._train_body(x, y)
             return self.loss.detach().float(), probs
+
+        def step(self, x, y):
+            probs = O.vision_transformer_forward(x, dict(self.P, **dict(zip(self.names, [t.double() for t in self._views(self.flat.flat)]))), 3, 3,
+                                                 as_executed=False)
+            return O.compute_loss(y, probs, self.global_batch).float(), probs
     return _CpuNet
 
 
@@ -203,6 +208,11 @@ def _dp_worker(rank, world, port, tmp, chunks):
     assert calls[0] == "clip_local" and calls[1] == "advance" and all(c[0] == "adam" for c in calls[2:]), calls
     assert [c[1] for c in calls[2:]] == sorted(c[1] for c in calls[2:]) and calls[2][1] == 0 and calls[-1][2] == net.flat.total
     assert len(calls) - 2 == (chunks if chunks > 1 else 1) and net.repacks == 1
+    # mirrored_test_step (MainParallel.py:148-176): loss SUM-reduced, probabilities AND labels gathered along the batch axis
+    tl, tp, ty = tr.test_step(xs, ys)
+    assert tp.shape[0] == 4 and torch.equal(ty, y), "labels are gathered in rank order (MainParallel.py:163)"
+    l_all, p_all = net.step(x, y)
+    assert torch.allclose(tp, p_all, atol=1e-12) and abs(tl.item() - l_all.item()) < 1e-4 * abs(l_all.item())
     torch.save({"loss": loss, "P": {n: t.clone() for n, t in zip(net.names, net._views(net.flat.flat))}}, os.path.join(tmp, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -238,3 +248,26 @@ def test_mirrored_step_world2_gloo(tmp_path, chunks):
     assert abs(r0["loss"].item() - sum(losses)) < 1e-4 * abs(sum(losses))    # scalar SUM-reduce (MainParallel.py:131)
     for n, t in zip(names, new):
         assert torch.allclose(r0["P"][n].double(), t, rtol=1e-6, atol=2e-6), n   # first Adam step ~ lr*sign(g): entries with |g| near fp32 noise may differ
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` started by hand (no torchrun environment) must start its two ranks itself, as CHILD processes, and
+    relay rank 0's single JSON line (the driver's N>1 scaling runs use torch.distributed.run; a maintainer types the short form).
+    --dry-run swaps the model for a CPU stand-in over gloo: launch, batch split, exchange, max-over-ranks timing and reporting are
+    the shipped code."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True
+    assert d["config"]["per_gpu_batch"] == 16 and d["config"]["global_batch"] == 32 and d["config"]["dp_exchange_chunks"] == 1
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    # a failing rank makes the launcher exit non-zero
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--dry-run", "--scaling", "strong",
+                        "--arch", "T"], capture_output=True, text=True, timeout=600, env=dict(env, USSEG_BENCH_FAIL_RANK="1"))
+    assert r.returncode != 0

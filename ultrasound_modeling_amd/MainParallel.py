@@ -105,12 +105,17 @@ class MirroredTrainer:
         return loss, probs
 
     def test_step(self, x_local, y_local):
-        """mirrored_test_step (MainParallel.py:148-176): SUM-reduced loss, gathered probabilities and labels."""
+        """mirrored_test_step (MainParallel.py:148-176): SUM-reduced loss (:159), the probabilities of all replicas gathered along
+        the batch axis (:160) and the labels likewise (:163) -> (loss, probs [B_global,...], y [B_global,...])."""
         loss, probs = getattr(self.net, "eval_step", self.net.step)(x_local, y_local)
+        y = y_local
         if self.world > 1:
             loss = loss.clone()
             dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
-            plist = [torch.empty_like(probs) for _ in range(self.world)]
-            dist.all_gather(plist, probs.contiguous(), group=self.group)
-            probs = torch.cat(plist, dim=0)
-        return loss, probs
+            probs, y = self._gather(probs), self._gather(y_local.to(probs.device))
+        return loss, probs, y
+
+    def _gather(self, t):
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.cat(parts, dim=0)
