@@ -528,11 +528,13 @@ def train_step(x: Tensor, y: Tensor, P: Params, opt_state: dict, global_batch_si
 # ----------------------------------------------------------------------------
 def archA_split_attention(inputs: Sequence[Tensor], P: Params, prefix: str) -> Tensor:
     """TBI_ResNest.py:175-207: dense1+BN+ELU, one dense2 PER radix branch, softmax over channels."""
+    global STORAGE_DTYPE
     radix = len(inputs)
     holder = inputs[0]
     for t in inputs[1:]:
         holder = holder + t                                                                  # :179-184
     g = holder.mean(dim=(1, 2))[:, None, None, :]                                            # :186-187
+    saved_storage, STORAGE_DTYPE = STORAGE_DTYPE, None                                       # the product runs this tiny MLP in fp32
     a = conv2d_same(g, P[prefix + "1.kernel"], P[prefix + "1.bias"])                         # :189
     a = elu(_bn(a, P, prefix + "_bn"))                                                       # :190-191
     out = None
@@ -540,7 +542,8 @@ def archA_split_attention(inputs: Sequence[Tensor], P: Params, prefix: str) -> T
         z = conv2d_same(a, P[f"{prefix}2_r{r}.kernel"], P[f"{prefix}2_r{r}.bias"])           # :195
         z = torch.sigmoid(z) if radix == 1 else softmax_lastaxis(z)                          # :197-200
         out = inputs[r] * z if out is None else out + inputs[r] * z                          # :202-205
-    return out
+    STORAGE_DTYPE = saved_storage
+    return _q(out)
 
 
 def archA_cardinal(x: Tensor, P: Params, prefix: str, radix: int) -> Tensor:
@@ -561,7 +564,7 @@ def archA_residual_S(x: Tensor, P: Params, name: str, radix: int, kpaths: int) -
     if x.shape[-1] != c2.shape[-1]:                                                          # :142
         sc = conv2d_same(x, P[name + "_cc.kernel"], P[name + "_cc.bias"])                    # :143
         x = elu(_bn(sc, P, name + "_scbn"))                                                  # :144-145
-    return x + c2                                                                            # :148
+    return _q(x + c2)                                                                        # :148
 
 
 def archA_upsample(x: Tensor, P: Params, name: str, dropout_mask: Optional[Tensor]) -> Tensor:
@@ -574,7 +577,7 @@ def archA_upsample(x: Tensor, P: Params, name: str, dropout_mask: Optional[Tenso
     out = _bn(out, P, name + "_bn")                                                         # :213
     if dropout_mask is not None:
         out = out * dropout_mask * 2.0                                                       # :216
-    return torch.relu(out)                                                                   # :218
+    return _q(torch.relu(out))                                                               # :218
 
 
 def archA_forward(x: Tensor, P: Params, radix: int = 3, kpaths: int = 4,

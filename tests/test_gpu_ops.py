@@ -482,6 +482,58 @@ def test_split_attention_shared_branches(gen, B, H, W, P, Cg, radix):
         assert rel(got, want) < 2e-3, (got.shape,)
 
 
+@pytest.mark.parametrize("B,H,W,P,Cg,R", [(2, 6, 6, 4, 8, 3), (1, 4, 8, 2, 64, 3), (2, 4, 4, 4, 16, 3), (2, 3, 5, 3, 10, 3), (2, 8, 8, 2, 32, 2),
+                                         (1, 4, 4, 2, 6, 1)])
+def test_split_attention_distinct_branches(gen, B, H, W, P, Cg, R):
+    """Arch A form (TBI_ResNest.py:175-207): R DIFFERENT branch tensors per path, dense1 + BatchNormalization (moving statistics) + ELU,
+    one dense2 PER radix branch, softmax over channels (sigmoid if R == 1), out = sum_r y_r * z_r written into a channel slice of a
+    wider concat buffer - forward, dy and every MLP gradient."""
+    from ultrasound_modeling_amd import ops
+    Hd = Cg // 2
+    V, Co = P * R * Cg, P * Cg
+    Vp, Cop = (V + 7) // 8 * 8, (Co + 7) // 8 * 8
+    y = rnd(gen, B, H, W, V)
+    f = lambda *s, sc=1.0: (torch.randn(*s, generator=gen, dtype=torch.float64) * sc).float().double()
+    w1, b1 = f(P, Cg, Hd, sc=1 / math.sqrt(Cg)), f(P, Hd, sc=0.1)
+    ga, be = 1 + f(P, Hd, sc=0.2), f(P, Hd, sc=0.1)
+    mm, mv = f(P, Hd, sc=0.2), 0.5 + torch.rand(P, Hd, generator=gen, dtype=torch.float64).float().double()
+    w2, b2 = f(P, R, Hd, Cg, sc=1 / math.sqrt(Hd)), f(P, R, Cg, sc=0.1)
+    dout = rnd(gen, B, H, W, Co)
+
+    def ref_fn(yy, w1_, b1_, ga_, be_, w2_, b2_):
+        outs = []
+        for p in range(P):
+            Pd = {"a1.kernel": w1_[p].reshape(1, 1, Cg, Hd), "a1.bias": b1_[p], "a_bn.gamma": ga_[p], "a_bn.beta": be_[p],
+                  "a_bn.moving_mean": mm[p], "a_bn.moving_variance": mv[p]}
+            for r in range(R):
+                Pd[f"a2_r{r}.kernel"], Pd[f"a2_r{r}.bias"] = w2_[p, r].reshape(1, 1, Hd, Cg), b2_[p, r]
+            ins = [yy[..., (p * R + r) * Cg:(p * R + r + 1) * Cg] for r in range(R)]
+            outs.append(O.archA_split_attention(ins, Pd, "a"))
+        return torch.cat(outs, dim=-1)
+    leaves = [t.clone().requires_grad_(True) for t in (y, w1, b1, ga, be, w2, b2)]
+    ref = ref_fn(*leaves)
+    (ref * dout).sum().backward()
+
+    dev = lambda t: t.float().contiguous().to(DEV)
+    params = (dev(w1), dev(b1), dev(ga), dev(be), dev(mm), dev(mv), dev(w2), dev(b2))
+    yd = to_dev_padded(y)
+    cat = ops.new_act(B, H, W, Cop + 16, DEV, zero=True)          # the stage's concats_1 buffer: this slab owns channels [8, 8 + Co)
+    out = cat[..., 8:8 + Cop]
+    d = ops.splitattn_desc(B, H * W, P, R, Cg, Hd, Vp, Cop + 16, Vp, Cop, 1.0, 1, 1e-3, ops.ACT_ELU, 1.0, R == 1)
+    _, g, s, ws = ops.splitattn_fwd(d, yd, params, out)
+    assert rel(out[..., :Co], bf(ref)) < REL_BF16
+    assert cat[..., :8].abs().max().item() == 0 and cat[..., 8 + Cop:].abs().max().item() == 0
+    grads = tuple(torch.zeros_like(t) for t in (params[0], params[1], params[2], params[3], params[6], params[7]))
+    dcat = ops.new_act(B, H, W, Cop + 16, DEV, zero=True)
+    dcat[..., 8:8 + Co] = dout.to(torch.bfloat16).to(DEV)
+    dy = ops.splitattn_bwd(d, yd, dcat[..., 8:8 + Cop], params, grads, g, s, ws, torch.empty_like(yd))
+    torch.cuda.synchronize()
+    assert rel(dy[..., :V], bf(leaves[0].grad)) < 2 * REL_BF16
+    assert Vp == V or dy[..., V:].abs().max().item() == 0
+    for got, want in zip(grads, (leaves[1].grad, leaves[2].grad, leaves[3].grad, leaves[4].grad, leaves[5].grad, leaves[6].grad)):
+        assert rel(got, want) < 2e-3, (got.shape,)
+
+
 @pytest.mark.parametrize("B,H,W,P,Cg,radix", [(2, 8, 8, 3, 10, 3), (3, 16, 8, 3, 21, 3), (2, 4, 4, 3, 85, 3), (2, 32, 32, 3, 42, 3)])
 def test_split_attention_folded_into_its_norms(gen, B, H, W, P, Cg, radix):
     """The residual_S chain LayerNorm+LeakyReLU -> split attention (ResNest.py:143-147,171-199) as the model runs it: the norm
