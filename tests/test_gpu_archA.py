@@ -1,7 +1,8 @@
 """GPU parity of Arch A (TBI_ResNest.py model + my_loss_cat + step) against the fp64 oracle, same weights and inputs.
 
-Tolerances are the bf16-depth bars of test_gpu_model.py (probabilities 2e-2, loss 5e-3, gradients median 3e-2 and
-every tensor within 1.5e-1 of the oracle run with bf16 storage emulation).  The always-on tf.nn.dropout(0.5) of the
+Per-layer parity at 1e-3 is tests/test_gpu_insitu_archA.py; this file is the END-TO-END check: probabilities / loss map 2e-3,
+every gradient tensor within max(5e-2, 3x the deviation bf16 storage alone causes in the oracle for that tensor), Adam update
+exact (1e-4) on the product's own gradients.  The always-on tf.nn.dropout(0.5) of the
 first three decoder levels (TBI_ResNest.py:215-216) is made deterministic by injecting the keep masks on both sides.
 """
 import pytest
@@ -64,7 +65,7 @@ def test_forward_loss_and_gradients(arch_a):
     assert tuple(loss_map.shape) == (64, 64) and tuple(probs.shape) == (2, 64, 64, 3)
     e_p, e_l = rel(probs, probs_r), rel(loss_map, lm_r)
     print(f"probs rel {e_p:.3e}  loss-map rel {e_l:.3e}  acc {acc.item():.3f}")
-    assert e_p < 2e-2 and e_l < 2e-2
+    assert e_p < 2e-3 and e_l < 2e-3
     acc_r = (probs_r.argmax(-1) == y.argmax(-1)).double().mean().item()
     assert abs(acc.item() - acc_r) < 2e-2
     g = net.export_grads()
@@ -73,17 +74,22 @@ def test_forward_loss_and_gradients(arch_a):
     emu = sorted(rel(g_e[k], g_r[k]) for k in names)
     print(f"grad rel median {errs[len(errs) // 2]:.3e} p90 {errs[int(len(errs) * .9)]:.3e}; worst vs bf16-emulated oracle {worst_emu}; "
           f"bf16-emulated oracle vs fp64: median {emu[len(emu) // 2]:.3e} p90 {emu[int(len(emu) * .9)]:.3e}")
-    # Arch A is deeper (5 stages, 1024-channel transposed convs, ReLU + dropout decoder): bf16 storage alone moves the
-    # gradients by the amounts printed for the emulated oracle; the GPU must stay within 1.5x of that spread.
+    # End-to-end bars.  Every launch of this model is within 1e-3 of the oracle on identical inputs (tests/test_gpu_insitu_archA.py);
+    # what is left end to end is the accumulation of bf16 STORAGE roundings through 5 stages and 1024-channel transposed convs,
+    # which the oracle reproduces when it rounds at the same storage points (g_e).  Per tensor: within max(5e-2, 3x) of the deviation
+    # bf16 storage alone causes in the oracle for THAT tensor (two independent realisations of the same rounding noise; observed: median ratio 1.0, 99th percentile 3.2, worst tensor 4.5e-2 vs 1.5e-2).
     assert errs[len(errs) // 2] < max(3e-2, 1.5 * emu[len(emu) // 2]) and errs[int(len(errs) * 0.9)] < max(1e-1, 1.5 * emu[int(len(emu) * 0.9)])
-    assert worst_emu[0] < 2e-1
-    # plain Adam (no clipping), lr 5e-3: compare the update
+    bad = [(k, rel(g[k], g_r[k]), rel(g_e[k], g_r[k])) for k in names if rel(g[k], g_r[k]) > max(5e-2, 3.0 * rel(g_e[k], g_r[k]))]
+    assert not bad, bad[:5]
+    # plain Adam (no clipping, TBI_ResNest.py:46), lr 5e-3: the update the product applied == the oracle's Adam on the product's OWN
+    # gradients at fp32 accuracy.  (Against the oracle's gradients the first Adam step, ~lr*sign(g), flips wherever bf16 noise flips
+    # the sign of a near-zero entry: a 0.2 bar that said nothing about the optimiser.)
     new = [P[n].clone() for n in names]
-    O.adam_step(new, [g_r[n] for n in names], [torch.zeros_like(t) for t in new], [torch.zeros_like(t) for t in new], 1, 5e-3)
+    O.adam_step(new, [g[n].double().cpu() for n in names], [torch.zeros_like(t) for t in new], [torch.zeros_like(t) for t in new], 1, 5e-3)
     after = net.export_params()
     num = sum(((after[n].double().cpu() - before[n].double().cpu()) - (t - P[n])).pow(2).sum().item() for n, t in zip(names, new))
     den = sum((t - P[n]).pow(2).sum().item() for n, t in zip(names, new))
-    assert (num / den) ** 0.5 < 0.2
+    assert (num / den) ** 0.5 < 1e-4
 
 
 def test_eval_step_and_random_dropout(arch_a):

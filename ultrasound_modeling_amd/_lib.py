@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must be imported first: the HIP runtime torch loads is the one this library must share)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libusseg_hip.so")
+LIB_PATH = os.environ.get("USSEG_LIB") or os.path.join(_HERE, "libusseg_hip.so")   # USSEG_LIB: a diagnostic build of the SAME sources (tools/diag_norm_variants.sh)
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

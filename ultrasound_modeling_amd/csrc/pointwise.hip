@@ -49,6 +49,37 @@ extern "C" int64_t usseg_reduce_ws_floats(void) { return (int64_t)USSEG_REDUCE_M
 #ifndef NORM_OCC_G3
 #define NORM_OCC_G3 1   /* 3 waves (162-168 VGPRs) measured no faster on the latency-bound per-group LayerNorm launches, +7 us with the 24-byte spill of the fused variant */
 #endif
+// Butterfly sum of NG per-group partials over the LPP lanes of a pixel.  NORM_LADDER selects how the cross-lane results are consumed
+// (diagnostic builds of tools/diag_norm_variants.sh, which cleared this ladder: variants 1 and 2 fail exactly like 0 - the cause of the
+// load-dependent results was the unpadded packed-fp32 producer -> consumer pairs of the sum-of-squares chain):
+//   0: plain C++ (`s[g] += __shfl_xor(s[g], msk)`): with packed-fp32 code generation the compiler pairs two groups into
+//      ds_bpermute x3 -> s_waitcnt lgkmcnt(1) -> v_pk_add_f32 v[a:a+1], v[a:a+1], v[t:t+1]  (pair t:t+1 written by TWO LDS returns)
+//   1: every returned value passes through an empty asm first: the compiler must wait lgkmcnt(0) before any add
+//   2: the adds are single v_add_f32 (inline asm), whatever the rest of the kernel is compiled to
+#ifndef NORM_LADDER
+#define NORM_LADDER 0
+#endif
+template <int NG>
+__device__ __forceinline__ void ladder_sum(float (&s)[NG], int LPP) {
+  for (int msk = 1; msk < LPP; msk <<= 1) {
+    float t[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t[g] = __shfl_xor(s[g], msk, 64);
+#if NORM_LADDER == 1
+#pragma unroll
+    for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(t[g]));
+#endif
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#if NORM_LADDER == 2
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(s[g]) : "v"(t[g]));
+#else
+      s[g] += t[g];
+#endif
+    }
+  }
+}
+
 struct NormParams {
   const bf16_t* x; const bf16_t* dy; bf16_t* y; bf16_t* dx;
   const float *gamma, *beta, *mean, *var;
@@ -87,8 +118,13 @@ constexpr int norm_occ(bool bwd, int mode, int ng, bool fuse, bool pool) {
   return 4;
 }
 // (POOL sits at 130 VGPRs without the bound: two registers over the four-waves-per-SIMD line, 1.6x slower)
+#ifdef NORM_NO_OCC
+#define NORM_BOUNDS __launch_bounds__(256)
+#else
+#define NORM_BOUNDS __launch_bounds__(256, norm_occ(BWD, MODE, NG, FUSE, POOL))
+#endif
 template <bool BWD, int MODE, int NG, bool FUSE = false, bool POOL = false, bool RES = false>
-__global__ __launch_bounds__(256, norm_occ(BWD, MODE, NG, FUSE, POOL)) void norm_act_kernel(const NormParams p) {
+__global__ NORM_BOUNDS void norm_act_kernel(const NormParams p) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int LPP = p.LPP, ppw = 64 / LPP;
   const int chunk = lane & (LPP - 1), slot = lane / LPP;
@@ -191,11 +227,15 @@ __global__ __launch_bounds__(256, norm_occ(BWD, MODE, NG, FUSE, POOL)) void norm
         if (NG == 1) s[0] += xv[j] * okf[j];
         else
 #pragma unroll
-          for (int g = 0; g < NG; ++g) s[g] = fmaf(gm[g][j], xv[j], s[g]);
+          for (int g = 0; g < NG; ++g) {
+#ifdef NORM_SUMS_SCALAR   /* diagnostic: the per-group sums as single v_fmac_f32, the rest of the kernel as the compiler likes */
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s[g]) : "v"(gm[g][j]), "v"(xv[j]));
+#else
+            s[g] = fmaf(gm[g][j], xv[j], s[g]);
+#endif
+          }
       }
-      for (int msk = 1; msk < LPP; msk <<= 1)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) s[g] += __shfl_xor(s[g], msk, 64);
+      ladder_sum<NG>(s, LPP);
       float d[8], ss[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) ss[g] = 0.f;
@@ -213,11 +253,17 @@ __global__ __launch_bounds__(256, norm_occ(BWD, MODE, NG, FUSE, POOL)) void norm
         if (NG == 1) ss[0] = fmaf(d[j], d[j], ss[0]);
         else
 #pragma unroll
-          for (int g = 0; g < NG; ++g) ss[g] = fmaf(gm[g][j] * d[j], d[j], ss[g]);
+          for (int g = 0; g < NG; ++g) {
+#ifdef NORM_SUMS_SCALAR
+            float gd;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(gd) : "v"(gm[g][j]), "v"(d[j]));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(ss[g]) : "v"(gd), "v"(d[j]));
+#else
+            ss[g] = fmaf(gm[g][j] * d[j], d[j], ss[g]);
+#endif
+          }
       }
-      for (int msk = 1; msk < LPP; msk <<= 1)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) ss[g] += __shfl_xor(ss[g], msk, 64);
+      ladder_sum<NG>(ss, LPP);
       float rstd_g[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) rstd_g[g] = rsqrtf(ss[g] * inv_cg + p.eps);
@@ -320,12 +366,8 @@ __global__ __launch_bounds__(256, norm_occ(BWD, MODE, NG, FUSE, POOL)) void norm
               s2[g] = fmaf(gm[g][j] * dxh[j], xh[j], s2[g]);
             }
         }
-        for (int msk = 1; msk < LPP; msk <<= 1)
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            s1[g] += __shfl_xor(s1[g], msk, 64);
-            s2[g] += __shfl_xor(s2[g], msk, 64);
-          }
+        ladder_sum<NG>(s1, LPP);
+        ladder_sum<NG>(s2, LPP);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float a1, a2;
