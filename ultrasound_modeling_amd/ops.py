@@ -485,8 +485,20 @@ def _norm_desc(x, C_logical, out_ld, G, mode, eps, act, alpha) -> NormDesc:
     return NormDesc(B * H * W, C_logical, Cphys, ldx, out_ld, G, mode, eps, act, alpha)
 
 
+def _readable(t: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
+    """The norm kernels read their per-channel vectors in 16-byte pieces up to Cphys floats (include/usseg.h).  The model's vectors
+    are views of the flat parameter buffer, where every variable is padded to 8 floats; a stand-alone C-float tensor (tests) is
+    copied into a padded one so the kernel never reads past an allocation."""
+    if t is None or t.numel() >= n or t.storage_offset() + n <= t.untyped_storage().nbytes() // t.element_size():
+        return t
+    out = torch.zeros(n, dtype=t.dtype, device=t.device)
+    out[:t.numel()] = t.reshape(-1)
+    return out
+
+
 def norm_act_fwd(x, C_logical, gamma, beta, out, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None, var=None, mask=None):
     d = _norm_desc(x, C_logical, geom(out)[4], G, mode, eps, act, alpha)
+    gamma, beta, mean, var = (_readable(t, d.Cphys) for t in (gamma, beta, mean, var))
     ldm = geom(mask)[4] if mask is not None else 0
     L.check(L.load().usseg_norm_act_fwd(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean), _ptr(var),
                                         _ptr(mask), ldm, out.data_ptr(), _stream()), "norm_act_fwd")
@@ -498,6 +510,7 @@ def norm_act_fwd_gap(x, C_logical, gamma, beta, out, mode, G=1, eps=1e-3, act=AC
     ResNest.py:179): -> (out, (rows [B,nb,Cphys] fp32, nb, Cphys)) for ``splitattn_fwd(..., gap=...)``."""
     B, H, W, Cphys, _ = geom(x)
     d = _norm_desc(x, C_logical, geom(out)[4], G, mode, eps, act, alpha)
+    gamma, beta, mean, var = (_readable(t, Cphys) for t in (gamma, beta, mean, var))
     nb = max(1, min(32, (H * W) // 32))
     rows = torch.empty((B, nb, Cphys), dtype=torch.float32, device=x.device)
     L.check(L.load().usseg_norm_act_fwd_gap(C.byref(d), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean), _ptr(var), out.data_ptr(),
@@ -511,6 +524,7 @@ def norm_act_bwd_sa(x, dout, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G,
     (formed in registers: no usseg_splitattn_apply_bwd_dy pass, no dy tensor)."""
     B, H, W, Cphys, ldx = geom(x)
     d = NormDesc(B * H * W, C_logical, Cphys, ldx, geom(dout)[4], G, mode, eps, act, alpha, geom(dx)[4])
+    gamma, beta, mean, var = (_readable(t, Cphys) for t in (gamma, beta, mean, var))
     L.check(L.load().usseg_norm_act_bwd_sa(C.byref(d), x.data_ptr(), dout.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean), _ptr(var), B,
                                            sa_s.data_ptr(), sa_dg.data_ptr(), sa_mult, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                            _ptr(dbias), reduce_ws(x.device).data_ptr(), _stream()), "norm_act_bwd_sa")
@@ -522,6 +536,7 @@ def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, ep
     B, H, W, Cphys, ldx = geom(x)
     lddy = geom(dy)[4]
     d = NormDesc(B * H * W, C_logical, Cphys, ldx, lddy, G, mode, eps, act, alpha, geom(dx)[4])
+    gamma, beta, mean, var = (_readable(t, Cphys) for t in (gamma, beta, mean, var))
     ldm = geom(mask)[4] if mask is not None else 0
     L.check(L.load().usseg_norm_act_bwd(C.byref(d), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(mean),
                                         _ptr(var), _ptr(mask), ldm, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias),
