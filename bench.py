@@ -137,6 +137,21 @@ def pmc_traffic(arch, per_gpu_batch, launches_per_step):
     return None
 
 
+def pmc_mfma(arch):
+    """MFMA utilisation from the committed rocprofv3 --pmc pass of the same workload (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x the
+    dispatch's GRBM_GUI_ACTIVE / 8 cycles; tools/pmc_mfma.py, tools/profile_round.sh), newest round first, or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_mfma_arch{arch}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            fam = d["families"].get("conv forward / backward-data")
+            return {"conv_family": fam["mfma_busy_frac"], "weight_gradients": d["families"].get("weight gradients", {}).get("mfma_busy_frac"),
+                    "whole_step": d["whole_step_mfma_busy_frac"], "source": "profiles/" + os.path.basename(path)}
+        except Exception:
+            continue
+    return None
+
+
 def layer_probe(dev):
     """The two 3x3 exemplars of BASELINE.md section 2, forward only, B=32: the HBM-bound stem conv 32->32 at 256x256
     (north_star's "3x3 conv fwd at 256x256 bs=32") and the MFMA-bound concats_2 256->512 at 16x16.  HIP-event timed."""
@@ -467,6 +482,7 @@ def main():
                     "attainable_ms_per_step": round(algorithmic_flops.attainable_s * 1e3, 3),
                     "frac_of_attainable": round(algorithmic_flops.attainable_s * 1e3 / max(ig_ms, 1e-9), 4)}
         roofline["traffic"] = pmc_traffic(arch, per_gpu, ig_n)
+        roofline["mfma_busy_frac"] = pmc_mfma(arch)
         roofline["layers"] = layer_probe(dev)
 
     if rank == 0:

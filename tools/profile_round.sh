@@ -18,6 +18,9 @@ python3 tools/step_timeline.py gpurun_out/stats2_$TAG/r_kernel_trace.csv profile
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_f_$TAG.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_w_$TAG.log 2>&1
 python3 tools/pmc_traffic.py gpurun_out/pmc_f_$TAG/r_counter_collection.csv gpurun_out/pmc_w_$TAG/r_counter_collection.csv 4 profiles/${R}_pmc_traffic_arch${ARCH}.json $ARCH
+# MFMA utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation against peak"): its own --pmc pass, eager, 4 steps
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d gpurun_out/pmc_m_$TAG -o r --output-format csv -- python3 bench.py --arch $ARCH --no-graph --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > gpurun_out/pmc_m_$TAG.log 2>&1
+python3 tools/pmc_mfma.py gpurun_out/pmc_m_$TAG/r_counter_collection.csv 4 profiles/${R}_pmc_mfma_arch${ARCH}.json $ARCH
 python3 bench.py --arch $ARCH > profiles/${R}_bench_${V}_arch${ARCH}.json 2> gpurun_out/bench_$TAG.err
-mkdir -p gpurun_out/profiles && cp profiles/${R}_*_${V}_arch${ARCH}.* profiles/${R}_pmc_traffic_arch${ARCH}.json gpurun_out/profiles/   # gpurun merges only gpurun_out/ back: copy these into profiles/ and commit
+mkdir -p gpurun_out/profiles && cp profiles/${R}_*_${V}_arch${ARCH}.* profiles/${R}_pmc_traffic_arch${ARCH}.json profiles/${R}_pmc_mfma_arch${ARCH}.json gpurun_out/profiles/   # gpurun merges only gpurun_out/ back: copy these into profiles/ and commit
 tail -3 gpurun_out/bench_$TAG.err; tail -6 profiles/${R}_step_timeline_${V}_arch${ARCH}.txt
