@@ -265,6 +265,29 @@ int usseg_norm_act_fwd_gap(const UssegNormDesc* d, const void* x, const float* g
 int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, const void* dout, const float* gamma, const float* beta,
                           const float* mean, const float* var, int32_t B, const float* sa_s, const float* sa_dg, float sa_mult,
                           void* dx, float* dgamma, float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
+/* One residual_S stage's cardinal group AND shortcut as ONE launch (SURVEY.md section 2.2 "K3"; ResNest.py:136-147 per path - the `kpaths`
+ * paths share the input, :99-101 shortcut): replaces, in the implicit TensorFlow graph of the reference, Conv2D(1x1) -> LayerNormalization ->
+ * LeakyReLU -> Conv2D(3x3) -> LayerNormalization -> LeakyReLU (+ the reduce_mean of :179) per path and Conv2D(1x1) -> LayerNormalization ->
+ * LeakyReLU of the shortcut.  One workgroup owns an 8x8-pixel tile (+1 halo) of one image in LDS.
+ *   x [B,H,W,Cin] bf16; w1 [roundup(Up,16)][Cin], w2 [roundup(Vp,16)][9*Up] (block diagonal over the paths), wsc [Oc][Cin]: the packed
+ *   forward operands of usseg_conv2d_fwd; b1/g1/be1 [Up]/[P*cv11], b2/g2/be2 [Vp]/[P*cvkk], bsc/gsc/besc [Oc] fp32 (per-path vectors back to back);
+ *   outputs (all kept for the backward pass): u_raw, u [B,H,W,Up]; v_raw, y [B,H,W,Vp]; sc_raw, sc [B,H,W,Oc];
+ *   gap_rows [B][ceil(H/8)*ceil(W/8)][Vp] fp32: per-tile sums of y over its pixels (consumed by usseg_splitattn_mlp_fwd).
+ * Values are rounded to bf16 where the unfused launches round them.  usseg_cardinal_supported: 1 if a fused kernel exists for the
+ * channel configuration (the four stages of ResNest.py with radix 3 / kpaths 3), else the caller runs the unfused launches. */
+typedef struct UssegCardinalDesc {
+  int32_t B, H, W;
+  int32_t Cin;              /* physical input channels */
+  int32_t P, cv11, cvkk;    /* paths; logical channels per path after the 1x1 / the 3x3 (ResNest.py:120-121) */
+  int32_t Up, Vp, Oc;       /* physical widths roundup(P*cv11, 8), roundup(P*cvkk, 8); shortcut / stage output channels */
+  int32_t ldx, ldu, ldv, ldsc;
+  float eps, alpha;         /* LayerNormalization epsilon, LeakyReLU slope */
+} UssegCardinalDesc;
+int32_t usseg_cardinal_supported(const UssegCardinalDesc* d);
+int usseg_cardinal_fwd(const UssegCardinalDesc* d, const void* x, const void* w1, const float* b1, const float* g1, const float* be1,
+                       const void* w2, const float* b2, const float* g2, const float* be2, const void* wsc, const float* bsc,
+                       const float* gsc, const float* besc, void* u_raw, void* u, void* v_raw, void* y, float* gap_rows, void* sc_raw,
+                       void* sc, usseg_stream_t stream);
 /* Inference BatchNormalization + activation + AveragePooling2D(2,2) in one pass - the stem's convtmp_2bn -> LeakyReLU ->
  * conv1_pool (ResNest.py:45-47) and conv2_1_2bn -> ELU -> pool_1 (TBI_ResNest.py:90-92): the activated full-resolution tensor
  * feeds the pool only, so it is never written.  x [B,H,W,Cphys] pre-norm; y / dy [B,H/2,W/2,Cphys]; dx [B,H,W,Cphys] is the

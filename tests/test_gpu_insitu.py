@@ -424,6 +424,33 @@ def test_residual_S_stage_layer_by_layer(world, stage):
     norm_layer_check(net, rec, P, pre + "convtmp_scbn", st.convtmp_scbn, worst, "ln")
     sc = rec.act_after(rec.norm[pre + "convtmp_scbn"][1]).detach()
     conv_layer_check(net, rec, P, pre + "concats_2", st.concats_2, worst, residual=sc)
+    # ---- the fused launch (csrc/cardinal.hip): grouped 1x1 -> LN -> LeakyReLU -> grouped 3x3 -> LN -> LeakyReLU (+ pooled rows) and the
+    # shortcut 1x1 -> LN -> LeakyReLU from ONE read of the stage input.  Its only input is x, so the later tensors are compared with the
+    # oracle's own chain (same bf16 storage points): a value that lands on the other side of a rounding boundary moves the tensors behind it.
+    if grp.fused_ok(st.convtmp_sc):
+        fw = []
+        u_raw_f, u_f, v_raw_f, y_f, gap_f, sc_raw_f, sc_f = ops.cardinal_fwd(
+            xd, grp.w1_f, grp.b1, grp.g1, grp.be1, grp.w2_f, grp.b2, grp.g2, grp.be2, st.convtmp_sc.wp_f, st.convtmp_sc.bias.data,
+            st.convtmp_scbn.gamma.data, st.convtmp_scbn.beta.data, grp.P, grp.cv11, grp.cvkk, grp.Up, grp.Vp, st.convtmp_sc.cout, 1e-3, a)
+        torch.cuda.synchronize()
+        cat = lambda ts: torch.cat([t.detach() for t in ts], 3)
+        check("fused: grouped conv1", u_raw_f[..., :grp.U], cat([rec.conv[c + "conv1"][1] for c in cards]), worst=fw)
+        check("fused: conv1_bn + act", u_f[..., :grp.U], cat([rec.act_after(rec.norm[c + "conv1_bn"][1]) for c in cards]), 2 * TOL, worst=fw)
+        check("fused: grouped conv2", v_raw_f[..., :grp.V], cat([rec.conv[c + "conv2"][1] for c in cards]), 2 * TOL, worst=fw)
+        check("fused: conv2_bn + act", y_f[..., :grp.V], cat([rec.sa[c + "split."][0] for c in cards]), 2 * TOL, worst=fw)
+        check("fused: shortcut conv", sc_raw_f, rec.conv[pre + "convtmp_sc"][1], worst=fw)
+        check("fused: shortcut LN + act", sc_f, sc, 2 * TOL, worst=fw)
+        for t, wlog in ((u_raw_f, grp.U), (u_f, grp.U), (v_raw_f, grp.V), (y_f, grp.V)):
+            assert t.shape[3] == wlog or t[..., wlog:].abs().max().item() == 0, "fused: pad channels"
+        check("fused: pooled partial rows", gap_f[0].sum(dim=1)[:, :grp.V] / (H * W), y_f[..., :grp.V].double().mean(dim=(1, 2)), worst=fw)
+        # against the product's own unfused launches on the same input: the same arithmetic at the same rounding points
+        u_raw_u = ops.conv2d_fwd(xd, grp.w1_f, grp.b1, 1, 1, ops.new_act(B, H, W, grp.Up, DEV))
+        u_u = ops.norm_act_fwd(u_raw_u, grp.U, grp.g1, grp.be1, torch.empty_like(u_raw_u), 0, 3, 1e-3, ops.ACT_LRELU, a)
+        v_raw_u = ops.conv2d_fwd(u_u, grp.w2_f, grp.b2, grp.k, grp.dil, ops.new_act(B, H, W, grp.Vp, DEV))
+        y_u = ops.norm_act_fwd(v_raw_u, grp.V, grp.g2, grp.be2, torch.empty_like(v_raw_u), 0, 3, 1e-3, ops.ACT_LRELU, a)
+        for nm, f_, u_ in (("u_raw", u_raw_f, u_raw_u), ("u", u_f, u_u), ("v_raw", v_raw_f, v_raw_u), ("y", y_f, y_u)):
+            check(f"fused vs unfused launches: {nm}", f_, u_, worst=fw)
+        print(f"stage {stage} fused:", [(f"{e:.2e}", n) for e, n in sorted(fw, reverse=True)[:6]])
     print(f"stage {stage} worst:", [(f"{e:.2e}", n) for e, n in sorted(worst, reverse=True)[:5]])
 
 

@@ -36,6 +36,8 @@ from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 # blocks') weight gradients beside this encoder, and more forks made Arch B 1 % and cfg4 3 % slower
 _STAGE_LAZY = os.environ.get("USSEG_ENC_LAZY", "0") != "0"
 _FOLD_BN = os.environ.get("USSEG_FOLD_BN", "1") != "0"
+# the cardinal group + shortcut of a stage as ONE launch (csrc/cardinal.hip); 0 = the six unfused launches (the cross-check of the tests)
+_FUSED_CARDINAL = os.environ.get("USSEG_FUSED_CARDINAL", "1") != "0"
 
 
 def _span(t: torch.Tensor, n: int) -> torch.Tensor:
@@ -224,6 +226,31 @@ class _CardinalGroup:
     def _mlp_params(self):
         return self.mlp_p[:4] + self.sta + self.mlp_p[4:]
 
+    def fused_ok(self, sc_conv) -> bool:
+        """True if csrc/cardinal.hip has a kernel for this stage (LayerNormalization variant, 3x3, no dilation, the channel
+        configurations of ResNest.py with radix 3 / kpaths 3)."""
+        ok = getattr(self, "_fused_ok", None)
+        if ok is None:
+            ok = self._fused_ok = (not self.bn and self.k == 3 and self.dil == 1 and sc_conv.k == 1 and sc_conv.cout_p == sc_conv.cout and
+                                   ops.cardinal_supported(self.cin_p, self.P, self.cv11, self.cvkk, self.Up, self.Vp, sc_conv.cout))
+        return ok and _FUSED_CARDINAL
+
+    def forward_fused(self, x, sc_conv, sc_norm, out=None):
+        """ResNest.py:136-147 for all paths + the shortcut :99-101 in one launch, then the split-attention MLP and re-weighting
+        (:171-199).  Leaves exactly the state the unfused forward leaves (``_saved``, the shortcut layers' saved inputs), so the
+        backward pass is the same code. -> (concats_1, sc)"""
+        B, H, W, _, _ = ops.geom(x)
+        a = KERAS_LRELU_ALPHA
+        u_raw, u, v_raw, y, gap, sc_raw, sc = ops.cardinal_fwd(x, self.w1_f, self.b1, self.g1, self.be1, self.w2_f, self.b2, self.g2, self.be2,
+                                                               sc_conv.wp_f, sc_conv.bias.data, sc_norm.gamma.data, sc_norm.beta.data,
+                                                               self.P, self.cv11, self.cvkk, self.Up, self.Vp, sc_conv.cout, KERAS_LN_EPS, a)
+        out = out if out is not None else ops.new_act(B, H, W, self.Vp, x.device)
+        _, g, s, ws = ops.splitattn_fwd(self._sa_desc(B, H * W), y, self._mlp_params(), out, gap=gap)
+        self._saved = (x, u_raw, u, v_raw, y, g, s, ws)
+        sc_conv._x = x
+        sc_norm._x, sc_norm._act = sc_raw, (ACT_LRELU, a)
+        return out, sc
+
     def forward(self, x, out=None):
         B, H, W, C, _ = ops.geom(x)
         dev = x.device
@@ -291,6 +318,9 @@ class residual_S(nn.Module):
         return self._group.pack_jobs()
 
     def forward(self, x, out=None):
+        if self._group.fused_ok(self.convtmp_sc):
+            concats_1, sc = self._group.forward_fused(x, self.convtmp_sc, self.convtmp_scbn)        # :91-96 and :99-101, one launch + the attention
+            return self.concats_2.forward(concats_1, out=out, residual=sc)                           # :98,:102
         concats_1 = self._group.forward(x)                                                          # :91-96
         sc_raw = self.convtmp_sc.forward(x)                                                          # :99
         sc = self.convtmp_scbn.forward(sc_raw, ACT_LRELU, KERAS_LRELU_ALPHA)                        # :100-101

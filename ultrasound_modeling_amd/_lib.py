@@ -60,6 +60,11 @@ class NormDesc(C.Structure):
                 ("mode", c_i32), ("eps", c_f32), ("act", c_i32), ("alpha", c_f32), ("lddx", c_i32)]
 
 
+class CardinalDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32), ("P", c_i32), ("cv11", c_i32), ("cvkk", c_i32), ("Up", c_i32),
+                ("Vp", c_i32), ("Oc", c_i32), ("ldx", c_i32), ("ldu", c_i32), ("ldv", c_i32), ("ldsc", c_i32), ("eps", c_f32), ("alpha", c_f32)]
+
+
 class SplitAttnDesc(C.Structure):
     _fields_ = [("B", c_i32), ("HW", c_i32), ("P", c_i32), ("R", c_i32), ("Cg", c_i32), ("Hd", c_i32),
                 ("ldy", c_i32), ("ldo", c_i32), ("Cy_phys", c_i32), ("Co_phys", c_i32), ("mult", c_f32),
@@ -140,6 +145,9 @@ _PROTOS = {
     "usseg_splitattn_ws_floats": (c_i64, [P(SplitAttnDesc)]),
     "usseg_splitattn_mlp_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_i32, P(SplitAttnParams), c_vp, c_vp, c_vp]),
     "usseg_norm_act_fwd_gap": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    # fused cardinal group + shortcut of a residual_S stage (ResNest.py:99-101,136-147): the ten Keras layers of a stage's first half
+    "usseg_cardinal_supported": (c_i32, [P(CardinalDesc)]),
+    "usseg_cardinal_fwd": (C.c_int, [P(CardinalDesc)] + [c_vp] * 21),
     "usseg_accuracy": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "usseg_norm_act_bwd_res": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_norm_act_bwd_sa": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

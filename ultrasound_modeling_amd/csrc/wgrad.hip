@@ -161,7 +161,7 @@ __device__ __forceinline__ wg_i32x4_t wg_rsrc(const void* base) {   // stride 0,
 }
 __device__ __forceinline__ void wg_dma16(const wg_i32x4_t rsrc, char* lds_dst, uint32_t voff) {
   const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rsrc) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rsrc) : "memory");   // (M0 is a reserved register to this compiler: it re-materialises M0 before every use of its own, and rejects it in a clobber list)
 }
 
 template <int TM, int NSTAGE>

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib as L
-from ._lib import (ACCUMULATE, ACT_ELU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, OUT_F32, ConvDesc, GemmDesc, LossDesc, NormDesc,
+from ._lib import (ACCUMULATE, ACT_ELU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, OUT_F32, CardinalDesc, ConvDesc, GemmDesc, LossDesc, NormDesc,
                    SplitAttnDesc, SplitAttnGrads, SplitAttnParams)
 
 BF16 = torch.bfloat16
@@ -722,6 +722,36 @@ def adam_clip_step(p, g, m, v, sumsq_t, clip_norm, lr_t_dev, b1, b2, eps):
 
 def adam_advance(step_dev, lr_t_dev, lr, b1, b2):
     L.check(L.load().usseg_adam_advance(step_dev.data_ptr(), lr_t_dev.data_ptr(), lr, b1, b2, _stream()), "adam_advance")
+
+
+# ------------------------------------------------------------------------------------------------ fused cardinal group (K3)
+def cardinal_desc(B, H, W, Cin, P, cv11, cvkk, Up, Vp, Oc, ldx, ldu, ldv, ldsc, eps, alpha) -> CardinalDesc:
+    return CardinalDesc(B, H, W, Cin, P, cv11, cvkk, Up, Vp, Oc, ldx, ldu, ldv, ldsc, eps, alpha)
+
+
+def cardinal_supported(Cin, P, cv11, cvkk, Up, Vp, Oc) -> bool:
+    d = cardinal_desc(1, 8, 8, Cin, P, cv11, cvkk, Up, Vp, Oc, Cin, Up, Vp, Oc, 1e-3, 0.3)
+    return bool(L.load().usseg_cardinal_supported(C.byref(d)))
+
+
+def cardinal_fwd(x, w1, b1, g1, be1, w2, b2, g2, be2, wsc, bsc, gsc, besc, P, cv11, cvkk, Up, Vp, Oc, eps, alpha):
+    """One launch for a residual_S stage's first half (ResNest.py:136-147 for all paths, :99-101): grouped 1x1 -> LN -> LeakyReLU ->
+    grouped 3x3 -> LN -> LeakyReLU (+ pooled partial rows) and the shortcut 1x1 -> LN -> LeakyReLU.
+    -> (u_raw, u, v_raw, y, gap, sc_raw, sc); gap = (rows [B,tiles,Vp], tiles, Vp) for ``splitattn_fwd(..., gap=gap)``."""
+    B, H, W, Cin, ldx = geom(x)
+    dev = x.device
+    u_raw, u = new_act(B, H, W, Up, dev), new_act(B, H, W, Up, dev)
+    v_raw, y = new_act(B, H, W, Vp, dev), new_act(B, H, W, Vp, dev)
+    sc_raw, sc = new_act(B, H, W, Oc, dev), new_act(B, H, W, Oc, dev)
+    tiles = ((H + 7) // 8) * ((W + 7) // 8)
+    rows = torch.empty((B, tiles, Vp), dtype=torch.float32, device=dev)
+    d = cardinal_desc(B, H, W, Cin, P, cv11, cvkk, Up, Vp, Oc, ldx, Up, Vp, Oc, eps, alpha)
+    g1, be1, g2, be2, gsc, besc = (_readable(t, n) for t, n in ((g1, P * cv11), (be1, P * cv11), (g2, P * cvkk), (be2, P * cvkk), (gsc, Oc), (besc, Oc)))
+    L.check(L.load().usseg_cardinal_fwd(C.byref(d), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), g1.data_ptr(), be1.data_ptr(), w2.data_ptr(),
+                                        b2.data_ptr(), g2.data_ptr(), be2.data_ptr(), wsc.data_ptr(), bsc.data_ptr(), gsc.data_ptr(), besc.data_ptr(),
+                                        u_raw.data_ptr(), u.data_ptr(), v_raw.data_ptr(), y.data_ptr(), rows.data_ptr(), sc_raw.data_ptr(),
+                                        sc.data_ptr(), _stream()), "cardinal_fwd")
+    return u_raw, u, v_raw, y, (rows, tiles, Vp), sc_raw, sc
 
 
 # ------------------------------------------------------------------------------------------------ split attention
