@@ -533,6 +533,309 @@ int launch_fwd(const CardFwd& p, hipStream_t s) {
 
 }  // namespace
 
+// =====================================================================================================================================
+// LayerNormalization + LeakyReLU BACKWARD of the cardinal group's norms (3 groups of 3..85 channels) and of the shortcut norm (one group of
+// 64..512), on the same lane = pixel scheme.  The general kernel (pointwise.hip norm_act_kernel<true, 0, 3>) keeps a pixel on several lanes
+// with per-lane 0/1 group masks folded into FMAs: ~30 FMAs per element, one wave per SIMD, 16-41 us per launch for 12-50 MB (7-10x its HBM
+// time) - 180 us of the Arch B step.  Here a workgroup stages a 64-pixel tile of x and dy in LDS; row passes (lane = pixel, wave-uniform
+// compile-time channels: no masks) produce the per-pixel statistics mean, 1/sigma, sum(dxh)/Cg, sum(dxh*xh)/Cg; a column pass (thread =
+// channel) forms dx and the three per-channel sums (dgamma, dbeta, sum dx = the producing conv's bias gradient) in pixel order - no
+// cross-lane reduction, bitwise reproducible; the tile leaves in whole rows.  Workgroups walk tiles (persistent), one partial row each.
+namespace {
+
+struct LnTile {
+  LnTileArgs a;
+  int32_t ntiles;
+};
+
+template <int CSI, int CP, int CG, int NG, bool FUSE>
+__device__ __forceinline__ void lnb_rows(const bf16_t* xrow, const bf16_t* dyrow, float* STAT, float4* pst, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, const float* SA, float eps, float alpha, int wvu, int lane) {
+  constexpr int CPS = (CP + 3) / 4, C = CG * NG, C0 = CSI * CPS, CPH = CP * 8;
+  const float inv = 1.f / (float)CG;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPS; ++j)
+    if (C0 + j < CP) {
+      float x[8];
+      unpack8(*reinterpret_cast<const uint4*>(xrow + (C0 + j) * 8), x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = (C0 + j) * 8 + e, g = ch / CG;
+        if (ch < C) { if (g == 0) s0 += x[e]; else if (g == 1) s1 += x[e]; else s2 += x[e]; }
+      }
+    }
+  float* st = STAT + wvu * 256 + lane;
+  st[0] = s0;
+  if (NG > 1) { st[64] = s1; st[128] = s2; }
+  __syncthreads();
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float* o = STAT + k * 256 + lane;
+    m0 += o[0];
+    if (NG > 1) { m1 += o[64]; m2 += o[128]; }
+  }
+  m0 *= inv; m1 *= inv; m2 *= inv;
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPS; ++j)
+    if (C0 + j < CP) {
+      float x[8];
+      unpack8(*reinterpret_cast<const uint4*>(xrow + (C0 + j) * 8), x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = (C0 + j) * 8 + e, g = ch / CG;
+        if (ch < C) {
+          const float d = x[e] - (g == 0 ? m0 : (g == 1 ? m1 : m2));
+          if (g == 0) q0 = fmaf(d, d, q0); else if (g == 1) q1 = fmaf(d, d, q1); else q2 = fmaf(d, d, q2);
+        }
+      }
+    }
+  st = STAT + 1024 + wvu * 256 + lane;
+  st[0] = q0;
+  if (NG > 1) { st[64] = q1; st[128] = q2; }
+  __syncthreads();
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float* o = STAT + 1024 + k * 256 + lane;
+    r0 += o[0];
+    if (NG > 1) { r1 += o[64]; r2 += o[128]; }
+  }
+  r0 = rsqrtf(r0 * inv + eps); r1 = rsqrtf(r1 * inv + eps); r2 = rsqrtf(r2 * inv + eps);
+  // sums of dxh and dxh * xh over each group (dxh = dy * act'(gamma * xh + beta) * gamma)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPS; ++j)
+    if (C0 + j < CP) {
+      float x[8], dy[8];
+      unpack8(*reinterpret_cast<const uint4*>(xrow + (C0 + j) * 8), x);
+      unpack8(*reinterpret_cast<const uint4*>(dyrow + (C0 + j) * 8), dy);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = (C0 + j) * 8 + e, g = ch / CG;
+        if (ch < C) {
+          const float mean = g == 0 ? m0 : (g == 1 ? m1 : m2), rstd = g == 0 ? r0 : (g == 1 ? r1 : r2);
+          const float xh = (x[e] - mean) * rstd;
+          const float pre = gamma[ch] * xh + beta[ch];
+          const float dye = FUSE ? fmaf(dy[e], SA[ch], SA[CPH + ch]) : dy[e];       // wave-uniform LDS reads
+          const float dxh = dye * (pre >= 0.f ? 1.f : alpha) * gamma[ch];
+          if (g == 0) { a0 += dxh; b0 = fmaf(dxh, xh, b0); }
+          else if (g == 1) { a1 += dxh; b1 = fmaf(dxh, xh, b1); }
+          else { a2 += dxh; b2 = fmaf(dxh, xh, b2); }
+        }
+      }
+    }
+  st = STAT + 2048 + wvu * 256 + lane;
+  st[0] = a0;
+  if (NG > 1) { st[64] = a1; st[128] = a2; }
+  st = STAT + 3072 + wvu * 256 + lane;
+  st[0] = b0;
+  if (NG > 1) { st[64] = b1; st[128] = b2; }
+  __syncthreads();
+  if (CSI == 0) {
+    float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        sa[g] += STAT[2048 + k * 256 + g * 64 + lane];
+        sb[g] += STAT[3072 + k * 256 + g * 64 + lane];
+      }
+    pst[lane * NG + 0] = make_float4(m0, r0, sa[0] * inv, sb[0] * inv);
+    if (NG > 1) {
+      pst[lane * NG + 1] = make_float4(m1, r1, sa[1] * inv, sb[1] * inv);
+      pst[lane * NG + 2] = make_float4(m2, r2, sa[2] * inv, sb[2] * inv);
+    }
+  }
+}
+
+template <int CP, int CG, int NG, bool FUSE>
+struct LnbCfg {
+  static constexpr int CPH = CP * 8, XS = CPH + 8;
+  static constexpr int XT_B = 64 * XS * 2, PST_B = 64 * NG * 16, STAT_B4 = 4 * 1024 * 4, SA_B = FUSE ? 2 * CPH * 4 : 0;
+  static constexpr int PG = CPH >= 256 ? 1 : 256 / CPH, NR = CPH > 256 ? CPH / 256 : 1;
+  static constexpr int RED_B = PG * 3 * CPH * 4;
+  static constexpr int LDS_B = 2 * XT_B + PST_B + STAT_B4 + RED_B + SA_B;
+};
+
+// FUSE (the split-attention re-weighting's backward dy_eff = sa_mult*s[b][c]*dy + dg[b][c], formed in fp32 and never stored): a tile lies
+// inside ONE image (the launcher checks HW % 64 == 0), so its (s, dg) row is staged in LDS once per tile.
+template <int CP, int CG, int NG, bool FUSE>
+__global__ __launch_bounds__(256) void ln_bwd_tile_kernel(const LnTile P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using Cfg = LnbCfg<CP, CG, NG, FUSE>;
+  constexpr int CPH = Cfg::CPH, XS = Cfg::XS, PG = Cfg::PG, NR = Cfg::NR, C = CG * NG;
+  const LnTileArgs& a = P.a;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  bf16_t* const XT = reinterpret_cast<bf16_t*>(lds);
+  bf16_t* const DT = reinterpret_cast<bf16_t*>(lds + Cfg::XT_B);
+  float4* const PST = reinterpret_cast<float4*>(lds + 2 * Cfg::XT_B);
+  float* const STAT = reinterpret_cast<float*>(lds + 2 * Cfg::XT_B + Cfg::PST_B);
+  float* const RED = reinterpret_cast<float*>(lds + 2 * Cfg::XT_B + Cfg::PST_B + Cfg::STAT_B4);
+  float* const SA = reinterpret_cast<float*>(lds + 2 * Cfg::XT_B + Cfg::PST_B + Cfg::STAT_B4 + Cfg::RED_B);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // column role: channel ct (+ 256 in the second round of a 512-channel norm), pixel group cpg
+  const int ct = CPH >= 256 ? tid : tid % CPH, cpg = CPH >= 256 ? 0 : tid / CPH;
+  const bool col_on = CPH >= 256 || tid < PG * CPH;
+  float acc[NR][3];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
+  float cga[NR], cbe[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int ch = ct + 256 * r;
+    cga[r] = ch < C ? a.gamma[ch] : 0.f;
+    cbe[r] = ch < C ? a.beta[ch] : 0.f;
+  }
+  constexpr int NIT = (64 * CP + 255) / 256;
+  uint4 vx[NIT], vd[NIT];
+  float sav = 0.f, sag = 0.f;
+  auto issue = [&](int tile) {      // the tile's global loads into registers (in flight while the previous tile is processed)
+    const int64_t m0 = (int64_t)tile * 64;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = tid + i * 256;
+      const int row = it / CP, c = it - row * CP;
+      const bool ok = it < 64 * CP && m0 + row < a.M;
+      vx[i] = ok ? *reinterpret_cast<const uint4*>(a.x + (m0 + row) * a.ldx + c * 8) : make_uint4(0, 0, 0, 0);
+      vd[i] = ok ? *reinterpret_cast<const uint4*>(a.dy + (m0 + row) * a.lddy + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+    if (FUSE) {
+      const int64_t bimg = m0 / a.HW;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int ch = tid + 256 * r;
+        if (r == 0 && ch < CPH) {
+          const int cc = ch < a.sa_cy ? ch : a.sa_cy - 1;
+          sav = ch < C ? a.sa_mult * a.sa_s[bimg * a.sa_cy + cc] : 0.f;
+          sag = ch < C ? a.sa_dg[bimg * a.sa_cy + cc] : 0.f;
+        }
+      }
+    }
+  };
+  if ((int)blockIdx.x < P.ntiles) issue(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+    const int64_t m0 = (int64_t)tile * 64;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = tid + i * 256;
+      const int row = it / CP, c = it - row * CP;
+      if (it < 64 * CP) {
+        *reinterpret_cast<uint4*>(XT + row * XS + c * 8) = vx[i];
+        *reinterpret_cast<uint4*>(DT + row * XS + c * 8) = vd[i];
+      }
+    }
+    if (FUSE && tid < CPH) { SA[tid] = sav; SA[CPH + tid] = sag; }
+    __syncthreads();
+    if (tile + (int)gridDim.x < P.ntiles) issue(tile + gridDim.x);
+    // ---- row passes: per-pixel statistics
+    {
+      const bf16_t* xrow = XT + lane * XS;
+      const bf16_t* dyrow = DT + lane * XS;
+      if (wv == 0) lnb_rows<0, CP, CG, NG, FUSE>(xrow, dyrow, STAT, PST, a.gamma, a.beta, SA, a.eps, a.alpha, wv, lane);
+      else if (wv == 1) lnb_rows<1, CP, CG, NG, FUSE>(xrow, dyrow, STAT, PST, a.gamma, a.beta, SA, a.eps, a.alpha, wv, lane);
+      else if (wv == 2) lnb_rows<2, CP, CG, NG, FUSE>(xrow, dyrow, STAT, PST, a.gamma, a.beta, SA, a.eps, a.alpha, wv, lane);
+      else lnb_rows<3, CP, CG, NG, FUSE>(xrow, dyrow, STAT, PST, a.gamma, a.beta, SA, a.eps, a.alpha, wv, lane);
+    }
+    __syncthreads();
+    // ---- column pass: dx (in place of x) and the per-channel sums, pixels in order
+    if (col_on) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int ch = ct + 256 * r;
+        const int g = NG == 1 ? 0 : (ch >= CG) + (ch >= 2 * CG);
+        const float sv = FUSE ? SA[ch] : 1.f, sg = FUSE ? SA[CPH + ch] : 0.f;
+        float sga = 0.f, sbe = 0.f, sbi = 0.f;
+#pragma unroll 4
+        for (int px = cpg; px < 64; px += PG) {
+          float o = 0.f;
+          if (ch < C) {
+            const float4 st = PST[px * NG + (g < NG ? g : 0)];
+            const float x = bf2f(XT[px * XS + ch]);
+            float dy = bf2f(DT[px * XS + ch]);
+            if (FUSE) dy = fmaf(dy, sv, sg);
+            const float xh = (x - st.x) * st.y;
+            const float pre = cga[r] * xh + cbe[r];
+            const float dh = dy * (pre >= 0.f ? 1.f : a.alpha);
+            const float dxh = dh * cga[r];
+            o = st.y * (dxh - st.z - xh * st.w);
+            if (m0 + px < a.M) { sga = fmaf(dh, xh, sga); sbe += dh; sbi += o; }
+          }
+          XT[px * XS + ch] = f2bf(o);
+        }
+        if (PG == 1) { acc[r][0] += sga; acc[r][1] += sbe; acc[r][2] += sbi; }
+        else { RED[(cpg * 3 + 0) * CPH + ch] = sga; RED[(cpg * 3 + 1) * CPH + ch] = sbe; RED[(cpg * 3 + 2) * CPH + ch] = sbi; }
+      }
+    }
+    __syncthreads();
+    if (PG > 1 && tid < CPH) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float t = 0.f;
+        for (int gq = 0; gq < PG; ++gq) t += RED[(gq * 3 + k) * CPH + tid];
+        acc[0][k] += t;
+      }
+    }
+    // ---- dx leaves in whole rows
+    for (int it = tid; it < 64 * CP; it += 256) {
+      const int row = it / CP, c = it - row * CP;
+      if (m0 + row < a.M) *reinterpret_cast<uint4*>(a.dx + (m0 + row) * a.lddx + c * 8) = *reinterpret_cast<const uint4*>(XT + row * XS + c * 8);
+    }
+    __syncthreads();
+  }
+  if (CPH >= 256 || tid < CPH) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a.ws[((int64_t)blockIdx.x * 3 + k) * CPH + ct + 256 * r] = acc[r][k];
+  }
+#endif
+}
+
+template <int CP, int CG, int NG, bool FUSE>
+int launch_lnb(const LnTileArgs& a, float* dgamma, float* dbeta, float* dbias, float* caller_ws, hipStream_t s) {
+  using Cfg = LnbCfg<CP, CG, NG, FUSE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)ln_bwd_tile_kernel<CP, CG, NG, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_B);
+    attr_done = true;
+  }
+  LnTile P;
+  P.a = a;
+  P.ntiles = (int)((a.M + 63) / 64);
+  const int per_cu = Cfg::LDS_B > 80 * 1024 ? 1 : (Cfg::LDS_B > 40 * 1024 ? 2 : 4);
+  int grid = P.ntiles < 256 * per_cu ? P.ntiles : 256 * per_cu;
+  if (grid > USSEG_REDUCE_MAX_BLOCKS) grid = USSEG_REDUCE_MAX_BLOCKS;
+  P.a.ws = usseg_defer_reduce_ws(s, caller_ws, (int64_t)grid * 3 * Cfg::CPH);
+  hipLaunchKernelGGL((ln_bwd_tile_kernel<CP, CG, NG, FUSE>), dim3(grid), dim3(256), Cfg::LDS_B, s, P);
+  usseg_launch_reduce_finish(P.a.ws, 1, grid, 3, Cfg::CPH, a.C, 1.f, dgamma, dbeta, dbias, s, 0);
+  return 1;
+}
+
+}  // namespace
+
+int usseg_try_ln_bwd_tile(const LnTileArgs& a, float* dgamma, float* dbeta, float* dbias, float* caller_ws, hipStream_t s) {
+  static const int off = getenv("USSEG_LN_TILE") && atoi(getenv("USSEG_LN_TILE")) == 0;
+  if (off || a.M <= 0 || a.M >= (1ll << 31)) return 0;
+  const bool fuse = a.sa_s != nullptr;
+  // a 64-pixel tile is one long dependency chain per workgroup: it beats the streaming kernel (one pixel on 4-16 lanes, mask FMAs) once the
+  // tensor has several tiles per CU to overlap (measured: 2x on 128x128 / 64x64 x 16 images, slower below ~32k pixels)
+  static const int64_t min_px = getenv("USSEG_LN_TILE_MIN") ? atoll(getenv("USSEG_LN_TILE_MIN")) : 32768;
+  if (a.M < min_px || (fuse && a.HW % 64 != 0)) return 0;
+  const int cg = a.G > 0 ? a.C / a.G : 0;
+#define LNB(CPv, CGv, NGv)                                                                                                  \
+  if (a.Cphys == CPv * 8 && a.G == NGv && cg == CGv)                                                                        \
+    return fuse ? launch_lnb<CPv, CGv, NGv, true>(a, dgamma, dbeta, dbias, caller_ws, s) : launch_lnb<CPv, CGv, NGv, false>(a, dgamma, dbeta, dbias, caller_ws, s);
+  LNB(2, 3, 3) LNB(3, 7, 3) LNB(6, 14, 3) LNB(11, 28, 3)          // conv1_bn of the four stages (ResNest.py:140)
+  LNB(4, 10, 3) LNB(8, 21, 3) LNB(16, 42, 3) LNB(32, 85, 3)       // conv2_bn (:143), also with the split-attention re-weighting folded in
+  if (!fuse) { LNB(8, 64, 1) LNB(16, 128, 1) LNB(32, 256, 1) LNB(64, 512, 1) }   // convtmp_scbn (:100), DecoderCup.bn1 (Decoder.py:112)
+#undef LNB
+  return 0;
+}
+
 // The channel configurations of a ResNest.py stage with radix 3 / kpaths 3 (ResNest.py:120-121: cv11 = 3/7/14/28, cvkk = 10/21/42/85)
 static int card_config(const UssegCardinalDesc* d) {
   if (!d || d->P != 3) return -1;

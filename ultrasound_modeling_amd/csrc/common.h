@@ -375,6 +375,20 @@ void usseg_set_error(const char* fmt, ...);
   } while (0)
 int usseg_check_launch(const char* what);
 // opt-in per-launch timing: returns an event slot (>=0) after recording its start event, or -1 when disabled
+// LayerNorm + LeakyReLU backward on the lane-per-pixel tile kernel (cardinal.hip); returns 0 if it has no instantiation for the geometry
+struct LnTileArgs {
+  const bf16_t *x, *dy;
+  bf16_t* dx;
+  const float *gamma, *beta;
+  const float *sa_s, *sa_dg;     // split-attention re-weighting backward folded in: dy_eff = sa_mult * sa_s[b][c] * dy + sa_dg[b][c]; NULL = plain
+  float sa_mult;
+  int32_t sa_cy;
+  float* ws;                     // per-workgroup partial rows [grid][3][Cphys]
+  int64_t M, HW;
+  int32_t C, Cphys, G, ldx, lddy, lddx;
+  float eps, alpha;
+};
+int usseg_try_ln_bwd_tile(const LnTileArgs& a, float* dgamma, float* dbeta, float* dbias, float* caller_ws, hipStream_t s);
 int usseg_prof_start(int kind, hipStream_t s);
 void usseg_prof_stop(int kind, int slot, hipStream_t s);
 

@@ -471,6 +471,12 @@ extern "C" int usseg_norm_act_bwd(const UssegNormDesc* d, const void* x, const v
   p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->lddx > 0 ? d->lddx : d->ldx;
   USSEG_CHECK_ARG(p.lddx % 8 == 0 && p.lddx >= d->Cphys, "norm bwd: bad dx stride");
   if (p.M <= 0) return USSEG_OK;
+  if (d->mode == 0 && !mask && d->act == USSEG_ACT_LRELU) {      // the cardinal / shortcut LayerNorms: lane-per-pixel tile kernel (cardinal.hip)
+    LnTileArgs t = {};
+    t.x = p.x; t.dy = p.dy; t.dx = p.dx; t.gamma = gamma; t.beta = beta; t.M = p.M; t.HW = p.M; t.C = p.C; t.Cphys = p.Cphys; t.G = p.G;
+    t.ldx = p.ldx; t.lddy = p.lddy; t.lddx = p.lddx; t.eps = p.eps; t.alpha = p.alpha;
+    if (usseg_try_ln_bwd_tile(t, dgamma, dbeta, dbias, ws, (hipStream_t)stream)) return usseg_check_launch("norm_act_bwd (tile)");
+  }
   int ppb = 4 * (64 / p.LPP);
   // small tensors are latency bound (each loop trip is a dependent load -> store): spread them over many workgroups
   unsigned grid = grid_for(p.M, ppb * 2, USSEG_REDUCE_MAX_BLOCKS);
@@ -534,6 +540,13 @@ extern "C" int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, cons
   p.ldx = d->ldx; p.lddy = d->ldy; p.lddx = d->lddx > 0 ? d->lddx : d->ldx;
   p.HW = d->M / B; p.sa_s = sa_s; p.sa_dg = sa_dg; p.sa_cy = d->C; p.sa_mult = sa_mult;
   USSEG_CHECK_ARG(p.lddx % 8 == 0 && p.lddx >= d->Cphys, "norm bwd: bad dx stride");
+  if (d->mode == 0 && d->act == USSEG_ACT_LRELU && p.M > 0) {
+    LnTileArgs t = {};
+    t.x = p.x; t.dy = p.dy; t.dx = p.dx; t.gamma = gamma; t.beta = beta; t.M = p.M; t.HW = p.HW; t.C = p.C; t.Cphys = p.Cphys; t.G = p.G;
+    t.ldx = p.ldx; t.lddy = p.lddy; t.lddx = p.lddx; t.eps = p.eps; t.alpha = p.alpha;
+    t.sa_s = sa_s; t.sa_dg = sa_dg; t.sa_mult = sa_mult; t.sa_cy = p.sa_cy;
+    if (usseg_try_ln_bwd_tile(t, dgamma, dbeta, dbias, ws, (hipStream_t)stream)) return usseg_check_launch("norm_act_bwd_sa (tile)");
+  }
   const int ppb = 4 * (64 / p.LPP);
   int nb = (int)grid_for(p.HW, ppb * 2, USSEG_REDUCE_MAX_BLOCKS / B > 0 ? USSEG_REDUCE_MAX_BLOCKS / B : 1);
   const int64_t grid = (int64_t)nb * B;
