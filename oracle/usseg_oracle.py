@@ -51,6 +51,11 @@ KERAS = dict(
     adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-7,  # tf.optimizers.Adam (A.6)
     clip_norm=1.0,             # VisionTransformer.py:244
     bn_training=False,         # as driven: BN runs in inference mode (A.4)
+    # Judgement call a TensorFlow-equipped check can flip (parity is unpinned): Keras >= 2.4
+    # backend.categorical_crossentropy, given a tensor that a Keras softmax produced (Decoder.py:121 -> VisionTransformer.py:205), finds its
+    # cached `_keras_logits` and calls softmax_cross_entropy_with_logits on THEM: no renormalisation, no 1e-7 clip.  False = the documented
+    # probability path (renormalise, clip), which the product implements; the two differ only on saturated pixels (p < 1e-7).
+    cce_cached_logits=False,
 )
 
 
@@ -439,7 +444,7 @@ def vision_transformer_forward(x: Tensor, P: Params, radix: int = 3, kpaths: int
     return decoder_cup(hidden, feats, P, (gh, gw), "decoder.", norm)                        # :222
 
 
-def cce_label_smoothing(y_true: Tensor, probs: Tensor) -> Tensor:
+def cce_label_smoothing(y_true: Tensor, probs: Tensor, logits: Optional[Tensor] = None) -> Tensor:
     """CategoricalCrossentropy(label_smoothing=0.1, reduction=NONE) on probabilities -> [B,H,W].
 
     VisionTransformer.py:205; Appendix A.6: y <- y*(1-ls) + ls/C; p <- p/sum p; clip; -sum y log p.
@@ -447,6 +452,9 @@ def cce_label_smoothing(y_true: Tensor, probs: Tensor) -> Tensor:
     ls = KERAS["cce_label_smoothing"]
     C = y_true.shape[-1]
     y = y_true * (1.0 - ls) + ls / C
+    if KERAS["cce_cached_logits"]:      # the `_keras_logits` reading: -sum y * log_softmax(logits), no clip
+        lp = torch.log_softmax(logits, dim=-1) if logits is not None else torch.log(probs)
+        return -(y * lp).sum(dim=-1)
     p = probs / probs.sum(dim=-1, keepdim=True)
     eps = KERAS["cce_clip"]
     p = torch.clamp(p, eps, 1.0 - eps)

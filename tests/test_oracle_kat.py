@@ -268,3 +268,25 @@ def test_ksac_as_written_is_a_dilated_conv_with_cumulative_rates():
     d[0, 4, 4, 0] = 1.0
     y = O.kernel_sharing_conv2d_literal(d, torch.ones(3, 3, 1, 1, dtype=torch.float64), dilations=(1, 2))[1][0, :, :, 0]
     assert y[1, 1] == 1 and y[4, 7] == 1 and y[2, 2] == 0 and y.sum() == 9
+
+
+def test_cce_cached_logits_switch():
+    """The two readings of CategoricalCrossentropy on a Keras-softmax output (KERAS["cce_cached_logits"]): identical on ordinary pixels, and
+    on a saturated pixel the probability path clips at 1e-7 (finite, -log(1e-7) per missing class) while the cached-logits path returns
+    -sum y * log_softmax(logits) unclipped.  The product implements the probability path (the switch is False)."""
+    assert O.KERAS["cce_cached_logits"] is False
+    z = torch.tensor([[0.3, -1.2, 2.0], [40.0, -40.0, -40.0]], dtype=D)
+    y = torch.tensor([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0]], dtype=D)
+    p = O.softmax_lastaxis(z)
+    clip = O.cce_label_smoothing(y, p)
+    O.KERAS["cce_cached_logits"] = True
+    try:
+        logit = O.cce_label_smoothing(y, p, logits=z)
+    finally:
+        O.KERAS["cce_cached_logits"] = False
+    assert abs(clip[0].item() - logit[0].item()) < 1e-12                      # ordinary pixel: the same number
+    ys = 0.9 * y[1] + 0.1 / 3
+    want_logit = -(ys * torch.log_softmax(z[1], -1)).sum().item()             # = 0.9333*80 + 0.0333*80 = 77.33
+    assert abs(logit[1].item() - want_logit) < 1e-9 and abs(want_logit - (ys[1] + ys[2]).item() * 80.0) < 1e-6
+    want_clip = -(ys[0] * math.log(1 - 1e-7) + (ys[1] + ys[2]) * math.log(1e-7)).item()     # 0.9667 * 16.118 = 15.58
+    assert abs(clip[1].item() - want_clip) < 1e-9
