@@ -424,6 +424,19 @@ def test_residual_S_stage_layer_by_layer(world, stage):
     norm_layer_check(net, rec, P, pre + "convtmp_scbn", st.convtmp_scbn, worst, "ln")
     sc = rec.act_after(rec.norm[pre + "convtmp_scbn"][1]).detach()
     conv_layer_check(net, rec, P, pre + "concats_2", st.concats_2, worst, residual=sc)
+    # ---- ONE backward-data GEMM for the grouped 1x1 and the shortcut 1x1 (both read the stage input, ResNest.py:99,139): K = [Up | Oc]
+    if getattr(st, "wcat_d", None) is not None:
+        xl2, = fresh(x)
+        lw = [fresh(P[c + "conv1.kernel"], P[c + "conv1.bias"]) for c in cards]
+        wsc, bsc = fresh(P[pre + "convtmp_sc.kernel"], P[pre + "convtmp_sc.bias"])
+        outs = [O.conv2d_same(xl2, w_, b_) for w_, b_ in lw] + [O.conv2d_same(xl2, wsc, bsc)]
+        dys2 = [g_of(rec.conv[c + "conv1"][1]) for c in cards] + [g_of(rec.conv[pre + "convtmp_sc"][1])]
+        gx_both, = torch.autograd.grad(outs, [xl2], dys2)
+        dcat = ops.new_act(B, H, W, grp.Up + st.convtmp_sc.cout_p, DEV, zero=True)
+        dcat[..., :grp.Up] = cat_pad(dys2[:3], grp.Up)
+        dcat[..., grp.Up:] = dev(dys2[3])
+        dxm = ops.conv2d_dgrad(dcat, st.wcat_d, 1, 1, ops.new_act(B, H, W, grp.cin_p, DEV))
+        check("merged 1x1 backward-data (cardinal group + shortcut)", dxm[..., :grp.cin], bf(gx_both), worst=worst)
     # ---- the fused launch (csrc/cardinal.hip): grouped 1x1 -> LN -> LeakyReLU -> grouped 3x3 -> LN -> LeakyReLU (+ pooled rows) and the
     # shortcut 1x1 -> LN -> LeakyReLU from ONE read of the stage input.  Its only input is x, so the later tensors are compared with the
     # oracle's own chain (same bf16 storage points): a value that lands on the other side of a rounding boundary moves the tensors behind it.

@@ -38,6 +38,7 @@ _STAGE_LAZY = os.environ.get("USSEG_ENC_LAZY", "0") != "0"
 _FOLD_BN = os.environ.get("USSEG_FOLD_BN", "1") != "0"
 # the cardinal group + shortcut of a stage as ONE launch (csrc/cardinal.hip); 0 = the six unfused launches (the cross-check of the tests)
 _FUSED_CARDINAL = os.environ.get("USSEG_FUSED_CARDINAL", "1") != "0"
+_MERGED_DGRAD = os.environ.get("USSEG_MERGED_DGRAD", "1") != "0"     # one backward-data GEMM for a stage's grouped 1x1 and shortcut 1x1
 
 
 def _span(t: torch.Tensor, n: int) -> torch.Tensor:
@@ -268,7 +269,9 @@ class _CardinalGroup:
         self._saved = (x, u_raw, u, v_raw, y, g, s, ws)
         return out
 
-    def backward(self, dout, dx_residual=None):
+    def backward(self, dout, dx_residual=None, du_raw_out=None):
+        """``du_raw_out``: write the gradient w.r.t. the grouped 1x1 conv's output there (a channel slice of the stage's [du_raw | dsc_raw]
+        buffer) and leave the 1x1 backward-data pass to the caller (one GEMM for the cardinal group AND the shortcut: residual_S.backward)."""
         x, u_raw, u, v_raw, y, g, s, ws = self._saved
         B, H, W, _, _ = ops.geom(x)
         dev = x.device
@@ -283,9 +286,11 @@ class _CardinalGroup:
         # grouped 3x3: the dense [T][Up][Vp] gradient is never materialised - only the diagonal blocks are scattered
         ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(u, dv, self.k, self.dil, self._maps()[1]), u, dv)
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, self.dil, torch.empty_like(u))
-        du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, torch.empty_like(u_raw), self.dg1, self.dbe1, self.nmode, self.ngroups,
-                                  KERAS_LN_EPS, ACT_LRELU, a, *self.st1, dbias=self.db1)
+        du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, du_raw_out if du_raw_out is not None else torch.empty_like(u_raw),
+                                  self.dg1, self.dbe1, self.nmode, self.ngroups, KERAS_LN_EPS, ACT_LRELU, a, *self.st1, dbias=self.db1)
         ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(x, du_raw, 1, 1, self._maps()[0]), x, du_raw)
+        if du_raw_out is not None:
+            return None
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
 
 
@@ -309,13 +314,25 @@ class residual_S(nn.Module):
         return self._group.adjacent_params()
 
     def on_finalize(self, device):
-        self._group.on_finalize(device)
+        g, sc = self._group, self.convtmp_sc
+        # backward-data operand of [grouped 1x1 | shortcut 1x1] as ONE GEMM: rows = input channel, K = [Up | Oc] (ResNest.py:99,139 read the same x)
+        self.wcat_d = torch.zeros((roundup(g.cin_p, 16), g.Up + sc.cout_p), dtype=BF16, device=device) if _MERGED_DGRAD and sc.k == 1 else None
+        g.on_finalize(device)
 
     def repack(self):
-        self._group.repack()
+        jobs = self.pack_jobs()
+        ops.pack_weights_batched(ops.make_pack_table(jobs, self._group.w1_f.device), len(jobs))
 
     def pack_jobs(self):
-        return self._group.pack_jobs()
+        g, sc = self._group, self.convtmp_sc
+        jobs = g.pack_jobs()
+        if self.wcat_d is not None:
+            Kc = g.Up + sc.cout_p
+            for p, c in enumerate(g.cards):
+                jobs.append(ops.pack_job(c.conv1.kernel.data, 0, g.cv11, 1, 1, g.cin, g.cv11, self.wcat_d, Kc, Kc, 0, p * g.cv11))
+            sT, sI, sO = sc._strides_tio()
+            jobs.append(ops.pack_job(sc.kernel.data, sT, sI, sO, 1, sc.cin, sc.cout, self.wcat_d, Kc, Kc, 0, g.Up))
+        return jobs
 
     def forward(self, x, out=None):
         if self._group.fused_ok(self.convtmp_sc):
@@ -329,6 +346,16 @@ class residual_S(nn.Module):
     def backward(self, dout, need_dx=True, bias_done=False):
         """``bias_done``: concats_2's bias gradient (the column sums of dout) was already produced by the kernel that made dout."""
         d_c1 = self.concats_2.backward(dout, skip_bias=bias_done)
+        if self.wcat_d is not None and need_dx:
+            # the gradients w.r.t. both 1x1 outputs land in one buffer and ONE backward-data GEMM with K = Up + Oc gives dx (:99 + :139 read the same x)
+            g, sc = self._group, self.convtmp_sc
+            x = sc._x
+            B, H, W, _, _ = ops.geom(x)
+            dcat = ops.new_act(B, H, W, g.Up + sc.cout_p, x.device)
+            dsc_raw = self.convtmp_scbn.backward(dout, dx=dcat[..., g.Up:], dbias=sc.bias.grad)
+            ops.wgrad_later(lambda: sc._wgrad(x, dsc_raw), x, dsc_raw)
+            g.backward(d_c1, du_raw_out=dcat[..., :g.Up])
+            return ops.conv2d_dgrad(dcat, self.wcat_d, 1, 1, ops.new_act(B, H, W, g.cin_p, x.device))
         dsc_raw = self.convtmp_scbn.backward(dout, dbias=self.convtmp_sc.bias.grad)
         dx_a = self._group.backward(d_c1)
         return self.convtmp_sc.backward(dsc_raw, need_dx=need_dx, dx_residual=dx_a, skip_bias=True)
