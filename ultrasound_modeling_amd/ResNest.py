@@ -318,6 +318,7 @@ class residual_S(nn.Module):
         # backward-data operand of [grouped 1x1 | shortcut 1x1] as ONE GEMM: rows = input channel, K = [Up | Oc] (ResNest.py:99,139 read the same x)
         self.wcat_d = torch.zeros((roundup(g.cin_p, 16), g.Up + sc.cout_p), dtype=BF16, device=device) if _MERGED_DGRAD and sc.k == 1 else None
         g.on_finalize(device)
+        self.repack()          # (the group packs its own operands; this adds the merged one - a freshly built model must not step on zeros)
 
     def repack(self):
         jobs = self.pack_jobs()
