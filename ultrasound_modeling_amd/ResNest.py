@@ -288,9 +288,9 @@ class _CardinalGroup:
         du = ops.conv2d_dgrad(dv, self.w2_d, self.k, self.dil, torch.empty_like(u))
         du_raw = ops.norm_act_bwd(u_raw, du, self.U, self.g1, self.be1, du_raw_out if du_raw_out is not None else torch.empty_like(u_raw),
                                   self.dg1, self.dbe1, self.nmode, self.ngroups, KERAS_LN_EPS, ACT_LRELU, a, *self.st1, dbias=self.db1)
-        ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(x, du_raw, 1, 1, self._maps()[0]), x, du_raw)
-        if du_raw_out is not None:
+        if du_raw_out is not None:      # the caller runs ONE weight gradient and ONE backward-data pass for [grouped 1x1 | shortcut 1x1]
             return None
+        ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(x, du_raw, 1, 1, self._maps()[0]), x, du_raw)
         return ops.conv2d_dgrad(du_raw, self.w1_d, 1, 1, ops.new_act(B, H, W, self.cin_p, dev), dx_residual)
 
 
@@ -316,7 +316,8 @@ class residual_S(nn.Module):
     def on_finalize(self, device):
         g, sc = self._group, self.convtmp_sc
         # backward-data operand of [grouped 1x1 | shortcut 1x1] as ONE GEMM: rows = input channel, K = [Up | Oc] (ResNest.py:99,139 read the same x)
-        self.wcat_d = torch.zeros((roundup(g.cin_p, 16), g.Up + sc.cout_p), dtype=BF16, device=device) if _MERGED_DGRAD and sc.k == 1 else None
+        self.wcat_d = (torch.zeros((roundup(g.cin_p, 16), g.Up + sc.cout_p), dtype=BF16, device=device)
+                       if _MERGED_DGRAD and sc.k == 1 and g.P <= 3 else None)        # (a mapped weight gradient scatters into at most four variables)
         g.on_finalize(device)
         self.repack()          # (the group packs its own operands; this adds the merged one - a freshly built model must not step on zeros)
 
@@ -353,13 +354,24 @@ class residual_S(nn.Module):
             x = sc._x
             B, H, W, _, _ = ops.geom(x)
             dcat = ops.new_act(B, H, W, g.Up + sc.cout_p, x.device)
-            dsc_raw = self.convtmp_scbn.backward(dout, dx=dcat[..., g.Up:], dbias=sc.bias.grad)
-            ops.wgrad_later(lambda: sc._wgrad(x, dsc_raw), x, dsc_raw)
+            self.convtmp_scbn.backward(dout, dx=dcat[..., g.Up:], dbias=sc.bias.grad)
             g.backward(d_c1, du_raw_out=dcat[..., :g.Up])
+            # x^T . [du_raw | dsc_raw]: the weight gradients of the paths' 1x1 convs and of the shortcut conv in one launch (four mapped blocks)
+            ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(x, dcat, 1, 1, self._wcat_map()), x, dcat)
             return ops.conv2d_dgrad(dcat, self.wcat_d, 1, 1, ops.new_act(B, H, W, g.cin_p, x.device))
         dsc_raw = self.convtmp_scbn.backward(dout, dbias=self.convtmp_sc.bias.grad)
         dx_a = self._group.backward(d_c1)
         return self.convtmp_sc.backward(dsc_raw, need_dx=need_dx, dx_residual=dx_a, skip_bias=True)
+
+    def _wcat_map(self):
+        """Destination map of the merged 1x1 weight gradient [Cin][Up + Oc]: one block per cardinal path + the shortcut conv (Keras [1,1,in,out])."""
+        g, sc = self._group, self.convtmp_sc
+        key = sc.kernel.grad.data_ptr()
+        if getattr(self, "_wcat_key", None) != key:
+            blocks = [(c.conv1.kernel.grad, 0, g.cv11, 1, 0, p * g.cv11, g.cin, g.cv11) for p, c in enumerate(g.cards)]
+            blocks.append((sc.kernel.grad, 0, sc.cout, 1, 0, g.Up, sc.cin, sc.cout))
+            self._wcat_m, self._wcat_key = ops.wgrad_dst(blocks), key
+        return self._wcat_m
 
     def __call__(self, x, *args, **kwargs):
         return self.forward(x)
