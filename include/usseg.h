@@ -395,6 +395,11 @@ int64_t usseg_splitattn_mlp_bwd_ws_floats(const UssegSplitAttnDesc* d);
 int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float* g, int32_t g_rows, int32_t g_stride,
                             const UssegSplitAttnParams* p, const float* s, const float* ws, const float* ds, float* dg,
                             const UssegSplitAttnGrads* grads, float* grad_ws, usseg_stream_t stream);
+/* usseg_splitattn_apply_bwd_reduce + usseg_splitattn_mlp_bwd as one call with no finishing launch between them: the MLP kernel adds the
+ * reduce kernel's per-workgroup rows (in `reduce_ws`, usseg_reduce_ws_floats()) itself.  Outputs: dg [B][P*R*Cg] and the parameter gradients. */
+int usseg_splitattn_bwd_fused(const UssegSplitAttnDesc* d, const void* y, const void* dout, int32_t lddo, const float* g, int32_t g_rows,
+                              int32_t g_stride, const UssegSplitAttnParams* p, const float* s, const float* ws, float* dg,
+                              const UssegSplitAttnGrads* grads, float* reduce_ws, float* grad_ws, usseg_stream_t stream);
 int usseg_splitattn_apply_bwd_dy(const UssegSplitAttnDesc* d, const void* dout, int32_t lddo, const float* s,
                                  const float* dg, void* dy, int32_t lddy, usseg_stream_t stream);
 

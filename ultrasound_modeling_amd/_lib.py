@@ -154,6 +154,8 @@ _PROTOS = {
     "usseg_splitattn_apply_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp, c_vp]),
     "usseg_splitattn_apply_bwd_reduce": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "usseg_splitattn_mlp_bwd_ws_floats": (c_i64, [P(SplitAttnDesc)]),
+    "usseg_splitattn_bwd_fused": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, P(SplitAttnParams), c_vp, c_vp, c_vp,
+                                            P(SplitAttnGrads), c_vp, c_vp, c_vp]),
     "usseg_splitattn_mlp_bwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_i32, P(SplitAttnParams), c_vp, c_vp, c_vp, c_vp,
                                           P(SplitAttnGrads), c_vp, c_vp]),
     "usseg_splitattn_apply_bwd_dy": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),

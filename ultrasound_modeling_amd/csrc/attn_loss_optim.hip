@@ -136,6 +136,8 @@ struct SaMlp {
   int32_t g_rows, g_stride;   // g = [B][g_rows][g_stride] partial rows of the pooled sums (1 row of Cy floats: already summed)
   float* gws;      // backward: per-(path, image) rows of parameter-gradient partials [w1 | b1 | gamma | beta | w2 | b2] (no atomics)
   int32_t Ctot;
+  // backward, fused entry: ds arrives as the reduce kernel's partial rows [B][ds_nb][ds_cp] (summed here in row order: no finishing launch)
+  const float* ds_rows; int32_t ds_nb, ds_cp; float ds_mult;
 };
 
 extern "C" int64_t usseg_splitattn_ws_floats(const UssegSplitAttnDesc* d) {
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(SA_THR) void sa_mlp_kernel(const SaMlp a) {
   const int tid = threadIdx.x;
   const int Cg = d.Cg, Hd = d.Hd, R = d.R;
   __shared__ float gin[128], h1[64], xh[64], av[64], red[4], dz[4 * 128], da[64], dh[64], part[8 * 128];
+  __shared__ float dsl[BWD ? 4 * 128 : 1];
   const int Cy = d.P * R * Cg;
   float* wsb = a.ws + (int64_t)(b * d.P + p) * (Cg + 2 * Hd);
   const float* w1 = a.p.w1 + (int64_t)p * Cg * Hd;
@@ -269,10 +272,20 @@ __global__ __launch_bounds__(SA_THR) void sa_mlp_kernel(const SaMlp a) {
       __syncthreads();
     }
   } else {
+    if (a.ds_rows) {      // ds[b][cy] = mult * sum over the reduce kernel's partial rows, in row order
+      for (int i = tid; i < R * Cg; i += SA_THR) {
+        const int r = i / Cg, c = i - r * Cg;
+        const float* src = a.ds_rows + (int64_t)b * a.ds_nb * a.ds_cp + (p * R + r) * Cg + c;
+        float t = 0.f;
+        for (int j = 0; j < a.ds_nb; ++j) t += src[(int64_t)j * a.ds_cp];
+        dsl[r * 128 + c] = a.ds_mult * t;
+      }
+      __syncthreads();
+    }
     // softmax / sigmoid backward -> dz[r][c]
     for (int r = 0; r < R; ++r) {
       const float* sv = a.s + ((int64_t)(b * d.P + p) * R + r) * Cg;
-      const float* dsv = a.ds + (int64_t)b * Cy + (p * R + r) * Cg;
+      const float* dsv = a.ds_rows ? dsl + r * 128 : a.ds + (int64_t)b * Cy + (p * R + r) * Cg;
       if (tid < 64) {
         float t0 = (!d.use_sigmoid && tid < Cg) ? dsv[tid] * sv[tid] : 0.f;
         float t1 = (!d.use_sigmoid && tid + 64 < Cg) ? dsv[tid + 64] * sv[tid + 64] : 0.f;
@@ -386,6 +399,45 @@ extern "C" int usseg_splitattn_mlp_bwd(const UssegSplitAttnDesc* d, const float*
     off += sizes[i];
   }
   return usseg_check_launch("splitattn_mlp_bwd");
+}
+
+// usseg_splitattn_apply_bwd_reduce + usseg_splitattn_mlp_bwd without the finishing launch between them: the MLP kernel sums the reduce
+// kernel's partial rows itself (ResNest.py:194-197 backward into :186-192)
+extern "C" int usseg_splitattn_bwd_fused(const UssegSplitAttnDesc* d, const void* y, const void* dout, int32_t lddo, const float* g, int32_t g_rows,
+                                         int32_t g_stride, const UssegSplitAttnParams* p, const float* s, const float* ws, float* dg,
+                                         const UssegSplitAttnGrads* grads, float* reduce_ws, float* grad_ws, usseg_stream_t stream) {
+  const float* ds = reduce_ws;
+  int rc = sa_check(d);
+  if (rc) return rc;
+  USSEG_CHECK_ARG(g && p && s && ds && dg && grads && grad_ws && y && dout && lddo % 8 == 0, "null pointer");
+  const int Cy = d->P * d->R * d->Cg;
+  const int LPPr = lanes_per_pixel(roundup(Cy, 8) / 8);
+  int gx = (int)cdiv64(d->HW, (int64_t)(4 * (64 / LPPr)) * 8);
+  int gmax = USSEG_REDUCE_MAX_BLOCKS / d->B;
+  if (gmax > 64) gmax = 64;
+  if (gmax < 1) gmax = 1;
+  if (gx > gmax) gx = gmax;
+  hipLaunchKernelGGL(sa_reduce_kernel, dim3(gx, d->B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)dout, d->HW, Cy,
+                     d->ldy, lddo, d->R, d->Cg, LPPr, reduce_ws);
+  USSEG_CHECK_ARG(g_rows >= 1 && g_stride >= d->P * d->R * d->Cg, "splitattn_mlp: bad pooled-row layout");
+  USSEG_CHECK_ARG(grads->w1 && grads->b1 && grads->gamma && grads->beta && grads->w2 && grads->b2, "null grad pointer");
+  SaMlp a = {};
+  a.d = *d; a.p = *p; a.gr = *grads; a.g = g; a.s = const_cast<float*>(s); a.ws = const_cast<float*>(ws); a.ds = nullptr; a.dg = dg;
+  a.ds_rows = reduce_ws; a.ds_nb = gx; a.ds_cp = roundup(Cy, 8); a.ds_mult = d->mult;
+  a.g_rows = g_rows; a.g_stride = g_stride;
+  const int Cg = d->Cg, Hd = d->Hd, R = d->R;
+  a.Ctot = Cg * Hd + 3 * Hd + R * Hd * Cg + R * Cg;
+  a.gws = usseg_defer_reduce_ws((hipStream_t)stream, grad_ws, (int64_t)d->B * d->P * a.Ctot);   // a private region while finishes are deferred
+  hipLaunchKernelGGL(sa_mlp_kernel<true>, dim3(d->B * d->P), dim3(SA_THR), 0, (hipStream_t)stream, a);
+  // per parameter: rows (path, image) of Ctot floats -> the path's variable (per-path variables are adjacent: [P][numel])
+  const int sizes[6] = {Cg * Hd, Hd, Hd, Hd, R * Hd * Cg, R * Cg};
+  float* dst[6] = {grads->w1, grads->b1, grads->gamma, grads->beta, grads->w2, grads->b2};
+  int off = 0;
+  for (int i = 0; i < 6; ++i) {
+    usseg_launch_reduce_finish(a.gws + off, d->P, d->B, 1, a.Ctot, sizes[i], 1.f, dst[i], nullptr, nullptr, (hipStream_t)stream);
+    off += sizes[i];
+  }
+  return usseg_check_launch("splitattn_bwd_fused");
 }
 
 // out[b,hw,p*Cg+c] = mult * sum_r y[b,hw,(p*R+r)*Cg+c] * s[b][p][r][c]   (ResNest.py:194-197)

@@ -789,19 +789,18 @@ def splitattn_bwd(d: SplitAttnDesc, y, dout, params, grads, g, s, ws, dy):
     ``norm_act_bwd_sa`` (R == 1 only) and (s, dg) are returned for it."""
     dev = y.device
     Cy = d.P * d.R * d.Cg
-    ds = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)     # overwritten by usseg_splitattn_apply_bwd_reduce
     dg = torch.empty((d.B, Cy), dtype=torch.float32, device=dev)
     lib = L.load()
     lddo = geom(dout)[4]
     if not isinstance(g, tuple):
         g = (g, 1, Cy)
-    L.check(lib.usseg_splitattn_apply_bwd_reduce(C.byref(d), y.data_ptr(), dout.data_ptr(), lddo, ds.data_ptr(),
-                                                 reduce_ws(dev).data_ptr(), _stream()), "splitattn_apply_bwd_reduce")
     sp = _sa_params(*params)
     sg = SplitAttnGrads(*[_ptr(t) for t in grads])
     gws = torch.empty(int(lib.usseg_splitattn_mlp_bwd_ws_floats(C.byref(d))), dtype=torch.float32, device=dev)
-    L.check(lib.usseg_splitattn_mlp_bwd(C.byref(d), g[0].data_ptr(), g[1], g[2], C.byref(sp), s.data_ptr(), ws.data_ptr(), ds.data_ptr(),
-                                        dg.data_ptr(), C.byref(sg), gws.data_ptr(), _stream()), "splitattn_mlp_bwd")
+    # sum_pixels dout*y per (image, channel) as per-workgroup rows, summed by the MLP kernel itself (no finishing launch between the two)
+    L.check(lib.usseg_splitattn_bwd_fused(C.byref(d), y.data_ptr(), dout.data_ptr(), lddo, g[0].data_ptr(), g[1], g[2], C.byref(sp), s.data_ptr(),
+                                          ws.data_ptr(), dg.data_ptr(), C.byref(sg), reduce_ws(dev).data_ptr(), gws.data_ptr(), _stream()),
+            "splitattn_bwd_fused")
     if dy is None:
         assert d.R == 1, "the fused re-weighting backward needs identical radix branches (R == 1)"
         return s, dg
