@@ -397,7 +397,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   const int ntn = (Nb + bn - 1) / bn;
   const int tiles = tm * ntn;
   const int ngroups = P.job[0].ngroups;
-  // split-K over pixel chunks: aim for ~512 workgroups (over all jobs) with >= 2 chunks each.  With a workspace every
+  // split-K over pixel chunks: aim for ~256 workgroups (over all jobs; 512 until round 3) with >= 2 chunks each.  With a workspace every
   // split writes its own partial slab (plain stores) and the finishing kernel sums them; fp32 atomics into a 9*64*64 tile
   // from hundreds of workgroups run at the ~1.3 TB/s atomic rate and cost more than the MFMAs (no-workspace fallback only).
   const int64_t slab = (int64_t)9 * Ma * Nb;
@@ -406,7 +406,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   // register prefetch in place: 2x is the minimum, 4.95 vs 5.05 ms/step at 8x; sending the deep layers back to the
   // per-tap kernel was slower).
   const int64_t in_bytes = (int64_t)gm[0].B * gm[0].H * gm[0].W * (Ma + Nb) * 2, slab_bytes = slab * 4;
-  static const int wg_target = getenv("USSEG_WG_TARGET") ? atoi(getenv("USSEG_WG_TARGET")) : 512;
+  static const int wg_target = getenv("USSEG_WG_TARGET") ? atoi(getenv("USSEG_WG_TARGET")) : 256;   // round 3 sweep (128 / 192 / 256 / 384 / 512 / 768): 256 is -25 us on Arch B (half the slabs for wgrad_finish), neutral on A / T
   int splits = (wg_target + tiles * njobs - 1) / (tiles * njobs);
   int max_splits = (ngroups + 1) / 2;
   static const int slab_cap = getenv("USSEG_SLAB_CAP") ? atoi(getenv("USSEG_SLAB_CAP")) : 2;
