@@ -15,7 +15,7 @@ import sys
 rows = collections.defaultdict(lambda: collections.Counter())
 n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     rows[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
         n[k] += 1

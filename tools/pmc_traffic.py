@@ -11,7 +11,7 @@ def load(path, counter):
     for r in csv.DictReader(open(path)):
         if r.get("Counter_Name") != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         tot[k] += float(r["Counter_Value"]); n[k] += 1
     return tot, n
 
@@ -20,7 +20,7 @@ write, nw = load(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3])
 arch = sys.argv[5] if len(sys.argv) > 5 else "B"
 batch = int(sys.argv[6]) if len(sys.argv) > 6 else {"B": 16, "A": 32, "T": 8, "S": 16}[arch]
-fam = lambda k: k.startswith("igemm") or k.startswith("conv_halo") or k.startswith("conv_big") or k.startswith("conv_stream")
+fam = lambda k: k.startswith(("igemm", "conv_halo", "conv_big", "conv_stream", "cardinal_fwd"))
 out = {"arch": arch, "per_gpu_batch": batch, "hw": 256, "steps_profiled": steps, "kernels": {}}
 cb = cl = 0.0
 for k in sorted(set(fetch) | set(write)):

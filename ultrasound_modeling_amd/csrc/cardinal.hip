@@ -527,7 +527,9 @@ int launch_fwd(const CardFwd& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)cardinal_fwd_kernel<CIN, CV11, CVKK, OC>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_B);
     attr_done = true;
   }
+  const int slot = usseg_prof_start(1, s);       // counted with the conv family (it replaces three of its launches per stage)
   hipLaunchKernelGGL((cardinal_fwd_kernel<CIN, CV11, CVKK, OC>), dim3(p.ntiles, p.B, 2), dim3(256), Cfg::LDS_B, s, p);
+  usseg_prof_stop(1, slot, s);
   return usseg_check_launch("cardinal_fwd");
 }
 
