@@ -190,6 +190,27 @@ def layer_probe(dev):
         out.append({"layer": name, "us": round(us, 2), "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4),
                     "ai_flop_per_byte": round(flops / byts, 1), "roofline_tflops": round(roof, 1), "frac_of_roofline": round(tf / roof, 4),
                     "gb_per_s": round(byts / us / 1e3, 1)})
+    # the whole stem chain (ResNest.py:39-47: conv1 + act -> convtmp_1 + BN + act -> convtmp_2 -> BN + act -> pool) as ONE launch, B=32: the
+    # fused context of north_star's "3x3 conv fwd at 256x256 bs=32".  Bytes = what a training step must move: x in (8 physical channels), the
+    # three tensors the backward pass needs (y1, t1, pre-norm convtmp_2 output) and the pooled output out - no intermediate is re-read.
+    B, HW = 32, 256
+    c1, c2, c3 = Conv2D(8, 16, 3), Conv2D(16, 32, 3), Conv2D(32, 32, 3)
+    mods = torch.nn.ModuleList([c1, c2, c3])
+    FlatParams(mods, dev)
+    x = torch.randn(B, HW, HW, 8, device=dev).to(torch.bfloat16)
+    v32 = lambda f: torch.full((32,), f, device=dev)
+    args = (x, c1.wp_f, c1.bias.data, c2.wp_f, v32(0.0), c3.wp_f, c3.bias.data, v32(1.0), v32(0.0), v32(0.0), v32(1.0), 1e-3, 0.3)
+    for _ in range(3):
+        ops.stem_fwd(*args)
+    us = _time_us(lambda: ops.stem_fwd(*args), n=10)
+    M = B * HW * HW
+    flops = 2.0 * M * 9 * (1 * 16 + 16 * 32 + 32 * 32)
+    byts = 2.0 * M * (8 + 16 + 32 + 32 + 32 / 4)
+    tf = flops / us / 1e6
+    roof = min(PEAK_BF16_TFLOPS, flops / byts * 8.0)
+    out.append({"layer": "stem chain fwd (conv1 -> convtmp_1 + BN -> convtmp_2 -> BN + pool, all activations) @256x256 B=32, ONE launch, training outputs written",
+                "us": round(us, 2), "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4), "ai_flop_per_byte": round(flops / byts, 1),
+                "roofline_tflops": round(roof, 1), "frac_of_roofline": round(tf / roof, 4), "gb_per_s": round(byts / us / 1e3, 1)})
     # the decoder's three dilated 3x3 512->64 branches at 32x32 (Decoder.py:14-25) as ONE multi-job launch, B=32
     B, HW, ci, co = 32, 32, 512, 64
     convs = torch.nn.ModuleList([Conv2D(ci, co, 3, d) for d in (2, 4, 8)])

@@ -265,6 +265,15 @@ int usseg_norm_act_fwd_gap(const UssegNormDesc* d, const void* x, const float* g
 int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, const void* dout, const float* gamma, const float* beta,
                           const float* mean, const float* var, int32_t B, const float* sa_s, const float* sa_dg, float sa_mult,
                           void* dx, float* dgamma, float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
+/* The encoder stem as ONE launch (ResNest.py:39-47): Conv2D(1->16) + LeakyReLU -> Conv2D(16->32) + inference BatchNormalization (its scale
+ * folded into the packed operand w2, its shift = b2) + LeakyReLU -> Conv2D(32->32) -> BatchNormalization + LeakyReLU -> AveragePooling2D(2,2).
+ * x [B,H,W,8 physical channels]; w1 [16][72], w2 [32][144], w3 [32][288]: the packed forward operands of usseg_conv2d_fwd; b1 [16], b2 [32],
+ * b3 [32], gamma / beta / mean / var [32] fp32.  Outputs, all kept for the backward pass: y1 [B,H,W,16] and t1 [B,H,W,32] (activated),
+ * c2 [B,H,W,32] (pre-norm convtmp_2 output), pooled [B,H/2,W/2,32].  A workgroup owns a 16x16 tile and recomputes the two inner convs on
+ * its halo, so no intermediate is re-read from HBM; rounding points are those of the four unfused launches. */
+int usseg_stem_fwd(int32_t B, int32_t H, int32_t W, const void* x, int32_t ldx, const void* w1, const float* b1, const void* w2, const float* b2,
+                   const void* w3, const float* b3, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                   float alpha, void* y1, void* t1, void* c2, void* pooled, usseg_stream_t stream);
 /* One residual_S stage's cardinal group AND shortcut as ONE launch (SURVEY.md section 2.2 "K3"; ResNest.py:136-147 per path - the `kpaths`
  * paths share the input, :99-101 shortcut): replaces, in the implicit TensorFlow graph of the reference, Conv2D(1x1) -> LayerNormalization ->
  * LeakyReLU -> Conv2D(3x3) -> LayerNormalization -> LeakyReLU (+ the reduce_mean of :179) per path and Conv2D(1x1) -> LayerNormalization ->

@@ -309,6 +309,29 @@ def test_stem_and_pools(world):
         dy = g_of(y)
         dx = pool.backward(dev(dy))
         check(f"pool{i} bwd", dx, bf(torch.autograd.grad(ref, xl, dy)[0]), worst=worst)
+    # ---- the fused stem launch (csrc/stem.hip): conv1 + act -> convtmp_1 + folded BN + act -> convtmp_2 -> BN + act + pool from ONE read of x.
+    # Its only input is x, so the inner tensors are compared with the oracle's own chain (same bf16 storage points).
+    if enc.convtmp_1.fold_scale() is not None:
+        fw = []
+        x0 = rec.conv[ENC + "conv1"][0].detach()
+        bn1, bn2 = enc.convtmp_1bn, enc.convtmp_2bn
+        y1f, t1f, c2f, pf = ops.stem_fwd(dev(x0, 8), enc.conv1.wp_f, enc.conv1.bias.data, enc.convtmp_1.wp_f, bn1.fold_shift, enc.convtmp_2.wp_f,
+                                         enc.convtmp_2.bias.data, bn2.gamma.data, bn2.beta.data, bn2.moving_mean_p, bn2.moving_variance_p, bn2.eps, 0.3)
+        torch.cuda.synchronize()
+        check("fused stem: conv1 + act", y1f, rec.act_after(rec.conv[ENC + "conv1"][1]), worst=fw)
+        # convtmp_1 runs with the BatchNorm scale folded into its bf16 operand (one more operand rounding than the oracle's unfolded chain:
+        # the 5e-3 bar of the folded launch above), and convtmp_2 / the pool inherit its output
+        check("fused stem: convtmp_1 + bn + act", t1f, rec.act_after(rec.norm[ENC + "convtmp_1bn"][1]), 5 * TOL, worst=fw)
+        check("fused stem: convtmp_2 (pre-norm)", c2f, rec.conv[ENC + "convtmp_2"][1], 5 * TOL, worst=fw)
+        check("fused stem: bn + act + pool", pf, rec.pool[0][1], 5 * TOL, worst=fw)
+        # against the product's own four launches on the same input: the same arithmetic at the same rounding points
+        y1u = enc.conv1.forward(dev(x0, 8), act=ops.ACT_LRELU, alpha=0.3)
+        t1u = enc.convtmp_1.forward(y1u, act=ops.ACT_LRELU, alpha=0.3, bias=bn1.fold_shift)
+        c2u = enc.convtmp_2.forward(t1u)
+        pu = bn2.forward_pool(c2u, ops.ACT_LRELU, 0.3)
+        for nm, f_, u_ in (("y1", y1f, y1u), ("t1", t1f, t1u), ("c2", c2f, c2u), ("pooled", pf, pu)):
+            check(f"fused stem vs the four launches: {nm}", f_, u_, worst=fw)
+        print("fused stem:", [(f"{e:.2e}", n) for e, n in sorted(fw, reverse=True)[:8]])
     print("stem/pools worst:", sorted(worst, reverse=True)[:4])
 
 

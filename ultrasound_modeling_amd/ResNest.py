@@ -38,6 +38,7 @@ _STAGE_LAZY = os.environ.get("USSEG_ENC_LAZY", "0") != "0"
 _FOLD_BN = os.environ.get("USSEG_FOLD_BN", "1") != "0"
 # the cardinal group + shortcut of a stage as ONE launch (csrc/cardinal.hip); 0 = the six unfused launches (the cross-check of the tests)
 _FUSED_CARDINAL = os.environ.get("USSEG_FUSED_CARDINAL", "1") != "0"
+_FUSED_STEM = os.environ.get("USSEG_FUSED_STEM", "1") != "0"             # the stem (three convs, two norms, pool) as one launch (csrc/stem.hip)
 _MERGED_DGRAD = os.environ.get("USSEG_MERGED_DGRAD", "1") != "0"     # one backward-data GEMM for a stage's grouped 1x1 and shortcut 1x1
 
 
@@ -412,9 +413,19 @@ class ResNest(nn.Module):
         if x.dtype != BF16:
             x = ops.cast_input(x.contiguous(), roundup(self.channel, 8))
         a = KERAS_LRELU_ALPHA
-        self._y1 = self.conv1.forward(x, act=ACT_LRELU, alpha=a)                                  # :39-40
         bn1, bn2 = self.convtmp_1bn, self.convtmp_2bn
         self._fold = self.convtmp_1.fold_scale() is not None
+        if (_FUSED_STEM and self._fold and not bn2.training_mode and self.conv1.cin_p == 8 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+                and (self.conv1.cout, self.convtmp_1.cout, self.convtmp_2.cout) == (16, 32, 32)):
+            # :39-47 as ONE launch (csrc/stem.hip); leaves the state the four launches below leave, so the backward pass is the same code
+            self._y1, self._t1, c2, t = ops.stem_fwd(x, self.conv1.wp_f, self.conv1.bias.data, self.convtmp_1.wp_f, bn1.fold_shift,
+                                                     self.convtmp_2.wp_f, self.convtmp_2.bias.data, bn2.gamma.data, bn2.beta.data,
+                                                     bn2.moving_mean_p, bn2.moving_variance_p, bn2.eps, a)
+            self.conv1._x, self.convtmp_1._x, self.convtmp_2._x = x, self._y1, self._t1
+            bn2._x, bn2._act = c2, (ACT_LRELU, a)
+            self._pool_fused = True
+            return self._stages_forward(t, o1, o2, o3)
+        self._y1 = self.conv1.forward(x, act=ACT_LRELU, alpha=a)                                  # :39-40
         self._pool_fused = False
         if self._fold:   # :41-43: convtmp_1bn's scale sits in the packed operand, its shift is the bias, LeakyReLU in the epilogue
             self._t1 = t = self.convtmp_1.forward(self._y1, act=ACT_LRELU, alpha=a, bias=bn1.fold_shift)
@@ -427,6 +438,9 @@ class ResNest(nn.Module):
             t = self.convtmp_2bn.forward_pool(t, ACT_LRELU, a)
         else:
             t = self.conv1_pool.forward(self.convtmp_2bn.forward(t, ACT_LRELU, a))               # :45-47
+        return self._stages_forward(t, o1, o2, o3)
+
+    def _stages_forward(self, t, o1, o2, o3):
         x_1 = self.conv_1.forward(t, out=o1)                                                     # :48
         x_2 = self.conv_2.forward(self.conv2_pool.forward(x_1), out=o2)                          # :49-50
         x_3 = self.conv_3.forward(self.conv3_pool.forward(x_2), out=o3)                          # :51-52

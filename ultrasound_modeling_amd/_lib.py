@@ -146,6 +146,9 @@ _PROTOS = {
     "usseg_splitattn_mlp_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_i32, P(SplitAttnParams), c_vp, c_vp, c_vp]),
     "usseg_norm_act_fwd_gap": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     # fused cardinal group + shortcut of a residual_S stage (ResNest.py:99-101,136-147): the ten Keras layers of a stage's first half
+    # fused encoder stem (ResNest.py:39-47): three convs, two BatchNorms, the activations and the pool
+    "usseg_stem_fwd": (C.c_int, [c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32,
+                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_cardinal_supported": (c_i32, [P(CardinalDesc)]),
     "usseg_cardinal_fwd": (C.c_int, [P(CardinalDesc)] + [c_vp] * 21),
     "usseg_accuracy": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),

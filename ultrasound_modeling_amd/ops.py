@@ -724,6 +724,20 @@ def adam_advance(step_dev, lr_t_dev, lr, b1, b2):
     L.check(L.load().usseg_adam_advance(step_dev.data_ptr(), lr_t_dev.data_ptr(), lr, b1, b2, _stream()), "adam_advance")
 
 
+# ------------------------------------------------------------------------------------------------ fused stem
+def stem_fwd(x, w1, b1, w2, b2, w3, b3, gamma, beta, mean, var, eps, alpha):
+    """ResNest.py:39-47 in one launch -> (y1 [B,H,W,16], t1 [B,H,W,32], c2 [B,H,W,32] pre-norm, pooled [B,H/2,W/2,32])."""
+    B, H, W, Cin, ldx = geom(x)
+    assert Cin == 8 and x.dtype == BF16
+    dev = x.device
+    y1, t1, c2 = new_act(B, H, W, 16, dev), new_act(B, H, W, 32, dev), new_act(B, H, W, 32, dev)
+    pooled = new_act(B, H // 2, W // 2, 32, dev)
+    L.check(L.load().usseg_stem_fwd(B, H, W, x.data_ptr(), ldx, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+                                    b3.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, alpha,
+                                    y1.data_ptr(), t1.data_ptr(), c2.data_ptr(), pooled.data_ptr(), _stream()), "stem_fwd")
+    return y1, t1, c2, pooled
+
+
 # ------------------------------------------------------------------------------------------------ fused cardinal group (K3)
 def cardinal_desc(B, H, W, Cin, P, cv11, cvkk, Up, Vp, Oc, ldx, ldu, ldv, ldsc, eps, alpha) -> CardinalDesc:
     return CardinalDesc(B, H, W, Cin, P, cv11, cvkk, Up, Vp, Oc, ldx, ldu, ldv, ldsc, eps, alpha)
