@@ -442,6 +442,10 @@ def main():
         trainer.train_step(x, y)
     if use_graph:
         net.capture_graph(x, y)
+        gx, gy = net.graph_inputs()           # the synthetic batch lives in the captured step's own input buffers (inputs resident in HBM;
+        if gx.shape == x.shape and gx.dtype == x.dtype and gy.shape == y.shape and gy.dtype == y.dtype:
+            gx.copy_(x); gy.copy_(y)          # a real loader - ultrasound_modeling_amd/Dataset_2.py - writes each batch there)
+            x, y = gx, gy
         for _ in range(args.warmup):
             trainer.train_step(x, y)
 

@@ -115,10 +115,18 @@ class TrainStepDriver:
                 self._update_body()
         self._graph = (g1, g2)
 
+    def graph_inputs(self):
+        """The (x, y) buffers the captured step reads: write the next batch THERE and pass these tensors to ``train_step`` - no copy."""
+        return self._gx, self._gy
+
     def _graph_replay(self, x, y):
         """-> the STATIC probability buffer of the captured step (overwritten by the next replay)."""
-        self._gx.copy_(x)
-        self._gy.copy_(y)
+        # a producer that writes the batch straight into the captured step's input buffers (``graph_inputs()``: the device input
+        # pipeline, a data loader with pinned staging) skips these two copies
+        if x.data_ptr() != self._gx.data_ptr():
+            self._gx.copy_(x)
+        if y.data_ptr() != self._gy.data_ptr():
+            self._gy.copy_(y)
         g1, g2 = self._graph
         g1.replay()
         if self.grad_sync is not None:
