@@ -887,3 +887,77 @@ def test_accuracy_metric(gen, M, C):
     assert abs(a.item() - ref.item()) < 1e-6
     a2 = ops.accuracy(probs.to(DEV), y.to(DEV), acc)          # the accumulator is reusable without zeroing
     assert a2.item() == a.item()
+
+
+# ------------------------------------------------------------------------------------------------ fused tile kernels vs the launches they replace
+@pytest.mark.parametrize("cin,cv11,cvkk,oc", [(32, 3, 10, 64), (64, 7, 21, 128), (128, 14, 42, 256), (256, 28, 85, 512)])
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 8, 8), (3, 16, 5), (2, 4, 4), (1, 20, 36)])
+def test_fused_cardinal_forward_equals_the_unfused_launches(gen, cin, cv11, cvkk, oc, B, H, W):
+    """csrc/cardinal.hip on ragged geometries (the native 256x80 grid gives 64x20, 32x10, 16x5 stages; tiles are 8x8): every output of
+    the fused launch against the six launches it replaces (same packed operands, same rounding points), incl. pad channels and the
+    pooled partial rows."""
+    from ultrasound_modeling_amd import ops
+    P = 3
+    U, V = P * cv11, P * cvkk
+    Up, Vp = (U + 7) // 8 * 8, (V + 7) // 8 * 8
+    r16 = lambda n: (n + 15) // 16 * 16
+    bfz = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(torch.bfloat16)
+    x = bfz(B, H, W, cin).to(DEV)
+    w1 = torch.zeros(r16(Up), cin, dtype=torch.bfloat16)
+    w1[:U] = bfz(U, cin, sc=cin ** -0.5)
+    w2 = torch.zeros(r16(Vp), 9 * Up, dtype=torch.bfloat16)
+    for p_ in range(P):           # block diagonal: path p's outputs see only path p's inputs
+        blk = bfz(cvkk, 9, cv11, sc=(9 * cv11) ** -0.5)
+        for t in range(9):
+            w2[p_ * cvkk:(p_ + 1) * cvkk, t * Up + p_ * cv11:t * Up + (p_ + 1) * cv11] = blk[:, t]
+    wsc = bfz(oc, cin, sc=cin ** -0.5)
+    padv = lambda n, np_, sc, off=0.0: torch.cat([off + sc * torch.randn(n, generator=gen), torch.zeros(np_ - n)]).to(DEV)
+    b1, g1, be1 = padv(U, Up, 0.1), padv(U, Up, 0.2, 1.0), padv(U, Up, 0.1)
+    b2, g2, be2 = padv(V, Vp, 0.1), padv(V, Vp, 0.2, 1.0), padv(V, Vp, 0.1)
+    bsc, gsc, besc = padv(oc, oc, 0.1), padv(oc, oc, 0.2, 1.0), padv(oc, oc, 0.1)
+    w1, w2, wsc = w1.to(DEV), w2.to(DEV), wsc.to(DEV)
+    assert ops.cardinal_supported(cin, P, cv11, cvkk, Up, Vp, oc)
+    u_raw, u, v_raw, y, gap, sc_raw, sc = ops.cardinal_fwd(x, w1, b1, g1, be1, w2, b2, g2, be2, wsc, bsc, gsc, besc, P, cv11, cvkk, Up, Vp, oc, 1e-3, 0.3)
+    a = 0.3
+    u_raw_u = ops.conv2d_fwd(x, w1, b1, 1, 1, ops.new_act(B, H, W, Up, DEV))
+    u_u = ops.norm_act_fwd(u_raw_u, U, g1, be1, torch.empty_like(u_raw_u), 0, P, 1e-3, ops.ACT_LRELU, a)
+    v_raw_u = ops.conv2d_fwd(u_u, w2, b2, 3, 1, ops.new_act(B, H, W, Vp, DEV))
+    y_u = ops.norm_act_fwd(v_raw_u, V, g2, be2, torch.empty_like(v_raw_u), 0, P, 1e-3, ops.ACT_LRELU, a)
+    sc_raw_u = ops.conv2d_fwd(x, wsc, bsc, 1, 1, ops.new_act(B, H, W, oc, DEV))
+    sc_u = ops.norm_act_fwd(sc_raw_u, oc, gsc, besc, torch.empty_like(sc_raw_u), 0, 1, 1e-3, ops.ACT_LRELU, a)
+    torch.cuda.synchronize()
+    for nm, f_, u_ in (("u_raw", u_raw, u_raw_u), ("u", u, u_u), ("v_raw", v_raw, v_raw_u), ("y", y, y_u), ("sc_raw", sc_raw, sc_raw_u), ("sc", sc, sc_u)):
+        assert rel(f_, u_) < REL_BF16, (nm, rel(f_, u_))
+    for t, wlog in ((u_raw, U), (u, U), (v_raw, V), (y, V)):
+        assert t.shape[3] == wlog or t[..., wlog:].abs().max().item() == 0
+    pooled = gap[0].sum(dim=1)[:, :V] / (H * W)
+    assert rel(pooled, y[..., :V].float().mean(dim=(1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 16, 16), (2, 34, 18), (1, 64, 80), (3, 2, 6)])
+def test_fused_stem_is_bit_identical_to_its_four_launches(gen, B, H, W):
+    """csrc/stem.hip on ragged geometries (16x16 tiles, 3-pixel halo): y1, t1, the pre-norm convtmp_2 output and the pooled tensor are the
+    BITS of conv1 + act -> convtmp_1 (+ shift) + act -> convtmp_2 -> BatchNorm + act + pool."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import BatchNormalization, Conv2D
+    c1, c2, c3, bn = Conv2D(1, 16, 3), Conv2D(16, 32, 3), Conv2D(32, 32, 3), BatchNormalization(32)
+    finalize(torch.nn.ModuleList([c1, c2, c3, bn]))
+    f = lambda n, sc, off=0.0: (off + sc * torch.randn(n, generator=gen)).to(DEV)
+    for c in (c1, c2, c3):
+        c.bias.data.copy_(f(c.cout, 0.1))
+        c.repack()
+    bn.gamma.data.copy_(f(32, 0.2, 1.0)); bn.beta.data.copy_(f(32, 0.1))
+    bn.moving_mean_p.copy_(f(32, 0.3)); bn.moving_variance_p.copy_(0.5 + torch.rand(32, generator=gen).to(DEV))
+    shift = f(32, 0.1)
+    x = torch.zeros(B, H, W, 8, dtype=torch.bfloat16)
+    x[..., 0] = torch.randn(B, H, W, generator=gen).to(torch.bfloat16)
+    x = x.to(DEV)
+    y1, t1, cc, pooled = ops.stem_fwd(x, c1.wp_f, c1.bias.data, c2.wp_f, shift, c3.wp_f, c3.bias.data, bn.gamma.data, bn.beta.data,
+                                      bn.moving_mean_p, bn.moving_variance_p, bn.eps, 0.3)
+    y1u = c1.forward(x, act=ops.ACT_LRELU, alpha=0.3)
+    t1u = c2.forward(y1u, act=ops.ACT_LRELU, alpha=0.3, bias=shift)
+    ccu = c3.forward(t1u)
+    pu = bn.forward_pool(ccu, ops.ACT_LRELU, 0.3)
+    torch.cuda.synchronize()
+    for nm, f_, u_ in (("y1", y1, y1u), ("t1", t1, t1u), ("c2", cc, ccu), ("pooled", pooled, pu)):
+        assert torch.equal(f_, u_), (nm, rel(f_, u_))
