@@ -297,6 +297,24 @@ int usseg_cardinal_fwd(const UssegCardinalDesc* d, const void* x, const void* w1
                        const void* w2, const float* b2, const float* g2, const float* be2, const void* wsc, const float* bsc,
                        const float* gsc, const float* besc, void* u_raw, void* u, void* v_raw, void* y, float* gap_rows, void* sc_raw,
                        void* sc, usseg_stream_t stream);
+/* The backward pass of the same stage half as ONE launch (K3 backward; GradientTape through ResNest.py:136-147 and :100-101): replaces the
+ * split-attention re-weighting's backward + LayerNormalization/LeakyReLU backward of conv2_bn, the grouped 3x3's backward-data pass, the
+ * LayerNormalization/LeakyReLU backward of conv1_bn, and the shortcut norm's backward.
+ *   dout [B,H,W,Vp] (stride ldo): gradient w.r.t. the split-attention output (concats_1); sa_s / sa_dg [B][P*cvkk] fp32 from
+ *   usseg_splitattn_bwd_fused: the gradient w.r.t. y is sa_mult*sa_s[b][c]*dout + sa_dg[b][c], formed in registers;
+ *   dsc [B,H,W,Oc] (stride lddsc): gradient w.r.t. the activated shortcut; v_raw, u_raw, sc_raw: saved by usseg_cardinal_fwd;
+ *   w2d [roundup(Up,16)][9*Vp]: the packed backward-data operand of the grouped 3x3 (block diagonal, as usseg_conv2d_dgrad takes it);
+ *   outputs: dv [B,H,W,Vp] (stride d->ldv; gradient w.r.t. v_raw - the grouped 3x3's weight gradient reads it) and
+ *   dcat [B,H,W,ldc] = [du_raw (Up) | dsc_raw (Oc)]: the gradients w.r.t. both 1x1 outputs, the operand of ONE backward-data GEMM and ONE
+ *   weight-gradient launch (both 1x1 convs read the stage input);
+ *   dg2/dbe2/db2, dg1/dbe1/db1, dgsc/dbesc/dbsc: gamma / beta gradients of the three norms and the bias gradients of the convs in front of
+ *   them, ACCUMULATED (one partial row per workgroup + an ordered finishing reduction: bitwise reproducible);
+ *   ws: usseg_reduce_ws_floats() floats.  A workgroup owns an 8x8 tile and recomputes the first norm's backward on its one-pixel halo. */
+int usseg_cardinal_bwd(const UssegCardinalDesc* d, const void* dout, int32_t ldo, const void* dsc, int32_t lddsc, const void* v_raw,
+                       const void* u_raw, const void* sc_raw, const void* w2d, const float* g2, const float* be2, const float* g1,
+                       const float* be1, const float* gsc, const float* besc, const float* sa_s, const float* sa_dg, float sa_mult, void* dv,
+                       void* dcat, int32_t ldc, float* dg2, float* dbe2, float* db2, float* dg1, float* dbe1, float* db1, float* dgsc,
+                       float* dbesc, float* dbsc, float* ws, usseg_stream_t stream);
 /* Inference BatchNormalization + activation + AveragePooling2D(2,2) in one pass - the stem's convtmp_2bn -> LeakyReLU ->
  * conv1_pool (ResNest.py:45-47) and conv2_1_2bn -> ELU -> pool_1 (TBI_ResNest.py:90-92): the activated full-resolution tensor
  * feeds the pool only, so it is never written.  x [B,H,W,Cphys] pre-norm; y / dy [B,H/2,W/2,Cphys]; dx [B,H,W,Cphys] is the

@@ -487,6 +487,61 @@ def test_residual_S_stage_layer_by_layer(world, stage):
         for nm, f_, u_ in (("u_raw", u_raw_f, u_raw_u), ("u", u_f, u_u), ("v_raw", v_raw_f, v_raw_u), ("y", y_f, y_u)):
             check(f"fused vs unfused launches: {nm}", f_, u_, worst=fw)
         print(f"stage {stage} fused:", [(f"{e:.2e}", n) for e, n in sorted(fw, reverse=True)[:6]])
+    # ---- the fused BACKWARD launch (csrc/cardinal.hip, K3 backward): re-weighting + conv2_bn backward -> grouped 3x3 backward-data -> conv1_bn
+    # backward, and the shortcut norm's backward, on the oracle's saved tensors and incoming gradients.  dv sits directly behind the oracle's
+    # inputs; du_raw is behind two more bf16 storage points of the product's own chain (dv, du), so it gets the two-rounding bar, and every
+    # output is also compared with the product's unfused launches on the same inputs.
+    if grp.fused_ok(st.convtmp_sc) and getattr(st, "wcat_d", None) is not None:
+        bw = []
+        oc = st.convtmp_sc.cout
+        v_raw_o = cat_pad([rec.conv[c + "conv2"][1] for c in cards], grp.Vp)
+        u_raw_o = cat_pad([rec.conv[c + "conv1"][1] for c in cards], grp.Up)
+        sc_raw_o = dev(rec.conv[pre + "convtmp_sc"][1])
+        dout_d = cat_pad(douts, grp.Vp)
+        dsc_d = dev(g_of(rec.act_after(rec.norm[pre + "convtmp_scbn"][1])))
+        scn = st.convtmp_scbn
+
+        def run(fused):
+            net.flat.zero_grad()
+            sa_s, sa_dg = ops.splitattn_bwd(d, yd, dout_d, params, grp.mlp_g, g, s, ws, None)
+            dcat_ = ops.new_act(B, H, W, grp.Up + oc, DEV)
+            if fused:
+                dv_ = torch.empty_like(v_raw_o)
+                grads_ = (grp.dg2, grp.dbe2, grp.db2, grp.dg1, grp.dbe1, grp.db1, scn.gamma.grad, scn.beta.grad, st.convtmp_sc.bias.grad)
+                ops.cardinal_bwd(dout_d, dsc_d, v_raw_o, u_raw_o, sc_raw_o, grp.w2_d, grp.g2, grp.be2, grp.g1, grp.be1, scn.gamma.data, scn.beta.data,
+                                 sa_s, sa_dg, 3.0, dv_, dcat_, grads_, grp.cin_p, grp.P, grp.cv11, grp.cvkk, grp.Up, grp.Vp, oc, 1e-3, a)
+            else:
+                dv_ = ops.norm_act_bwd_sa(v_raw_o, dout_d, grp.V, grp.g2, grp.be2, torch.empty_like(v_raw_o), grp.dg2, grp.dbe2, 0, 3, 1e-3,
+                                          ops.ACT_LRELU, a, sa_s, sa_dg, 3.0, dbias=grp.db2)
+                du_ = ops.conv2d_dgrad(dv_, grp.w2_d, grp.k, grp.dil, torch.empty_like(u_raw_o))
+                ops.norm_act_bwd(u_raw_o, du_, grp.U, grp.g1, grp.be1, dcat_[..., :grp.Up], grp.dg1, grp.dbe1, 0, 3, 1e-3, ops.ACT_LRELU, a, dbias=grp.db1)
+                ops.norm_act_bwd(sc_raw_o, dsc_d, oc, scn.gamma.data, scn.beta.data, dcat_[..., grp.Up:], scn.gamma.grad, scn.beta.grad, 0, 1, 1e-3,
+                                 ops.ACT_LRELU, a, dbias=st.convtmp_sc.bias.grad)
+            torch.cuda.synchronize()
+            vecs = [t.detach().clone() for t in (grp.dg2, grp.dbe2, grp.db2, grp.dg1, grp.dbe1, grp.db1, scn.gamma.grad, scn.beta.grad,
+                                                 st.convtmp_sc.bias.grad)]
+            return dv_, dcat_, vecs
+        dv_f, dcat_f, vec_f = run(True)
+        dv_u, dcat_u, vec_u = run(False)
+        cat = lambda ts: torch.cat([t.detach() for t in ts], 3)
+        # dv: the oracle stores the re-weighting's backward (radix*s*dout + dg) in bf16 before the norm backward; both product paths form it in
+        # fp32 registers, so each is compared with the oracle at the bar the UNFUSED launch needs, and with each other at the plain bar below
+        want_dv = cat([g_of(rec.conv[c + "conv2"][1]) for c in cards])
+        e_u = rel(dv_u[..., :grp.V], want_dv)
+        check("fused bwd: dv (gradient at the grouped conv2 output)", dv_f[..., :grp.V], want_dv, max(2 * TOL, 1.1 * e_u), worst=bw)
+        assert e_u < 1e-2, f"unfused dv vs the oracle: {e_u:.2e}"
+        want_du = cat([g_of(rec.conv[c + "conv1"][1]) for c in cards])
+        e_u1 = rel(dcat_u[..., :grp.U], want_du)
+        check("fused bwd: du_raw (gradient at the grouped conv1 output)", dcat_f[..., :grp.U], want_du, max(2 * TOL, 1.1 * e_u1), worst=bw)
+        assert e_u1 < 1e-2, f"unfused du_raw vs the oracle: {e_u1:.2e}"      # (behind dv and du, LayerNorm backward amplifies)
+        check("fused bwd: dsc_raw (gradient at the shortcut conv output)", dcat_f[..., grp.Up:], g_of(rec.conv[pre + "convtmp_sc"][1]), worst=bw)
+        assert grp.Vp == grp.V or dv_f[..., grp.V:].abs().max().item() == 0, "fused bwd: pad channels"
+        assert grp.Up == grp.U or dcat_f[..., grp.U:grp.Up].abs().max().item() == 0, "fused bwd: pad channels"
+        check("fused bwd vs unfused launches: dv", dv_f, dv_u, worst=bw)
+        check("fused bwd vs unfused launches: dcat", dcat_f, dcat_u, worst=bw)
+        for nm, f_, u_ in zip(("dgamma2", "dbeta2", "dbias2", "dgamma1", "dbeta1", "dbias1", "dgamma_sc", "dbeta_sc", "dbias_sc"), vec_f, vec_u):
+            check(f"fused bwd vs unfused launches: {nm}", f_, u_, worst=bw)
+        print(f"stage {stage} fused bwd:", [(f"{e:.2e}", n) for e, n in sorted(bw, reverse=True)[:6]])
     print(f"stage {stage} worst:", [(f"{e:.2e}", n) for e, n in sorted(worst, reverse=True)[:5]])
 
 

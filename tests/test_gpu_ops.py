@@ -961,3 +961,58 @@ def test_fused_stem_is_bit_identical_to_its_four_launches(gen, B, H, W):
     torch.cuda.synchronize()
     for nm, f_, u_ in (("y1", y1, y1u), ("t1", t1, t1u), ("c2", cc, ccu), ("pooled", pooled, pu)):
         assert torch.equal(f_, u_), (nm, rel(f_, u_))
+
+
+@pytest.mark.parametrize("cin,cv11,cvkk,oc", [(32, 3, 10, 64), (64, 7, 21, 128), (128, 14, 42, 256), (256, 28, 85, 512)])
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 8, 8), (3, 16, 5), (2, 4, 4), (1, 20, 36)])
+def test_fused_cardinal_backward_equals_the_unfused_launches(gen, cin, cv11, cvkk, oc, B, H, W):
+    """csrc/cardinal.hip backward (K3) on ragged geometries: dv, du_raw, dsc_raw and the nine per-channel gradient vectors of the ONE fused
+    launch against the four launches it replaces (norm_act_bwd_sa -> conv2d_dgrad 3x3 -> norm_act_bwd | norm_act_bwd of the shortcut) on the
+    same inputs and packed operands; same rounding points (dv and du are bf16 where the unfused launches store them)."""
+    from ultrasound_modeling_amd import ops
+    P = 3
+    U, V = P * cv11, P * cvkk
+    Up, Vp = (U + 7) // 8 * 8, (V + 7) // 8 * 8
+    r16 = lambda n: (n + 15) // 16 * 16
+    bfz = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(torch.bfloat16)
+
+    def padded(n, npad, *lead, sc=1.0):
+        t = torch.zeros(*lead, npad, dtype=torch.bfloat16)
+        t[..., :n] = bfz(*lead, n, sc=sc)
+        return t.to(DEV)
+    v_raw, dout = padded(V, Vp, B, H, W), padded(V, Vp, B, H, W)
+    u_raw = padded(U, Up, B, H, W)
+    sc_raw, dsc = bfz(B, H, W, oc).to(DEV), bfz(B, H, W, oc).to(DEV)
+    w2d = torch.zeros(r16(Up), 9 * Vp, dtype=torch.bfloat16)
+    for p_ in range(P):           # block diagonal backward-data operand: rows = the path's inputs, K = (tap, the path's outputs)
+        blk = bfz(cv11, 9, cvkk, sc=(9 * cvkk) ** -0.5)
+        for t in range(9):
+            w2d[p_ * cv11:(p_ + 1) * cv11, t * Vp + p_ * cvkk:t * Vp + (p_ + 1) * cvkk] = blk[:, t]
+    w2d = w2d.to(DEV)
+    padv = lambda n, np_, sc, off=0.0: torch.cat([off + sc * torch.randn(n, generator=gen), torch.zeros(np_ - n)]).to(DEV)
+    g1, be1 = padv(U, Up, 0.2, 1.0), padv(U, Up, 0.1)
+    g2, be2 = padv(V, Vp, 0.2, 1.0), padv(V, Vp, 0.1)
+    gsc, besc = padv(oc, oc, 0.2, 1.0), padv(oc, oc, 0.1)
+    sa_s = torch.rand(B, V, generator=gen).to(DEV)
+    sa_dg = (0.05 * torch.randn(B, V, generator=gen)).to(DEV)
+    a, mult = 0.3, 3.0
+    z = lambda n: torch.zeros(n, device=DEV)
+    gf = [z(Vp), z(Vp), z(Vp), z(Up), z(Up), z(Up), z(oc), z(oc), z(oc)]
+    dv = ops.new_act(B, H, W, Vp, DEV)
+    dcat = ops.new_act(B, H, W, Up + oc, DEV)
+    ops.cardinal_bwd(dout, dsc, v_raw, u_raw, sc_raw, w2d, g2, be2, g1, be1, gsc, besc, sa_s, sa_dg, mult, dv, dcat, gf, cin, P, cv11, cvkk, Up, Vp, oc,
+                     1e-3, a)
+    gu = [z(Vp), z(Vp), z(Vp), z(Up), z(Up), z(Up), z(oc), z(oc), z(oc)]
+    dv_u = ops.norm_act_bwd_sa(v_raw, dout, V, g2, be2, torch.empty_like(v_raw), gu[0], gu[1], 0, P, 1e-3, ops.ACT_LRELU, a, sa_s, sa_dg, mult, dbias=gu[2])
+    du_u = ops.conv2d_dgrad(dv_u, w2d, 3, 1, torch.empty_like(u_raw))
+    dur_u = ops.norm_act_bwd(u_raw, du_u, U, g1, be1, torch.empty_like(u_raw), gu[3], gu[4], 0, P, 1e-3, ops.ACT_LRELU, a, dbias=gu[5])
+    dsr_u = ops.norm_act_bwd(sc_raw, dsc, oc, gsc, besc, torch.empty_like(sc_raw), gu[6], gu[7], 0, 1, 1e-3, ops.ACT_LRELU, a, dbias=gu[8])
+    torch.cuda.synchronize()
+    assert rel(dv, dv_u) < REL_BF16, ("dv", rel(dv, dv_u))
+    assert rel(dcat[..., :Up], dur_u) < 2 * REL_BF16, ("du_raw", rel(dcat[..., :Up], dur_u))      # behind two bf16 storage points (dv, du)
+    assert rel(dcat[..., Up:], dsr_u) < REL_BF16, ("dsc_raw", rel(dcat[..., Up:], dsr_u))
+    assert Vp == V or dv[..., V:].abs().max().item() == 0
+    assert Up == U or dcat[..., U:Up].abs().max().item() == 0
+    names = ("dgamma2", "dbeta2", "dbias2", "dgamma1", "dbeta1", "dbias1", "dgamma_sc", "dbeta_sc", "dbias_sc")
+    for nm, f_, u_ in zip(names, gf, gu):
+        assert rel(f_, u_) < (2e-3 if "1" in nm else 1e-4), (nm, rel(f_, u_))

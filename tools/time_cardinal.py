@@ -50,3 +50,54 @@ for st, (cin, cv11, cvkk, oc) in enumerate(((32, 3, 10, 64), (64, 7, 21, 128), (
         print("   cardinal workgroup (us):", ", ".join(f"{n} {(b_ - a_) / 100:.2f}" for n, a_, b_ in zip(names, card, card[1:])), f"| total {(card[9] - card[0]) / 100:.2f}")
         names = ["x tile load", "GEMM", "sc_raw copy-out", "LN", "sc copy-out"]
         print("   shortcut workgroup (us):", ", ".join(f"{n} {(b_ - a_) / 100:.2f}" for n, a_, b_ in zip(names, sc, sc[1:])), f"| total {(sc[5] - sc[0]) / 100:.2f}")
+
+# ---- backward: the fused launch against the four launches it replaces
+print("backward:")
+for st, (cin, cv11, cvkk, oc) in enumerate(((32, 3, 10, 64), (64, 7, 21, 128), (128, 14, 42, 256), (256, 28, 85, 512))):
+    h = HW // (2 << st)
+    P = 3
+    U, V = P * cv11, P * cvkk
+    Up, Vp = (U + 7) // 8 * 8, (V + 7) // 8 * 8
+    r16 = lambda n: (n + 15) // 16 * 16
+    t = lambda c: torch.randn(B, h, h, c, device=dev).to(torch.bfloat16)
+    v_raw, dout, u_raw, sc_raw, dsc = t(Vp), t(Vp), t(Up), t(oc), t(oc)
+    w2d = (torch.randn(r16(Up), 9 * Vp, device=dev) * 0.1).to(torch.bfloat16)
+    f = lambda n: torch.randn(n, device=dev) * 0.1
+    g2, be2, g1, be1, gsc, besc = 1 + f(Vp), f(Vp), 1 + f(Up), f(Up), 1 + f(oc), f(oc)
+    sa_s, sa_dg = torch.rand(B, V, device=dev), f(B * V).reshape(B, V)
+    z = lambda n: torch.zeros(n, device=dev)
+    gr = [z(Vp), z(Vp), z(Vp), z(Up), z(Up), z(Up), z(oc), z(oc), z(oc)]
+    dv, dcat = ops.new_act(B, h, h, Vp, dev), ops.new_act(B, h, h, Up + oc, dev)
+    du = torch.empty_like(u_raw)
+
+    def fused():
+        ops.cardinal_bwd(dout, dsc, v_raw, u_raw, sc_raw, w2d, g2, be2, g1, be1, gsc, besc, sa_s, sa_dg, 3.0, dv, dcat, gr, cin, P, cv11, cvkk, Up, Vp, oc, 1e-3, 0.3)
+
+    def unfused():
+        ops.norm_act_bwd_sa(v_raw, dout, V, g2, be2, dv, gr[0], gr[1], 0, P, 1e-3, ops.ACT_LRELU, 0.3, sa_s, sa_dg, 3.0, dbias=gr[2])
+        ops.conv2d_dgrad(dv, w2d, 3, 1, du)
+        ops.norm_act_bwd(u_raw, du, U, g1, be1, dcat[..., :Up], gr[3], gr[4], 0, P, 1e-3, ops.ACT_LRELU, 0.3, dbias=gr[5])
+        ops.norm_act_bwd(sc_raw, dsc, oc, gsc, besc, dcat[..., Up:], gr[6], gr[7], 0, 1, 1e-3, ops.ACT_LRELU, 0.3, dbias=gr[8])
+    res = []
+    for fn in (fused, unfused):
+        for _ in range(3):
+            fn()
+        n = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) * 1e3 / n)
+    print(f"stage {st + 1}: {h}x{h}: fused {res[0]:.1f} us, the four launches + their finishing reductions {res[1]:.1f} us")
+    if PH:
+        fused()
+        torch.cuda.synchronize()
+        from ultrasound_modeling_amd import _lib
+        buf = (ctypes.c_ulonglong * 32)()
+        _lib.load().usseg_cardinal_debug_read(buf)
+        card = list(buf[:9])
+        names = ["tile loads", "LN2 row passes", "LN2 column pass", "dv copy-out", "3x3 dgrad GEMM", "LN1 row pass", "LN1 column pass", "du_raw copy-out"]
+        print("   cardinal workgroup 0, its last tile (us):", ", ".join(f"{n} {(b_ - a_) / 100:.2f}" for n, a_, b_ in zip(names, card, card[1:])),
+              f"| total {(card[8] - card[0]) / 100:.2f}")

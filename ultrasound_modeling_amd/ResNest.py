@@ -38,6 +38,11 @@ _STAGE_LAZY = os.environ.get("USSEG_ENC_LAZY", "0") != "0"
 _FOLD_BN = os.environ.get("USSEG_FOLD_BN", "1") != "0"
 # the cardinal group + shortcut of a stage as ONE launch (csrc/cardinal.hip); 0 = the six unfused launches (the cross-check of the tests)
 _FUSED_CARDINAL = os.environ.get("USSEG_FUSED_CARDINAL", "1") != "0"
+_FUSED_CARDINAL_BWD = os.environ.get("USSEG_FUSED_CARDINAL_BWD", "1") != "0"     # ... and its backward chain + the shortcut norm's backward as one launch
+# The fused backward launch holds one 8x8 tile per workgroup with ~200-500 registers per lane (one or two workgroups per CU): it wins where a
+# stage has few tiles per CU (16x16 and 32x32 at batch 16: 49 vs 64 and 58 vs 71 us) and loses to the streaming norm kernels on the large stages
+# (125 vs 66 us at 64x64, 201 vs 92 us at 128x128: 16 rounds of 10-us tiles).
+_CARD_BWD_MAX_PX = int(os.environ.get("USSEG_CARD_BWD_MAX_PX", "32768"))
 _FUSED_STEM = os.environ.get("USSEG_FUSED_STEM", "1") != "0"             # the stem (three convs, two norms, pool) as one launch (csrc/stem.hip)
 _MERGED_DGRAD = os.environ.get("USSEG_MERGED_DGRAD", "1") != "0"     # one backward-data GEMM for a stage's grouped 1x1 and shortcut 1x1
 
@@ -270,6 +275,21 @@ class _CardinalGroup:
         self._saved = (x, u_raw, u, v_raw, y, g, s, ws)
         return out
 
+    def backward_fused(self, dout, dsc, sc_conv, sc_norm, dcat):
+        """The backward pass of ``forward_fused``'s launch as ONE launch (csrc/cardinal.hip, K3 backward): the re-weighting's backward +
+        conv2_bn backward -> grouped 3x3 backward-data -> conv1_bn backward into ``dcat[..., :Up]`` and the shortcut norm's backward of ``dsc``
+        into ``dcat[..., Up:]``; the nine per-channel gradient vectors accumulate.  The split-attention MLP's backward (a per-image
+        reduction over all pixels) stays in front of it, the grouped 3x3's weight gradient reads the dv it leaves."""
+        x, u_raw, u, v_raw, y, g, s, ws = self._saved
+        B, H, W, _, _ = ops.geom(x)
+        sa_s, sa_dg = ops.splitattn_bwd(self._sa_desc(B, H * W), y, dout, self._mlp_params(), self.mlp_g, g, s, ws, None)
+        dv = torch.empty_like(v_raw)
+        grads = (self.dg2, self.dbe2, self.db2, self.dg1, self.dbe1, self.db1, sc_norm.gamma.grad, sc_norm.beta.grad, sc_conv.bias.grad)
+        ops.cardinal_bwd(dout, dsc, v_raw, u_raw, sc_norm._x, self.w2_d, self.g2, self.be2, self.g1, self.be1, sc_norm.gamma.data, sc_norm.beta.data,
+                         sa_s, sa_dg, float(self.radix), dv, dcat, grads, self.cin_p, self.P, self.cv11, self.cvkk, self.Up, self.Vp, sc_conv.cout,
+                         KERAS_LN_EPS, KERAS_LRELU_ALPHA)
+        ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(u, dv, self.k, self.dil, self._maps()[1]), u, dv)
+
     def backward(self, dout, dx_residual=None, du_raw_out=None):
         """``du_raw_out``: write the gradient w.r.t. the grouped 1x1 conv's output there (a channel slice of the stage's [du_raw | dsc_raw]
         buffer) and leave the 1x1 backward-data pass to the caller (one GEMM for the cardinal group AND the shortcut: residual_S.backward)."""
@@ -355,8 +375,11 @@ class residual_S(nn.Module):
             x = sc._x
             B, H, W, _, _ = ops.geom(x)
             dcat = ops.new_act(B, H, W, g.Up + sc.cout_p, x.device)
-            self.convtmp_scbn.backward(dout, dx=dcat[..., g.Up:], dbias=sc.bias.grad)
-            g.backward(d_c1, du_raw_out=dcat[..., :g.Up])
+            if _FUSED_CARDINAL_BWD and g.fused_ok(sc) and B * H * W < _CARD_BWD_MAX_PX:
+                g.backward_fused(d_c1, dout, sc, self.convtmp_scbn, dcat)
+            else:
+                self.convtmp_scbn.backward(dout, dx=dcat[..., g.Up:], dbias=sc.bias.grad)
+                g.backward(d_c1, du_raw_out=dcat[..., :g.Up])
             # x^T . [du_raw | dsc_raw]: the weight gradients of the paths' 1x1 convs and of the shortcut conv in one launch (four mapped blocks)
             ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(x, dcat, 1, 1, self._wcat_map()), x, dcat)
             return ops.conv2d_dgrad(dcat, self.wcat_d, 1, 1, ops.new_act(B, H, W, g.cin_p, x.device))

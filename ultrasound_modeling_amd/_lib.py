@@ -151,6 +151,8 @@ _PROTOS = {
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_cardinal_supported": (c_i32, [P(CardinalDesc)]),
     "usseg_cardinal_fwd": (C.c_int, [P(CardinalDesc)] + [c_vp] * 21),
+    # ... and its backward pass: (re-weighting + conv2_bn) backward -> grouped 3x3 backward-data -> conv1_bn backward | shortcut norm backward
+    "usseg_cardinal_bwd": (C.c_int, [P(CardinalDesc), c_vp, c_i32, c_vp, c_i32] + [c_vp] * 12 + [c_f32, c_vp, c_vp, c_i32] + [c_vp] * 11),
     "usseg_accuracy": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "usseg_norm_act_bwd_res": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_norm_act_bwd_sa": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

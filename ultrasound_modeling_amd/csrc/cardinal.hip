@@ -374,19 +374,22 @@ __global__ __launch_bounds__(256) void cardinal_fwd_kernel(const CardFwd p) {
   constexpr int TPP = (CVKK + 15) / 16, PF2 = TPP > 4 ? 3 : PF;
   const int pcb = (wv * CV11) / 8, pnck = ((wv + 1) * CV11 + 7) / 8 - pcb, pn0 = wv * CVKK;     // chunk base / chunks per tap / first channel
   const int pnch = 9 * pnck, KSg = (pnch + 3) / 4;
+  // No select on the loaded value (`ok ? v : 0` made the compiler wait for every fragment right behind its load - vmcnt(0) - so nothing was
+  // ever in flight): a K chunk past the path's last one re-reads the last chunk and meets a ZEROED pixel fragment below, a row past the
+  // path's last channel re-reads the last row and lands in accumulator rows that are never stored.
   auto w2_frag = [&](int ks, int j) -> bf16x8_t {
-    const int chunk = 4 * ks + q, row = 16 * j + r;
-    const bool ok = chunk < pnch && row < CVKK;
-    const int tap = ok ? chunk / pnck : 0, choff = ok ? chunk - tap * pnck : 0;
-    const bf16x8_t v = ldg_frag(p.w2 + (int64_t)(pn0 + (ok ? row : 0)) * (9 * UP) + tap * UP + (pcb + choff) * 8);
-    return ok ? v : zero_frag();
+    int chunk = 4 * ks + q, row = 16 * j + r;
+    chunk = chunk < pnch ? chunk : pnch - 1;
+    row = row < CVKK ? row : CVKK - 1;
+    const int tap = chunk / pnck, choff = chunk - tap * pnck;
+    return ldg_frag(p.w2 + (int64_t)(pn0 + row) * (9 * UP) + tap * UP + (pcb + choff) * 8);
   };
   bf16x8_t a2[PF2][TPP];
   if (wv < 3) {
 #pragma unroll
     for (int s = 0; s < PF2; ++s)
 #pragma unroll
-      for (int j = 0; j < TPP; ++j) a2[s][j] = s < KSg ? w2_frag(s, j) : zero_frag();
+      for (int j = 0; j < TPP; ++j) a2[s][j] = w2_frag(s, j);
   }
   __syncthreads();
   CARD_STAMP(2);
@@ -434,7 +437,8 @@ __global__ __launch_bounds__(256) void cardinal_fwd_kernel(const CardFwd p) {
 #pragma unroll
         for (int s = 0; s < PF2; ++s) {
           const int ks = ks0 + s;
-          if (ks < KSg) {
+          {   // (no `ks < KSg` branch: a step past the end multiplies clamped weights with zeroed pixel fragments; a branch here makes the
+              //  compiler drain every weight load in flight - vmcnt(0) - at its join)
             const int chunk = 4 * ks + q;
             const bool kv = chunk < pnch;
             const int tap = kv ? chunk / pnck : 0, choff = kv ? chunk - tap * pnck : 0;
@@ -450,10 +454,8 @@ __global__ __launch_bounds__(256) void cardinal_fwd_kernel(const CardFwd p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
               for (int j = 0; j < TPP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[s][j], bu[i], acc[i][j], 0, 0, 0);
-            if (ks + PF2 < KSg) {
 #pragma unroll
-              for (int j = 0; j < TPP; ++j) a2[s][j] = w2_frag(ks + PF2, j);
-            }
+            for (int j = 0; j < TPP; ++j) a2[s][j] = w2_frag(ks + PF2, j);      // (unconditional, clamped: the compiler's vmcnt count stays exact)
           }
         }
       }
@@ -550,10 +552,12 @@ struct LnTile {
   int32_t ntiles;
 };
 
-template <int CSI, int CP, int CG, int NG, bool FUSE>
+// Waves = RB row blocks x 4 / RB chunk subsets (wave wvu: row block wvu % RB = rb, subset CSI = wvu / RB); `pst` points at this row block's
+// first entry.
+template <int CSI, int CP, int CG, int NG, bool FUSE, int RB = 1>
 __device__ __forceinline__ void lnb_rows(const bf16_t* xrow, const bf16_t* dyrow, float* STAT, float4* pst, const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, const float* SA, float eps, float alpha, int wvu, int lane) {
-  constexpr int CPS = (CP + 3) / 4, C = CG * NG, C0 = CSI * CPS, CPH = CP * 8;
+                                         const float* __restrict__ beta, const float* SA, float eps, float alpha, int wvu, int lane, int rb = 0) {
+  constexpr int CS = 4 / RB, CPS = (CP + CS - 1) / CS, C = CG * NG, C0 = CSI * CPS, CPH = CP * 8;
   const float inv = 1.f / (float)CG;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -573,8 +577,8 @@ __device__ __forceinline__ void lnb_rows(const bf16_t* xrow, const bf16_t* dyrow
   __syncthreads();
   float m0 = 0.f, m1 = 0.f, m2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float* o = STAT + k * 256 + lane;
+  for (int k = 0; k < CS; ++k) {
+    const float* o = STAT + (k * RB + rb) * 256 + lane;
     m0 += o[0];
     if (NG > 1) { m1 += o[64]; m2 += o[128]; }
   }
@@ -600,8 +604,8 @@ __device__ __forceinline__ void lnb_rows(const bf16_t* xrow, const bf16_t* dyrow
   __syncthreads();
   float r0 = 0.f, r1 = 0.f, r2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float* o = STAT + 1024 + k * 256 + lane;
+  for (int k = 0; k < CS; ++k) {
+    const float* o = STAT + 1024 + (k * RB + rb) * 256 + lane;
     r0 += o[0];
     if (NG > 1) { r1 += o[64]; r2 += o[128]; }
   }
@@ -639,11 +643,11 @@ __device__ __forceinline__ void lnb_rows(const bf16_t* xrow, const bf16_t* dyrow
   if (CSI == 0) {
     float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < CS; ++k)
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        sa[g] += STAT[2048 + k * 256 + g * 64 + lane];
-        sb[g] += STAT[3072 + k * 256 + g * 64 + lane];
+        sa[g] += STAT[2048 + (k * RB + rb) * 256 + g * 64 + lane];
+        sb[g] += STAT[3072 + (k * RB + rb) * 256 + g * 64 + lane];
       }
     pst[lane * NG + 0] = make_float4(m0, r0, sa[0] * inv, sb[0] * inv);
     if (NG > 1) {
@@ -664,13 +668,11 @@ struct LnbCfg {
 
 // FUSE (the split-attention re-weighting's backward dy_eff = sa_mult*s[b][c]*dy + dg[b][c], formed in fp32 and never stored): a tile lies
 // inside ONE image (the launcher checks HW % 64 == 0), so its (s, dg) row is staged in LDS once per tile.
+// workgroup `blk` of `nblk` walks the tiles blk, blk + nblk, ... and leaves ONE partial row a.ws[blk][3][CPH]
 template <int CP, int CG, int NG, bool FUSE>
-__global__ __launch_bounds__(256) void ln_bwd_tile_kernel(const LnTile P) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void lnb_tile_loop(const LnTileArgs& a, const int ntiles, char* lds, const int blk, const int nblk) {
   using Cfg = LnbCfg<CP, CG, NG, FUSE>;
   constexpr int CPH = Cfg::CPH, XS = Cfg::XS, PG = Cfg::PG, NR = Cfg::NR, C = CG * NG;
-  const LnTileArgs& a = P.a;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
   bf16_t* const XT = reinterpret_cast<bf16_t*>(lds);
   bf16_t* const DT = reinterpret_cast<bf16_t*>(lds + Cfg::XT_B);
   float4* const PST = reinterpret_cast<float4*>(lds + 2 * Cfg::XT_B);
@@ -717,9 +719,9 @@ __global__ __launch_bounds__(256) void ln_bwd_tile_kernel(const LnTile P) {
       }
     }
   };
-  if ((int)blockIdx.x < P.ntiles) issue(blockIdx.x);
+  if (blk < ntiles) issue(blk);
 
-  for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+  for (int tile = blk; tile < ntiles; tile += nblk) {
     const int64_t m0 = (int64_t)tile * 64;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(256) void ln_bwd_tile_kernel(const LnTile P) {
     }
     if (FUSE && tid < CPH) { SA[tid] = sav; SA[CPH + tid] = sag; }
     __syncthreads();
-    if (tile + (int)gridDim.x < P.ntiles) issue(tile + gridDim.x);
+    if (tile + nblk < ntiles) issue(tile + nblk);
     // ---- row passes: per-pixel statistics
     {
       const bf16_t* xrow = XT + lane * XS;
@@ -792,8 +794,15 @@ __global__ __launch_bounds__(256) void ln_bwd_tile_kernel(const LnTile P) {
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) a.ws[((int64_t)blockIdx.x * 3 + k) * CPH + ct + 256 * r] = acc[r][k];
+      for (int k = 0; k < 3; ++k) a.ws[((int64_t)blk * 3 + k) * CPH + ct + 256 * r] = acc[r][k];
   }
+}
+
+template <int CP, int CG, int NG, bool FUSE>
+__global__ __launch_bounds__(256) void ln_bwd_tile_kernel(const LnTile P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  lnb_tile_loop<CP, CG, NG, FUSE>(P.a, P.ntiles, lds, blockIdx.x, gridDim.x);
 #endif
 }
 
@@ -815,6 +824,384 @@ int launch_lnb(const LnTileArgs& a, float* dgamma, float* dbeta, float* dbias, f
   hipLaunchKernelGGL((ln_bwd_tile_kernel<CP, CG, NG, FUSE>), dim3(grid), dim3(256), Cfg::LDS_B, s, P);
   usseg_launch_reduce_finish(P.a.ws, 1, grid, 3, Cfg::CPH, a.C, 1.f, dgamma, dbeta, dbias, s, 0);
   return 1;
+}
+
+// =====================================================================================================================================
+// K3 backward: one launch for the backward pass of a stage's cardinal chain AND of its shortcut norm.
+//
+//   role 0 (even workgroups), one 8x8-pixel tile (+1 halo) at a time:
+//     dout, v_raw on the 100 halo pixels -> [split-attention re-weighting backward + conv2_bn LayerNorm/LeakyReLU backward] = dv on the halo
+//     (zero outside the image: the backward-data pass of a zero-padded conv pads dv) -> dv of the interior -> HBM (the 3x3 weight gradient
+//     reads it) -> grouped 3x3 BACKWARD-DATA as a block-diagonal implicit GEMM over (flipped tap, 8-channel chunk of the path) from the LDS
+//     dv tile -> du (bf16, as the unfused launch stores it) -> conv1_bn LayerNorm/LeakyReLU backward with the u_raw tile -> du_raw -> dcat[:, :Up];
+//   role 1 (odd workgroups): the shortcut norm's backward (convtmp_scbn, ResNest.py:100-101) on 64-pixel tiles -> dcat[:, Up:].
+//
+// Replaces norm_act_bwd_sa -> conv2d_dgrad (3x3) -> norm_act_bwd and the shortcut's norm_act_bwd; the halo rows of the first norm are
+// recomputed (100 / 64).  Per-channel sums (dgamma, dbeta, the producing conv's bias gradient) are taken over INTERIOR pixels only, in
+// pixel order per workgroup, one partial row per workgroup and norm: bitwise reproducible.
+struct CardBwd {
+  const bf16_t *dout, *v_raw, *u_raw, *w2d;
+  const float *g2, *be2, *g1, *be1, *sa_s, *sa_dg;
+  bf16_t *dv, *dcat;
+  float *ws2, *ws1;                 // partial rows [G][3][Vp], [G][3][Up]
+  int32_t B, H, W, ldo, ldv, ldu, lddv, ldc, tiles_x, tiles_img, ntiles, G;
+  float eps, alpha, sa_mult;
+  LnTileArgs sc;                    // the shortcut norm (role 1)
+  int32_t sc_tiles;
+};
+
+// column pass: a thread owns four channels of every PG-th row
+template <int CPH, int CG>
+struct LnColCfg {
+  static constexpr int NQ = CPH / 4, PG = 256 / NQ > 32 ? 32 : 256 / NQ;
+};
+
+template <int CV11, int CVKK, int OC>
+struct CardBwdCfg {
+  static constexpr int U = 3 * CV11, V = 3 * CVKK, UP = (U + 7) / 8 * 8, VP = (V + 7) / 8 * 8;
+  static constexpr int S1 = UP + 8, S2 = VP + 8;
+  static constexpr int VT_B = NHALO * S2 * 2, UT_B = NPIX * S1 * 2;
+  static constexpr int PST_B = 128 * 3 * 16, STAT_B4 = 4 * 1024 * 4, SA_B = 2 * VP * 4, FLG_B = 128;
+  static constexpr int RED2 = LnColCfg<VP, CVKK>::PG * 3 * VP, RED1 = LnColCfg<UP, CV11>::PG * 3 * UP, RED_B = (RED2 > RED1 ? RED2 : RED1) * 4;
+  static constexpr int OFF_DT = VT_B, OFF_PST = 2 * VT_B, OFF_STAT = OFF_PST + PST_B, OFF_RED = OFF_STAT + STAT_B4, OFF_SA = OFF_RED + RED_B,
+                       OFF_FLG = OFF_SA + SA_B, OFF_UT = OFF_FLG + FLG_B;
+  static constexpr int LDS_CARD = OFF_UT + UT_B;
+  static constexpr int LDS_SC = LnbCfg<OC / 8, OC, 1, false>::LDS_B;
+  static constexpr int LDS_B = LDS_CARD > LDS_SC ? LDS_CARD : LDS_SC;
+  static_assert(UT_B <= VT_B, "the du tile lives in the dout tile's LDS once the first norm is done");
+};
+
+// column pass of a LayerNorm backward over NPX staged rows: a thread owns FOUR consecutive channels (8-byte LDS accesses; 2-byte ones made
+// this pass LDS-instruction bound: 12 us of a 53 us workgroup at 256 channels) of every PG-th row; dx replaces x in XT; the three
+// per-channel sums of the rows whose flag has bit 1 set go to RED[pixel group][3][CPH], added up by lnb_cols_finish
+template <int CPH, int CG, int NPX, bool FUSE>
+__device__ __forceinline__ void lnb_cols(bf16_t* XT, const bf16_t* DT, int XS, const float4* PST, const float* SA, const unsigned char* FLG,
+                                         bool halo, float* RED, const float* __restrict__ gamma, const float* __restrict__ beta, float alpha, int tid) {
+  constexpr int C = 3 * CG, NQ = LnColCfg<CPH, CG>::NQ, PG = LnColCfg<CPH, CG>::PG;
+  const int cq = tid % NQ, cpg = tid / NQ;
+  if (cpg >= PG) return;
+  const int c0 = 4 * cq;
+  float cga[4], cbe[4], sv[4], sg[4], sga[4], sbe[4], sbi[4];
+  int gi[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = c0 + e;
+    const bool on = ch < C;
+    cga[e] = on ? gamma[ch] : 0.f;
+    cbe[e] = on ? beta[ch] : 0.f;
+    sv[e] = FUSE ? SA[ch] : 1.f;
+    sg[e] = FUSE ? SA[CPH + ch] : 0.f;
+    gi[e] = on ? (ch >= CG) + (ch >= 2 * CG) : 2;
+    sga[e] = sbe[e] = sbi[e] = 0.f;
+  }
+#pragma unroll 2
+  for (int px = cpg; px < NPX; px += PG) {
+    const int hp = halo ? px : ((px >> 3) + 1) * LW + (px & 7) + 1;
+    const unsigned f = FLG[hp];
+    const float4 stA = PST[px * 3 + gi[0]], stB = PST[px * 3 + gi[3]];
+    float4 stM = stA;
+    if (CG < 4) stM = PST[px * 3 + gi[1]];          // (three channels per group: a quad can touch three groups)
+    const uint2 xv = *reinterpret_cast<const uint2*>(XT + px * XS + c0);
+    const uint2 dv = *reinterpret_cast<const uint2*>(DT + px * XS + c0);
+    const float x[4] = {__uint_as_float(xv.x << 16), __uint_as_float(xv.x & 0xffff0000u), __uint_as_float(xv.y << 16), __uint_as_float(xv.y & 0xffff0000u)};
+    const float d[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16), __uint_as_float(dv.y & 0xffff0000u)};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 st = gi[e] == gi[0] ? stA : (gi[e] == gi[3] ? stB : stM);
+      const float dy = FUSE ? fmaf(d[e], sv[e], sg[e]) : d[e];
+      const float xh = (x[e] - st.x) * st.y;
+      const float pre = cga[e] * xh + cbe[e];
+      const float dh = dy * (pre >= 0.f ? 1.f : alpha);
+      const float dxh = dh * cga[e];
+      const float t = st.y * (dxh - st.z - xh * st.w);
+      const bool live = (f & 1u) && c0 + e < C;
+      o[e] = live ? t : 0.f;
+      if ((f & 2u) && c0 + e < C) { sga[e] = fmaf(dh, xh, sga[e]); sbe[e] += dh; sbi[e] += t; }
+    }
+    uint2 ov;
+    ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
+    *reinterpret_cast<uint2*>(XT + px * XS + c0) = ov;
+  }
+  *reinterpret_cast<float4*>(RED + (cpg * 3 + 0) * CPH + c0) = make_float4(sga[0], sga[1], sga[2], sga[3]);
+  *reinterpret_cast<float4*>(RED + (cpg * 3 + 1) * CPH + c0) = make_float4(sbe[0], sbe[1], sbe[2], sbe[3]);
+  *reinterpret_cast<float4*>(RED + (cpg * 3 + 2) * CPH + c0) = make_float4(sbi[0], sbi[1], sbi[2], sbi[3]);
+}
+// (after a barrier) thread tid < CPH adds its channel's partial sums in pixel-group order
+template <int CPH, int CG>
+__device__ __forceinline__ void lnb_cols_finish(const float* RED, int tid, float* sums) {
+  constexpr int PG = LnColCfg<CPH, CG>::PG;
+  if (tid < CPH) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float s_ = 0.f;
+      for (int gq = 0; gq < PG; ++gq) s_ += RED[(gq * 3 + k) * CPH + tid];
+      sums[k] += s_;
+    }
+  }
+}
+
+template <int CIN, int CV11, int CVKK, int OC>
+__global__ __launch_bounds__(256) void cardinal_bwd_kernel(const CardBwd p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using Cfg = CardBwdCfg<CV11, CVKK, OC>;
+  constexpr int U = Cfg::U, V = Cfg::V, UP = Cfg::UP, VP = Cfg::VP, S1 = Cfg::S1, S2 = Cfg::S2;
+  constexpr int CP1 = UP / 8, CP2 = VP / 8;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int blk = blockIdx.x >> 1;
+  if (blockIdx.x & 1) {      // ============================================= shortcut norm backward (ResNest.py:100-101)
+    lnb_tile_loop<OC / 8, OC, 1, false>(p.sc, p.sc_tiles, lds, blk, p.G);
+    return;
+  }
+  bf16_t* const VT = reinterpret_cast<bf16_t*>(lds);
+  bf16_t* const DT = reinterpret_cast<bf16_t*>(lds + Cfg::OFF_DT);
+  bf16_t* const DU = DT;      // (the dout tile is dead once dv exists)
+  float4* const PST = reinterpret_cast<float4*>(lds + Cfg::OFF_PST);
+  float* const STAT = reinterpret_cast<float*>(lds + Cfg::OFF_STAT);
+  float* const RED = reinterpret_cast<float*>(lds + Cfg::OFF_RED);
+  float* const SA = reinterpret_cast<float*>(lds + Cfg::OFF_SA);
+  unsigned char* const FLG = reinterpret_cast<unsigned char*>(lds + Cfg::OFF_FLG);
+  bf16_t* const UT = reinterpret_cast<bf16_t*>(lds + Cfg::OFF_UT);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  float acc2[3] = {0.f, 0.f, 0.f}, acc1[3] = {0.f, 0.f, 0.f};
+
+  // the grouped 3x3's backward-data operand, block diagonal: wave g < 3 computes path g's CV11 input-channel gradients from its CVKK dv channels;
+  // PFB K steps of weight fragments in flight (the loop is bound by the L2 latency of its weight rows: 27 K steps at 28 -> 85 channels)
+  constexpr int TPP = (CV11 + 15) / 16, PFB = 8;
+  const int pcb = (wv * CVKK) / 8, pnck = ((wv + 1) * CVKK + 7) / 8 - pcb, pn0 = wv * CV11;
+  const int pnch = 9 * pnck, KSg = (pnch + 3) / 4;
+  auto w2_frag = [&](int ks, int j) -> bf16x8_t {      // (clamped, never selected: see the forward kernel's w2_frag)
+    int chunk = 4 * ks + q, row = 16 * j + r;
+    chunk = chunk < pnch ? chunk : pnch - 1;
+    row = row < CV11 ? row : CV11 - 1;
+    const int tap = chunk / pnck, choff = chunk - tap * pnck;
+    return ldg_frag(p.w2d + (int64_t)(pn0 + row) * (9 * VP) + tap * VP + (pcb + choff) * 8);
+  };
+
+  for (int t = blk; t < p.ntiles; t += p.G) {
+    const int b = t / p.tiles_img, tile = t - b * p.tiles_img;
+    const int tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
+    const int ty0 = tyi * TILE, tx0 = txi * TILE;
+    const int64_t img = (int64_t)b * p.H * p.W;
+    CARD_STAMP(0);
+    const float *g2 = p.g2, *be2 = p.be2, *g1 = p.g1, *be1 = p.be1;
+    bf16x8_t a2[PFB][TPP];
+    if (wv < 3) {
+#pragma unroll
+      for (int s = 0; s < PFB; ++s)
+#pragma unroll
+        for (int j = 0; j < TPP; ++j) a2[s][j] = w2_frag(s, j);
+    }
+    // ---- A: v_raw and dout on the halo, u_raw on the interior -> LDS; per-pixel flags (bit 0: inside the image, bit 1: interior too)
+    if (tid < 128) {
+      const int hy = tid / LW, hx = tid - hy * LW;
+      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+      const bool in = tid < NHALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const bool inner = hy >= 1 && hy <= TILE && hx >= 1 && hx <= TILE;
+      FLG[tid] = (unsigned char)((in ? 1 : 0) | (in && inner ? 2 : 0));
+    }
+    auto halo_src = [&](const bf16_t* base, int ld, int hp) -> const bf16_t* {
+      const int hy = hp / LW, hx = hp - hy * LW;
+      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+      return (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? base + (img + (int64_t)gy * p.W + gx) * ld : nullptr;
+    };
+    {   // every load of the three tiles is issued before the first LDS store (three load -> store rounds cost three memory latencies)
+      constexpr int NV = (NHALO * CP2 + 255) / 256, NU = (NPIX * CP1 + 255) / 256;
+      uint4 rv[NV], rd[NV], ru[NU];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int it = tid + i * 256;
+        const int hp = it / CP2, c = it - hp * CP2;
+        const bf16_t* sv_ = it < NHALO * CP2 ? halo_src(p.v_raw, p.ldv, hp) : nullptr;
+        const bf16_t* sd_ = it < NHALO * CP2 ? halo_src(p.dout, p.ldo, hp) : nullptr;
+        rv[i] = sv_ ? *reinterpret_cast<const uint4*>(sv_ + c * 8) : make_uint4(0, 0, 0, 0);
+        rd[i] = sd_ ? *reinterpret_cast<const uint4*>(sd_ + c * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int it = tid + i * 256;
+        const int pp = it / CP1, c = it - pp * CP1;
+        const int gy = ty0 + (pp >> 3), gx = tx0 + (pp & 7);
+        const bool ok = it < NPIX * CP1 && gy < p.H && gx < p.W;
+        ru[i] = ok ? *reinterpret_cast<const uint4*>(p.u_raw + (img + (int64_t)gy * p.W + gx) * p.ldu + c * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int it = tid + i * 256;
+        const int hp = it / CP2, c = it - hp * CP2;
+        if (it < NHALO * CP2) {
+          *reinterpret_cast<uint4*>(VT + hp * S2 + c * 8) = rv[i];
+          *reinterpret_cast<uint4*>(DT + hp * S2 + c * 8) = rd[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int it = tid + i * 256;
+        const int pp = it / CP1, c = it - pp * CP1;
+        if (it < NPIX * CP1) *reinterpret_cast<uint4*>(UT + pp * S1 + c * 8) = ru[i];
+      }
+    }
+    if (tid < VP) {
+      SA[tid] = tid < V ? p.sa_mult * p.sa_s[(int64_t)b * V + tid] : 0.f;
+      SA[VP + tid] = tid < V ? p.sa_dg[(int64_t)b * V + tid] : 0.f;
+    }
+    __syncthreads();
+    CARD_STAMP(1);
+    // ---- B: conv2_bn backward, row passes on the 100 halo pixels: rows 0-63, then 64-99 (the four waves split the channels; one code copy
+    //         with a quarter of the channels per wave keeps the hoisted gamma / beta / SA constants - and the kernel's VGPR count - small)
+#pragma unroll 1
+    for (int rb = 0; rb < 2; ++rb) {
+      const int row = rb * 64 + lane < NHALO ? rb * 64 + lane : NHALO - 1;
+      const bf16_t* xrow = VT + row * S2;
+      const bf16_t* dyrow = DT + row * S2;
+      float4* pst = PST + rb * 64 * 3;
+      if (wv == 0) lnb_rows<0, CP2, CVKK, 3, true>(xrow, dyrow, STAT, pst, g2, be2, SA, p.eps, p.alpha, wv, lane);
+      else if (wv == 1) lnb_rows<1, CP2, CVKK, 3, true>(xrow, dyrow, STAT, pst, g2, be2, SA, p.eps, p.alpha, wv, lane);
+      else if (wv == 2) lnb_rows<2, CP2, CVKK, 3, true>(xrow, dyrow, STAT, pst, g2, be2, SA, p.eps, p.alpha, wv, lane);
+      else lnb_rows<3, CP2, CVKK, 3, true>(xrow, dyrow, STAT, pst, g2, be2, SA, p.eps, p.alpha, wv, lane);
+      __syncthreads();      // (STAT is reused by the second pass)
+    }
+    CARD_STAMP(2);
+    // ---- C: column pass: dv (zero outside the image) replaces v_raw in LDS; sums over the interior pixels
+    lnb_cols<VP, CVKK, NHALO, true>(VT, DT, S2, PST, SA, FLG, true, RED, g2, be2, p.alpha, tid);
+    __syncthreads();
+    lnb_cols_finish<VP, CVKK>(RED, tid, acc2);
+    CARD_STAMP(3);
+    // dv of the interior pixels -> HBM in whole rows (the grouped 3x3's weight gradient reads it)
+    for (int it = tid; it < NPIX * CP2; it += 256) {
+      const int pp = it / CP2, c = it - pp * CP2;
+      const int gy = ty0 + (pp >> 3), gx = tx0 + (pp & 7);
+      if (gy < p.H && gx < p.W) {
+        const int hp = ((pp >> 3) + 1) * LW + (pp & 7) + 1;
+        *reinterpret_cast<uint4*>(p.dv + (img + (int64_t)gy * p.W + gx) * p.lddv + c * 8) = *reinterpret_cast<const uint4*>(VT + hp * S2 + c * 8);
+      }
+    }
+    CARD_STAMP(4);
+    // ---- D: du[interior pixel][path channels] = sum over taps of dv[pixel - (tap - 1)] . W2[tap]^T (block diagonal)
+    {
+      f32x4_t acc[4][TPP];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TPP; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (wv < 3) {
+        int pbase[4];   // halo index of this lane's pixel shifted by (+1, +1): tap (ty, tx) reads pbase - ty * LW - tx
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int pp = i * 16 + r;
+          pbase[i] = ((pp >> 3) + 2) * LW + (pp & 7) + 2;
+        }
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < KSg; ks0 += PFB) {
+#pragma unroll
+          for (int s = 0; s < PFB; ++s) {
+            const int ks = ks0 + s;
+            {   // (no `ks < KSg` branch, as in the forward kernel)
+              const int chunk = 4 * ks + q;
+              const bool kv = chunk < pnch;
+              const int tap = kv ? chunk / pnck : 0, choff = kv ? chunk - tap * pnck : 0;
+              const int ty = tap / 3, tx = tap - ty * 3;
+              const int toff = -(ty * LW + tx) * S2 + (pcb + choff) * 8;
+              bf16x8_t bu[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                bu[i] = *reinterpret_cast<const bf16x8_t*>(VT + pbase[i] * S2 + toff);
+                if (!kv) bu[i] = zero_frag();
+              }
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TPP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[s][j], bu[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < TPP; ++j) a2[s][j] = w2_frag(ks + PFB, j);      // (unconditional, clamped: the vmcnt count stays exact)
+            }
+          }
+        }
+        // a path starts at any channel: 2-byte LDS stores (the dout tile's LDS: every thread passed the barrier after the column pass)
+#pragma unroll
+        for (int j = 0; j < TPP; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int pp = i * 16 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int cl = 16 * j + 4 * q + e;
+              if (cl < CV11) DU[pp * S1 + pn0 + cl] = f2bf(acc[i][j][e]);
+            }
+          }
+      } else if (UP > U) {
+        for (int c = U; c < UP; ++c) DU[lane * S1 + c] = 0;
+      }
+    }
+    __syncthreads();
+    CARD_STAMP(5);
+    // ---- E: conv1_bn backward on the 64 interior pixels: row pass, column pass (du_raw replaces u_raw in LDS), out in whole rows
+    {
+      const bf16_t* xrow = UT + lane * S1;
+      const bf16_t* dyrow = DU + lane * S1;
+      if (wv == 0) lnb_rows<0, CP1, CV11, 3, false>(xrow, dyrow, STAT, PST, g1, be1, SA, p.eps, p.alpha, wv, lane);
+      else if (wv == 1) lnb_rows<1, CP1, CV11, 3, false>(xrow, dyrow, STAT, PST, g1, be1, SA, p.eps, p.alpha, wv, lane);
+      else if (wv == 2) lnb_rows<2, CP1, CV11, 3, false>(xrow, dyrow, STAT, PST, g1, be1, SA, p.eps, p.alpha, wv, lane);
+      else lnb_rows<3, CP1, CV11, 3, false>(xrow, dyrow, STAT, PST, g1, be1, SA, p.eps, p.alpha, wv, lane);
+    }
+    __syncthreads();
+    CARD_STAMP(6);
+    lnb_cols<UP, CV11, NPIX, false>(UT, DU, S1, PST, SA, FLG, false, RED, g1, be1, p.alpha, tid);
+    __syncthreads();
+    lnb_cols_finish<UP, CV11>(RED, tid, acc1);
+    CARD_STAMP(7);
+    for (int it = tid; it < NPIX * CP1; it += 256) {
+      const int pp = it / CP1, c = it - pp * CP1;
+      const int gy = ty0 + (pp >> 3), gx = tx0 + (pp & 7);
+      if (gy < p.H && gx < p.W)
+        *reinterpret_cast<uint4*>(p.dcat + (img + (int64_t)gy * p.W + gx) * p.ldc + c * 8) = *reinterpret_cast<const uint4*>(UT + pp * S1 + c * 8);
+    }
+    __syncthreads();      // the next tile's loads overwrite the staged tiles
+    CARD_STAMP(8);
+  }
+  if (tid < VP) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.ws2[((int64_t)blk * 3 + k) * VP + tid] = acc2[k];
+  }
+  if (tid < UP) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.ws1[((int64_t)blk * 3 + k) * UP + tid] = acc1[k];
+  }
+#endif
+}
+
+template <int CIN, int CV11, int CVKK, int OC>
+int launch_bwd(CardBwd& p, float* dg2, float* dbe2, float* db2, float* dg1, float* dbe1, float* db1, float* dgsc, float* dbesc, float* dbsc,
+               float* caller_ws, hipStream_t s) {
+  using Cfg = CardBwdCfg<CV11, CVKK, OC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)cardinal_bwd_kernel<CIN, CV11, CVKK, OC>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_B);
+    attr_done = true;
+  }
+  // workgroup pairs (cardinal tile walker, shortcut tile walker): as many as are resident at once, at most one per tile
+  static const int g_env = getenv("USSEG_CARD_BWD_G") ? atoi(getenv("USSEG_CARD_BWD_G")) : 0;
+  const int per_cu = 160 * 1024 / (2 * Cfg::LDS_B) > 0 ? 160 * 1024 / (2 * Cfg::LDS_B) : 1;
+  const int most = p.ntiles > p.sc_tiles ? p.ntiles : p.sc_tiles;
+  int G = g_env > 0 ? g_env : 256 * per_cu;
+  if (G > most) G = most;
+  if (G > USSEG_REDUCE_MAX_BLOCKS) G = USSEG_REDUCE_MAX_BLOCKS;
+  p.G = G;
+  constexpr int VP = Cfg::VP, UP = Cfg::UP;
+  // three partial-row regions (private ones while the finishing reductions are deferred); caller_ws holds all three otherwise
+  const int64_t n2 = (int64_t)G * 3 * VP, n1 = (int64_t)G * 3 * UP, nsc = (int64_t)G * 3 * OC;
+  p.ws2 = usseg_defer_reduce_ws(s, caller_ws, n2);
+  p.ws1 = usseg_defer_reduce_ws(s, caller_ws + n2, n1);
+  p.sc.ws = usseg_defer_reduce_ws(s, caller_ws + n2 + n1, nsc);
+  const int slot = usseg_prof_start(1, s);       // counted with the conv family like the forward launch (it carries the grouped 3x3 backward-data pass)
+  hipLaunchKernelGGL((cardinal_bwd_kernel<CIN, CV11, CVKK, OC>), dim3(2 * G), dim3(256), Cfg::LDS_B, s, p);
+  usseg_prof_stop(1, slot, s);
+  usseg_launch_reduce_finish(p.ws2, 1, G, 3, VP, Cfg::V, 1.f, dg2, dbe2, db2, s, 0);
+  usseg_launch_reduce_finish(p.ws1, 1, G, 3, UP, Cfg::U, 1.f, dg1, dbe1, db1, s, 0);
+  usseg_launch_reduce_finish(p.sc.ws, 1, G, 3, OC, OC, 1.f, dgsc, dbesc, dbsc, s, 0);
+  return usseg_check_launch("cardinal_bwd");
 }
 
 }  // namespace
@@ -879,5 +1266,42 @@ extern "C" int usseg_cardinal_fwd(const UssegCardinalDesc* d, const void* x, con
     case 1: return launch_fwd<64, 7, 21, 128>(p, s);
     case 2: return launch_fwd<128, 14, 42, 256>(p, s);
     default: return launch_fwd<256, 28, 85, 512>(p, s);
+  }
+}
+
+extern "C" int usseg_cardinal_bwd(const UssegCardinalDesc* d, const void* dout, int32_t ldo, const void* dsc, int32_t lddsc, const void* v_raw,
+                                  const void* u_raw, const void* sc_raw, const void* w2d, const float* g2, const float* be2, const float* g1,
+                                  const float* be1, const float* gsc, const float* besc, const float* sa_s, const float* sa_dg, float sa_mult,
+                                  void* dv, void* dcat, int32_t ldc, float* dg2, float* dbe2, float* db2, float* dg1, float* dbe1, float* db1,
+                                  float* dgsc, float* dbesc, float* dbsc, float* ws, usseg_stream_t stream) {
+  const int cfg = card_config(d);
+  USSEG_CHECK_ARG(cfg >= 0, "cardinal_bwd: no fused kernel for this channel configuration (usseg_cardinal_supported)");
+  USSEG_CHECK_ARG(dout && dsc && v_raw && u_raw && sc_raw && w2d && g2 && be2 && g1 && be1 && gsc && besc && sa_s && sa_dg && dv && dcat && dg2 && dbe2 &&
+                      db2 && dg1 && dbe1 && db1 && dgsc && dbesc && dbsc && ws,
+                  "cardinal_bwd: null pointer");
+  USSEG_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && ldo >= d->Vp && lddsc >= d->Oc && d->ldu >= d->Up && d->ldv >= d->Vp && d->ldsc >= d->Oc &&
+                      ldc >= d->Up + d->Oc && ldo % 8 == 0 && lddsc % 8 == 0 && d->ldu % 8 == 0 && d->ldv % 8 == 0 && d->ldsc % 8 == 0 && ldc % 8 == 0,
+                  "cardinal_bwd: bad geometry / strides");
+  USSEG_CHECK_ARG((int64_t)d->B * d->H * d->W < (1ll << 31), "cardinal_bwd: too many pixels");
+  CardBwd p = {};
+  p.dout = (const bf16_t*)dout; p.v_raw = (const bf16_t*)v_raw; p.u_raw = (const bf16_t*)u_raw; p.w2d = (const bf16_t*)w2d;
+  p.g2 = g2; p.be2 = be2; p.g1 = g1; p.be1 = be1; p.sa_s = sa_s; p.sa_dg = sa_dg; p.sa_mult = sa_mult;
+  p.dv = (bf16_t*)dv; p.dcat = (bf16_t*)dcat;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.ldo = ldo; p.ldv = d->ldv; p.ldu = d->ldu; p.lddv = d->ldv; p.ldc = ldc;
+  p.tiles_x = (d->W + TILE - 1) / TILE;
+  p.tiles_img = p.tiles_x * ((d->H + TILE - 1) / TILE);
+  p.ntiles = p.tiles_img * d->B;
+  p.eps = d->eps; p.alpha = d->alpha;
+  LnTileArgs& t = p.sc;
+  t.x = (const bf16_t*)sc_raw; t.dy = (const bf16_t*)dsc; t.dx = (bf16_t*)dcat + d->Up; t.gamma = gsc; t.beta = besc;
+  t.M = (int64_t)d->B * d->H * d->W; t.HW = t.M; t.C = d->Oc; t.Cphys = d->Oc; t.G = 1;
+  t.ldx = d->ldsc; t.lddy = lddsc; t.lddx = ldc; t.eps = d->eps; t.alpha = d->alpha;
+  p.sc_tiles = (int)((t.M + 63) / 64);
+  hipStream_t s = (hipStream_t)stream;
+  switch (cfg) {
+    case 0: return launch_bwd<32, 3, 10, 64>(p, dg2, dbe2, db2, dg1, dbe1, db1, dgsc, dbesc, dbsc, ws, s);
+    case 1: return launch_bwd<64, 7, 21, 128>(p, dg2, dbe2, db2, dg1, dbe1, db1, dgsc, dbesc, dbsc, ws, s);
+    case 2: return launch_bwd<128, 14, 42, 256>(p, dg2, dbe2, db2, dg1, dbe1, db1, dgsc, dbesc, dbsc, ws, s);
+    default: return launch_bwd<256, 28, 85, 512>(p, dg2, dbe2, db2, dg1, dbe1, db1, dgsc, dbesc, dbsc, ws, s);
   }
 }

@@ -768,6 +768,24 @@ def cardinal_fwd(x, w1, b1, g1, be1, w2, b2, g2, be2, wsc, bsc, gsc, besc, P, cv
     return u_raw, u, v_raw, y, (rows, tiles, Vp), sc_raw, sc
 
 
+def cardinal_bwd(dout, dsc, v_raw, u_raw, sc_raw, w2d, g2, be2, g1, be1, gsc, besc, sa_s, sa_dg, sa_mult, dv, dcat, grads, Cin, P, cv11, cvkk, Up,
+                 Vp, Oc, eps, alpha):
+    """One launch for the backward pass of ``cardinal_fwd``'s chain (GradientTape through ResNest.py:136-147 and :100-101): the split-attention
+    re-weighting's backward (``sa_mult*sa_s*dout + sa_dg``) + conv2_bn backward -> ``dv``; grouped 3x3 backward-data; conv1_bn backward ->
+    ``dcat[..., :Up]``; shortcut norm backward of ``dsc`` -> ``dcat[..., Up:]``.  ``grads`` = (dg2, dbe2, db2, dg1, dbe1, db1, dgsc, dbesc,
+    dbsc) accumulate.  -> (dv, dcat)"""
+    B, H, W, _, ldo = geom(dout)
+    d = cardinal_desc(B, H, W, Cin, P, cv11, cvkk, Up, Vp, Oc, Cin, geom(u_raw)[4], geom(v_raw)[4], geom(sc_raw)[4], eps, alpha)
+    assert geom(dv)[4] == d.ldv and dcat.shape[-1] >= Up + Oc
+    g2, be2, g1, be1, gsc, besc = (_readable(t, n) for t, n in ((g2, P * cvkk), (be2, P * cvkk), (g1, P * cv11), (be1, P * cv11), (gsc, Oc), (besc, Oc)))
+    L.check(L.load().usseg_cardinal_bwd(C.byref(d), dout.data_ptr(), ldo, dsc.data_ptr(), geom(dsc)[4], v_raw.data_ptr(), u_raw.data_ptr(),
+                                        sc_raw.data_ptr(), w2d.data_ptr(), g2.data_ptr(), be2.data_ptr(), g1.data_ptr(), be1.data_ptr(),
+                                        gsc.data_ptr(), besc.data_ptr(), sa_s.data_ptr(), sa_dg.data_ptr(), float(sa_mult), dv.data_ptr(),
+                                        dcat.data_ptr(), geom(dcat)[4], *[t.data_ptr() for t in grads], reduce_ws(dout.device).data_ptr(),
+                                        _stream()), "cardinal_bwd")
+    return dv, dcat
+
+
 # ------------------------------------------------------------------------------------------------ split attention
 def splitattn_desc(B, HW, P, R, Cg, Hd, ldy, ldo, Cy_phys, Co_phys, mult, norm_mode, eps, act, alpha, use_sigmoid) -> SplitAttnDesc:
     return SplitAttnDesc(B, HW, P, R, Cg, Hd, ldy, ldo, Cy_phys, Co_phys, mult, norm_mode, eps, act, alpha, 1 if use_sigmoid else 0)
