@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
   };
   const bool nv1 = p.NV == 1;
   // two passes so that the table reads of every item are in flight together, then the global loads back to back
-  auto load_xy = [&](int (*tab)[8], uint4 (&rx)[X_IT], uint4 (&ry)[Y_IT]) {
+  // The loads are clamped, NOT masked: a select on a loaded value (`if (!ok) v = 0`) makes the compiler wait for every prefetch load right
+  // behind its issue (s_waitcnt vmcnt(N) + v_cndmask per item, in front of the MFMA phase the loads were meant to fly under).  The validity
+  // bits travel in mx / my and the zeroing happens where the registers are consumed: in front of the LDS stores, after the MFMAs.
+  auto load_xy = [&](int (*tab)[8], uint4 (&rx)[X_IT], uint4 (&ry)[Y_IT], uint32_t& mx, uint32_t& my) {
+    mx = my = 0u;
     int4 ex[X_IT];
     int yorg[Y_IT], yval[Y_IT];
     if (nv1) {      // one patch per group (every image at least 16 pixels wide and 8 high): one entry for all items
@@ -201,16 +205,14 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       const int ly = ex[it].z + ((geo >> 8) & 255), lx = ex[it].w + (geo & 255);
       // bitwise &: with && the compiler evaluates lazily and puts a branch per condition back
       const bool ok = (x_geo[it] >= 0) & x_cok & ((unsigned)ly < (unsigned)p.Hl) & ((unsigned)lx < (unsigned)p.Wl);
-      uint4 v = *reinterpret_cast<const uint4*>(p.x + (ok ? ex[it].x + x_rel[it] : 0));
-      if (!ok) v = make_uint4(0, 0, 0, 0);
-      rx[it] = v;
+      rx[it] = *reinterpret_cast<const uint4*>(p.x + (ok ? ex[it].x + x_rel[it] : 0));
+      mx |= (ok ? 1u : 0u) << it;
     }
 #pragma unroll
     for (int it = 0; it < Y_IT; ++it) {
       const bool ok = (tid + NTHR * it < 128 * YCH) & y_cok & (yval[it] != 0);
-      uint4 v = *reinterpret_cast<const uint4*>(p.dy + (ok ? yorg[it] + y_rel[it] : 0));
-      if (!ok) v = make_uint4(0, 0, 0, 0);
-      ry[it] = v;
+      ry[it] = *reinterpret_cast<const uint4*>(p.dy + (ok ? yorg[it] + y_rel[it] : 0));
+      my |= (ok ? 1u : 0u) << it;
     }
   };
   const uint32_t tmask = (MASKED && p.mask_ch) ? p.tapmask[n0 / p.mask_ch] : 0x1ffu;   // workgroup-uniform
@@ -268,37 +270,43 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       if ((rel & (TB - 1)) == 0) fill_batch(grp);
       __syncthreads();  // patch table ready; also: previous iteration's LDS reads are done
       uint4 rx[X_IT], ry[Y_IT];
-      load_xy(s_tab[rel & (TB - 1)], rx, ry);
+      uint32_t mx, my;
+      load_xy(s_tab[rel & (TB - 1)], rx, ry, mx, my);
 #pragma unroll
       for (int it = 0; it < X_IT; ++it)
-        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = rx[it];
+        if (x_geo[it] >= 0)
+          *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = (mx >> it) & 1u ? rx[it] : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int it = 0; it < Y_IT; ++it)
-        if (tid + NTHR * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = ry[it];
+        if (tid + NTHR * it < 128 * YCH)
+          *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = (my >> it) & 1u ? ry[it] : make_uint4(0, 0, 0, 0);
       __syncthreads();
       compute();
     }
   } else {
     uint4 rx[X_IT], ry[Y_IT];
+    uint32_t mx = 0u, my = 0u;
     if (g_begin < g_end) {
       fill_batch(g_begin);
       __syncthreads();
-      load_xy(s_tab[0], rx, ry);
+      load_xy(s_tab[0], rx, ry, mx, my);
     }
     for (int grp = g_begin; grp < g_end; ++grp) {
       const int rel1 = grp + 1 - g_begin;                 // the next group's slot; a new batch overwrites entries whose last
       int (*nxt)[8] = s_tab[rel1 & (TB - 1)];             // readers finished before the barrier that ended the previous group
 #pragma unroll
       for (int it = 0; it < X_IT; ++it)
-        if (x_geo[it] >= 0) *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = rx[it];
+        if (x_geo[it] >= 0)
+          *reinterpret_cast<uint4*>(&lds_x[((tid + NTHR * it) / XCH) * XS + xq * 8]) = (mx >> it) & 1u ? rx[it] : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int it = 0; it < Y_IT; ++it)
-        if (tid + NTHR * it < 128 * YCH) *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = ry[it];
+        if (tid + NTHR * it < 128 * YCH)
+          *reinterpret_cast<uint4*>(&lds_y[((tid + NTHR * it) / YCH) * YS + yq * 8]) = (my >> it) & 1u ? ry[it] : make_uint4(0, 0, 0, 0);
       const bool more = grp + 1 < g_end;
       if (more && (rel1 & (TB - 1)) == 0) fill_batch(grp + 1);
       __syncthreads();      // this group's tile and the next group's patch table are visible
       if (more) {
-        load_xy(nxt, rx, ry);
+        load_xy(nxt, rx, ry, mx, my);
       }
       compute();
       __syncthreads();      // everyone is done reading the tile before the next stores
