@@ -10,11 +10,12 @@
  * Contract (all functions)
  *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
  *  - the caller owns every buffer, including workspaces; the library allocates no device memory,
- *    never synchronises and never throws.  Process-wide host state it does keep (one process per GPU,
- *    one host thread per device - the threading model of this repo): a thread-local error string;
- *    the queue of deferred finishing reductions of every stream between usseg_defer_begin() and
- *    usseg_defer_end() (defer.hip); the opt-in launch timer of usseg_prof_* (runtime.hip); and the
- *    USSEG_* planner switches, each read from the environment once per process;
+ *    never synchronises and never throws.  Mutable host state is THREAD-LOCAL: the error string; the queue of
+ *    deferred finishing reductions of every stream between usseg_defer_begin() and usseg_defer_end() (defer.hip);
+ *    the opt-in launch timer of usseg_prof_* (runtime.hip) - so host threads that drive different streams do not
+ *    share any of it (a stream's begin / launches / flush / end come from one thread).  The only process-wide state
+ *    is immutable after first use: the USSEG_* planner switches, each read from the environment once (DESIGN.md
+ *    section 4), and the per-kernel "dynamic LDS size set" latches;
  *  - one producer per destination between two flushes is NOT required: deferred finishes that share a
  *    destination are issued as separate, stream-ordered launches (defer.hip);
  *  - all work is enqueued on the hipStream_t passed in (graph-capture safe);

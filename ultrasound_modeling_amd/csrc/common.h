@@ -58,6 +58,12 @@ __device__ __forceinline__ float act_grad(float v, int act, float alpha) {
 // streams tens of MB of stores (the fused softmax + loss kernel went from 36 to 74 us with it).  Ordering comes from data flow
 // instead: the partial is published with a RETURNING agent-scope atomic exchange (executed at the memory side), the ticket
 // increment consumes that return value, and the last workgroup reads the partials with agent-scope atomic loads.
+// All three atomics are RELAXED: under the HIP / LLVM memory model alone this is a data race.  What orders it is the ISA sequence
+// (checked on every build by tools/check_ordered_sum.py, csrc/Makefile isa_check): a returning `global_atomic_swap sc0` executes at the
+// memory side and only then returns; the wave waits for that value (`s_waitcnt vmcnt(0)`) before it issues the ticket's
+// `global_atomic_add`; the last workgroup reads the slots with `global_load_dword sc1` (agent scope: not served from a non-coherent
+// cache level).  A release on the ticket / acquire in the last workgroup would be the portable form; an agent-scope release writes the
+// XCD's L2 back, which is the cost this construction avoids.
 /* USSEG_ACC_FLOATS (usseg.h) = 2 + the largest grid of the kernels that use it */
 __device__ __forceinline__ bool grid_ordered_sum(float block_total /* thread 0 */, float* acc, int nblocks, int bid = -1) {
   __shared__ int s_last;

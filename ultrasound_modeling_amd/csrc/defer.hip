@@ -146,7 +146,7 @@ struct DeferCtx {
   std::vector<RJob> rj;
   std::vector<WJob> wj;
 };
-static std::vector<DeferCtx> g_ctx;   // one per stream between begin and end (a handful at most)
+static thread_local std::vector<DeferCtx> g_ctx;   // per host thread: one entry per stream between begin and end (a handful at most)
 
 static DeferCtx* find_ctx(hipStream_t s) {
   for (auto& c : g_ctx)

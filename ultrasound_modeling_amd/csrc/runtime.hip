@@ -28,8 +28,8 @@ extern "C" int usseg_version(void) { return 1; }
 // ---- opt-in per-launch timing ------------------------------------------------------------------
 #include <vector>
 struct ProfKind { std::vector<hipEvent_t> start, stop; int used = 0; };
-static ProfKind g_prof[3];
-static int g_prof_mask = 0;
+static thread_local ProfKind g_prof[3];      // per host thread, like the deferral queues: two threads driving two streams do not share them
+static thread_local int g_prof_mask = 0;
 
 extern "C" int usseg_prof_enable(int32_t kind_mask, int32_t capacity) {
   USSEG_CHECK_ARG(capacity > 0 && kind_mask > 0 && kind_mask < 4, "prof_enable: bad args");
