@@ -18,9 +18,11 @@ repack) on a synthetic batch of 256x256x1 tiles that is already resident in HBM.
               step.TrainStepDriver / MainParallel.MirroredTrainer code over gloo; its `value` measures nothing ("dry_run": true).
 
 Prints ONE JSON line on rank 0 (see the keys below).  Extra objects:
-  roofline     - the dominant kernel family (the conv kernels that run every conv / tconv forward and
-                 backward-data pass): algorithmic FLOPs of its launches in one step / the summed duration of
-                 those launches, measured with HIP events recorded by the library on the launch stream.
+  roofline     - the dominant kernel family (the conv kernels that run every plain conv / tconv forward and
+                 backward-data launch): algorithmic FLOPs of those launches in one step / their summed duration,
+                 measured with HIP events recorded by the library on the launch stream.  `fused_tiles` times the
+                 fused tile kernels (cardinal forward / backward, stem forward: convs + norms + activations in one
+                 launch) with the conv FLOPs they carry, `family` is both together, `wgrad` the weight gradients.
   cpu_baseline - the CPU oracle (a PyTorch-CPU fp32 restatement of the reference path; TensorFlow, hence the
                  reference itself, cannot run here) timed on this box's host cores on a bounded sample.
 """
@@ -67,7 +69,7 @@ def algorithmic_flops(net, arch):
     of the conv / tconv layers for the batch of the last forward pass: (forward, igemm family = fwd + dgrad actually run, wgrad)."""
     from ultrasound_modeling_amd.layers import Conv2D
     from ultrasound_modeling_amd import ops
-    fwd = igemm = 0.0
+    fwd = igemm = fused = 0.0     # fused: the part of `igemm` that runs inside the fused tile kernels (cardinal fwd / bwd, stem fwd)
     attain = [0.0]      # seconds the fwd + dgrad launches would take on their own rooflines: max(FLOPs / MFMA peak, min bytes / HBM)
 
     def roof(f, M, cin, cout, passes):
@@ -78,8 +80,21 @@ def algorithmic_flops(net, arch):
         from ultrasound_modeling_amd.ResNest import residual_S
         root = net
         first = net.transformer.embeddings.hybrid_model.conv1
+        from ultrasound_modeling_amd import ResNest as _RN
+        enc = net.transformer.embeddings.hybrid_model
+        fused_ids = {}      # id(conv) -> passes of it (forward = 1, backward-data = 1) that run inside a fused tile kernel
+        if getattr(enc, "_stem_fused", False):
+            fused_ids.update({id(enc.conv1): 1, id(enc.convtmp_1): 1, id(enc.convtmp_2): 1})
         for m in net.modules():
             if isinstance(m, residual_S):
+                g_ = m._group
+                x_ = g_._saved[0]
+                if g_.fused_ok(m.convtmp_sc):      # forward: grouped 1x1 + grouped 3x3 + shortcut 1x1 in usseg_cardinal_fwd
+                    bwd_in = (_RN._FUSED_CARDINAL_BWD and m.wcat_d is not None and x_.shape[0] * x_.shape[1] * x_.shape[2] < _RN._CARD_BWD_MAX_PX)
+                    fused_ids[id(m.convtmp_sc)] = 1
+                    for c in g_.cards:
+                        fused_ids[id(c.conv1)] = 1
+                        fused_ids[id(c.conv2)] = 2 if bwd_in else 1      # + the grouped 3x3's backward-data pass in usseg_cardinal_bwd
                 groups.append((m._group._saved[0], [(c.conv1, c.conv2) for c in m._group.cards]))
                 for c in m._group.cards:
                     managed.update((id(c.split.dense1), id(c.split.dense2)))
@@ -98,6 +113,9 @@ def algorithmic_flops(net, arch):
         f2 = sum(2.0 * M * c2.k * c2.k * c2.cin * c2.cout for _, c2 in pairs)
         fwd += f1 + f2
         igemm += 2 * (f1 + f2)
+        if arch == "B":
+            fused += sum(2.0 * M * c1.cin * c1.cout * fused_ids.get(id(c1), 0) for c1, _ in pairs)
+            fused += sum(2.0 * M * c2.k * c2.k * c2.cin * c2.cout * fused_ids.get(id(c2), 0) for _, c2 in pairs)
         roof(f1, M, pairs[0][0].cin, sum(c1.cout for c1, _ in pairs), 2)
         roof(f2, M, sum(c2.cin for _, c2 in pairs), sum(c2.cout for _, c2 in pairs), 2)
         for c1, c2 in pairs:
@@ -108,9 +126,12 @@ def algorithmic_flops(net, arch):
             f = 2.0 * Bx * Hx * Wx * m.k * m.k * m.cin * m.cout
             fwd += f
             igemm += f if m is first else 2 * f      # the first layer needs no input gradient
+            if arch == "B":
+                fused += f * fused_ids.get(id(m), 0)
             Mo = Bx * Hx * Wx * (4 if getattr(m, "transposed", False) else 1)
             roof(f, 0.5 * (Bx * Hx * Wx + Mo), m.cin, m.cout, 1 if m is first else 2)
     algorithmic_flops.attainable_s = attain[0]
+    algorithmic_flops.fused = fused
     return fwd, igemm, fwd
 
 
@@ -481,7 +502,7 @@ def main():
         side_saved, _ops._Side.enabled = _ops._Side.enabled, False   # per-kernel durations: no weight-gradient launches running beside them
         lazy_saved, _ops._LAZY = _ops._LAZY, False
         xp, yp = net._prep_x(x), net._prep_y(y)
-        _lib.check(lib.usseg_prof_enable(3, 4096 * P), "prof_enable")
+        _lib.check(lib.usseg_prof_enable(7, 4096 * P), "prof_enable")
         for _ in range(P):
             net._train_body(xp, yp)
         torch.cuda.synchronize()
@@ -491,23 +512,34 @@ def main():
         ig_ms, ig_n = ms.value / P, n.value // P
         _lib.check(lib.usseg_prof_read(2, ctypes.byref(ms), ctypes.byref(n)), "prof_read")
         wg_ms, wg_n = ms.value / P, n.value // P
+        _lib.check(lib.usseg_prof_read(4, ctypes.byref(ms), ctypes.byref(n)), "prof_read")
+        fu_ms, fu_n = ms.value / P, n.value // P
         lib.usseg_prof_disable()
         fwd_f, ig_f, wg_f = algorithmic_flops(net, arch)
         net._graph, net.grad_sync = net._graph_saved, sync_saved
-        achieved = ig_f / (ig_ms * 1e-3) / 1e12
-        roofline = {"kernel": "conv family: conv_stream_kernel / conv_big_kernel / igemm_dma_kernel / igemm_kernel / conv_halo_kernel / cardinal_fwd_kernel (every conv + "
-                              "tconv forward and backward-data launch, single stream; the fused cardinal launch carries its LayerNorms too)", "bound": "mfma", "achieved": round(achieved, 2),
+        fu_f = algorithmic_flops.fused
+        cv_f = ig_f - fu_f                      # FLOPs of the plain conv launches (what `frac` prices: comparable with rounds 1-2)
+        achieved = cv_f / (ig_ms * 1e-3) / 1e12
+        roofline = {"kernel": "conv_stream_kernel / conv_big_kernel / igemm_dma_kernel / igemm_kernel / conv_halo_kernel: every plain conv + tconv forward and "
+                              "backward-data launch (single stream).  The fused tile kernels (cardinal_fwd / cardinal_bwd / stem_fwd: convs + LayerNorm / "
+                              "BatchNorm + activation in one launch) are timed separately in `fused_tiles`; `family` is both together",
+                    "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
-                    "algorithmic_gflop_per_step": round(ig_f / 1e9, 2), "kernel_ms_per_step": round(ig_ms, 3),
+                    "algorithmic_gflop_per_step": round(cv_f / 1e9, 2), "kernel_ms_per_step": round(ig_ms, 3),
+                    "fused_tiles": {"launches_per_step": fu_n, "kernel_ms_per_step": round(fu_ms, 3), "algorithmic_gflop_per_step": round(fu_f / 1e9, 2),
+                                    "achieved": round(fu_f / max(fu_ms * 1e-3, 1e-12) / 1e12, 2),
+                                    "note": "conv FLOPs only; these launches also do the norms / activations / pools that were separate passes"},
+                    "family": {"launches_per_step": ig_n + fu_n, "kernel_ms_per_step": round(ig_ms + fu_ms, 3), "algorithmic_gflop_per_step": round(ig_f / 1e9, 2),
+                               "achieved": round(ig_f / ((ig_ms + fu_ms) * 1e-3) / 1e12, 2)},
                     "wgrad": {"launches_per_step": wg_n, "kernel_ms_per_step": round(wg_ms, 3),
                               "achieved": round(wg_f / (wg_ms * 1e-3) / 1e12, 2), "algorithmic_gflop_per_step": round(wg_f / 1e9, 2)},
                     "fwd_gflop_per_image": round(fwd_f / per_gpu / 1e9, 3),
                     # time-weighted: what the same launches would take if each ran on its own roofline (HBM-bound stem /
                     # stage-1 layers priced on bytes, the deep ones on FLOPs) over what they took
                     "attainable_ms_per_step": round(algorithmic_flops.attainable_s * 1e3, 3),
-                    "frac_of_attainable": round(algorithmic_flops.attainable_s * 1e3 / max(ig_ms, 1e-9), 4)}
-        roofline["traffic"] = pmc_traffic(arch, per_gpu, ig_n)
+                    "frac_of_attainable": round(algorithmic_flops.attainable_s * 1e3 / max(ig_ms + fu_ms, 1e-9), 4)}
+        roofline["traffic"] = pmc_traffic(arch, per_gpu, ig_n + fu_n)
         roofline["mfma_busy_frac"] = pmc_mfma(arch)
         roofline["layers"] = layer_probe(dev)
 

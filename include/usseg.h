@@ -627,7 +627,8 @@ int usseg_flash_attn_bwd(const UssegFlashDesc* d, const void* q, const void* k, 
 
 /* ---- opt-in per-launch timing (bench.py roofline leg) ------------------------------------------
  * When enabled, every launch of the selected kernel family is bracketed by hipEventRecord on ITS stream.
- * kinds: 1 = gather implicit-GEMM (conv/tconv fwd + dgrad), 2 = weight-gradient GEMM.  Events are created by
+ * kinds (bits): 1 = conv / tconv forward + backward-data launches, 2 = weight-gradient launches, 4 = fused tile kernels (usseg_cardinal_fwd /
+ * _bwd, usseg_stem_fwd: convs AND their norms in one launch).  Events are created by
  * usseg_prof_enable (never inside a launch function); usseg_prof_read synchronises the recorded events and
  * returns the summed duration and the launch count.  Not graph-capture safe: disable before capturing. */
 int usseg_prof_enable(int32_t kind_mask, int32_t capacity);

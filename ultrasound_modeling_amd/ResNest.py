@@ -446,8 +446,9 @@ class ResNest(nn.Module):
                                                      bn2.moving_mean_p, bn2.moving_variance_p, bn2.eps, a)
             self.conv1._x, self.convtmp_1._x, self.convtmp_2._x = x, self._y1, self._t1
             bn2._x, bn2._act = c2, (ACT_LRELU, a)
-            self._pool_fused = True
+            self._pool_fused = self._stem_fused = True
             return self._stages_forward(t, o1, o2, o3)
+        self._stem_fused = False
         self._y1 = self.conv1.forward(x, act=ACT_LRELU, alpha=a)                                  # :39-40
         self._pool_fused = False
         if self._fold:   # :41-43: convtmp_1bn's scale sits in the packed operand, its shift is the bias, LeakyReLU in the epilogue

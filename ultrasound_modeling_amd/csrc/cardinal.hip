@@ -529,9 +529,9 @@ int launch_fwd(const CardFwd& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)cardinal_fwd_kernel<CIN, CV11, CVKK, OC>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_B);
     attr_done = true;
   }
-  const int slot = usseg_prof_start(1, s);       // counted with the conv family (it replaces three of its launches per stage)
+  const int slot = usseg_prof_start(4, s);       // timed as a fused tile kernel (usseg_prof kind 4): convs + norms in one launch
   hipLaunchKernelGGL((cardinal_fwd_kernel<CIN, CV11, CVKK, OC>), dim3(p.ntiles, p.B, 2), dim3(256), Cfg::LDS_B, s, p);
-  usseg_prof_stop(1, slot, s);
+  usseg_prof_stop(4, slot, s);
   return usseg_check_launch("cardinal_fwd");
 }
 
@@ -1195,9 +1195,9 @@ int launch_bwd(CardBwd& p, float* dg2, float* dbe2, float* db2, float* dg1, floa
   p.ws2 = usseg_defer_reduce_ws(s, caller_ws, n2);
   p.ws1 = usseg_defer_reduce_ws(s, caller_ws + n2, n1);
   p.sc.ws = usseg_defer_reduce_ws(s, caller_ws + n2 + n1, nsc);
-  const int slot = usseg_prof_start(1, s);       // counted with the conv family like the forward launch (it carries the grouped 3x3 backward-data pass)
+  const int slot = usseg_prof_start(4, s);       // timed as a fused tile kernel (kind 4)
   hipLaunchKernelGGL((cardinal_bwd_kernel<CIN, CV11, CVKK, OC>), dim3(2 * G), dim3(256), Cfg::LDS_B, s, p);
-  usseg_prof_stop(1, slot, s);
+  usseg_prof_stop(4, slot, s);
   usseg_launch_reduce_finish(p.ws2, 1, G, 3, VP, Cfg::V, 1.f, dg2, dbe2, db2, s, 0);
   usseg_launch_reduce_finish(p.ws1, 1, G, 3, UP, Cfg::U, 1.f, dg1, dbe1, db1, s, 0);
   usseg_launch_reduce_finish(p.sc.ws, 1, G, 3, OC, OC, 1.f, dgsc, dbesc, dbsc, s, 0);

@@ -28,13 +28,14 @@ extern "C" int usseg_version(void) { return 1; }
 // ---- opt-in per-launch timing ------------------------------------------------------------------
 #include <vector>
 struct ProfKind { std::vector<hipEvent_t> start, stop; int used = 0; };
-static thread_local ProfKind g_prof[3];      // per host thread, like the deferral queues: two threads driving two streams do not share them
+static thread_local ProfKind g_prof[5];      // kinds are bits: 1 conv forward / backward-data, 2 weight gradients, 4 fused tile kernels (cardinal, stem)
+//      // per host thread, like the deferral queues: two threads driving two streams do not share them
 static thread_local int g_prof_mask = 0;
 
 extern "C" int usseg_prof_enable(int32_t kind_mask, int32_t capacity) {
-  USSEG_CHECK_ARG(capacity > 0 && kind_mask > 0 && kind_mask < 4, "prof_enable: bad args");
+  USSEG_CHECK_ARG(capacity > 0 && kind_mask > 0 && kind_mask < 8, "prof_enable: bad args");
   usseg_prof_disable();
-  for (int k = 1; k <= 2; ++k) {
+  for (int k = 1; k <= 4; k <<= 1) {
     if (!(kind_mask & k)) continue;
     g_prof[k].start.resize(capacity);
     g_prof[k].stop.resize(capacity);
@@ -52,7 +53,7 @@ extern "C" int usseg_prof_enable(int32_t kind_mask, int32_t capacity) {
 
 extern "C" int usseg_prof_disable(void) {
   g_prof_mask = 0;
-  for (int k = 1; k <= 2; ++k) {
+  for (int k = 1; k <= 4; k <<= 1) {
     for (auto e : g_prof[k].start) (void)hipEventDestroy(e);
     for (auto e : g_prof[k].stop) (void)hipEventDestroy(e);
     g_prof[k].start.clear();
@@ -63,7 +64,7 @@ extern "C" int usseg_prof_disable(void) {
 }
 
 extern "C" int usseg_prof_read(int32_t kind, double* total_ms, int64_t* launches) {
-  USSEG_CHECK_ARG((kind == 1 || kind == 2) && total_ms && launches, "prof_read: bad args");
+  USSEG_CHECK_ARG((kind == 1 || kind == 2 || kind == 4) && total_ms && launches, "prof_read: bad args");
   ProfKind& p = g_prof[kind];
   double tot = 0.0;
   for (int i = 0; i < p.used; ++i) {

@@ -245,8 +245,8 @@ extern "C" int usseg_stem_fwd(int32_t B, int32_t H, int32_t W, const void* x, in
     attr_done = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int slot = usseg_prof_start(1, s);
+  const int slot = usseg_prof_start(4, s);
   hipLaunchKernelGGL(stem_fwd_kernel, dim3(p.ntiles, B), dim3(256), LDS_B, s, p);
-  usseg_prof_stop(1, slot, s);
+  usseg_prof_stop(4, slot, s);
   return usseg_check_launch("stem_fwd");
 }
