@@ -480,6 +480,9 @@ int usseg_quad_bias_expand(const float* bias, int32_t C, int32_t Np, float* out 
 int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, usseg_stream_t stream);
 int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t Np, int32_t ksize, float* grad,
                             usseg_stream_t stream);
+/* usseg_tconv_quad_unpack + usseg_quad_bias_fold (with d16 = [4][Np] column sums) as ONE launch: the tail of the quad-form head's backward. */
+int usseg_quad_head_fold(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t Np, int32_t ksize, float* grad, const float* d16,
+                         float* dbias, usseg_stream_t stream);
 /* General quad-form transposed conv (any channel count; Np = physical output channels per parity class, the 16 of the head = 4*4):
  * y4 / dy4 are [B,H,W,4*Np] space-to-depth tensors of the [B,2H,2W,Np] output (usseg_space_to_depth2 converts either way);
  * the descriptor is that of the 3x3 stride-1 conv (ksize 3, Cout = 4*Np).  Each parity class only uses <= 2x2 of the nine stencil

@@ -173,6 +173,7 @@ _PROTOS = {
     "usseg_tconv_quad_wgrad": (C.c_int, [P(ConvDesc), c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "usseg_quad_bias_fold": (C.c_int, [c_vp, c_i32, c_vp, c_vp]),
     "usseg_tconv_quad_unpack": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "usseg_quad_head_fold": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "usseg_label2vec": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "usseg_augment": (C.c_int, [P(AugDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_loss_cat_scale": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -1265,6 +1265,33 @@ extern "C" int usseg_quad_bias_fold(const float* d16, int32_t C, float* dbias, u
   hipLaunchKernelGGL(quad_bias_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d16, C, dbias);
   return usseg_check_launch("quad_bias_fold");
 }
+// the head's two folds in one launch: kernel gradient (every workgroup) + bias gradient (workgroup 0)
+__global__ __launch_bounds__(256) void quad_head_fold_kernel(const float* dq, int Cin_phys, int Cin, int Cout, float* grad, int k, int Np, const float* d16,
+                                                             float* dbias) {
+  const int total = k * k * Cout * Cin, pad = k == 4 ? 1 : 0;
+  if (blockIdx.x == 0 && threadIdx.x < Cout) {
+    const int n = threadIdx.x;
+    dbias[n] += d16[n] + d16[Np + n] + d16[2 * Np + n] + d16[3 * Np + n];
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int c = i % Cin, r = i / Cin;
+    int n = r % Cout, kk = r / Cout;
+    int kh = kk / k, kw = kk - k * kh;
+    int a = (kh + pad) & 1, b = (kw + pad) & 1;
+    int di = (a + pad - kh) / 2, dj = (b + pad - kw) / 2;
+    int t = (di + 1) * 3 + (dj + 1);
+    grad[i] += dq[((int64_t)t * Cin_phys + c) * (4 * Np) + (a * 2 + b) * Np + n];
+  }
+}
+extern "C" int usseg_quad_head_fold(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t Np, int32_t ksize, float* grad,
+                                    const float* d16, float* dbias, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(dq && grad && d16 && dbias && Cin >= 1 && Cin <= Cin_phys && Cout >= 1 && Cout <= Np && Cout <= 256 && (ksize == 3 || ksize == 4),
+                  "quad_head_fold: bad args");
+  int g = (ksize * ksize * Cout * Cin + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(quad_head_fold_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dq, Cin_phys, Cin, Cout, grad, ksize, Np, d16, dbias);
+  return usseg_check_launch("quad_head_fold");
+}
 extern "C" int usseg_tconv_quad_unpack(const float* dq, int32_t Cin_phys, int32_t Cin, int32_t Cout, int32_t Np, int32_t ksize, float* grad,
                                        usseg_stream_t stream) {
   USSEG_CHECK_ARG(dq && grad && Cin >= 1 && Cin <= Cin_phys && Cout >= 1 && Cout <= Np && (ksize == 3 || ksize == 4), "tconv_quad_unpack: bad args");

@@ -301,8 +301,7 @@ class QuadHead:
             ops.colsum(dl4, self.d16, 16)
 
             def fold():     # dq / d16 are complete once the deferred finishing reductions have run: fold them into the Keras variables then
-                ops.tconv_quad_unpack(self.dq, h.cin_p, h.cin, h.cout, 4, h.k, h.kernel.grad)
-                ops.quad_bias_fold(self.d16, h.cout, h.bias.grad)
+                ops.quad_head_fold(self.dq, h.cin_p, h.cin, h.cout, 4, h.k, h.kernel.grad, self.d16, h.bias.grad)
             ops.after_flush(fold)
         ops.wgrad_later(params, x, dl4)
         if not need_dx:

@@ -908,6 +908,12 @@ def tconv_quad_unpack(dq, Cin_phys, Cin, Cout, Np, ksize, grad):
     L.check(L.load().usseg_tconv_quad_unpack(dq.data_ptr(), Cin_phys, Cin, Cout, Np, ksize, grad.data_ptr(), _stream()), "tconv_quad_unpack")
 
 
+def quad_head_fold(dq, Cin_phys, Cin, Cout, Np, ksize, grad, d16, dbias):
+    """tconv_quad_unpack + quad_bias_fold in one launch (the tail of the quad-form head's backward)."""
+    L.check(L.load().usseg_quad_head_fold(dq.data_ptr(), Cin_phys, Cin, Cout, Np, ksize, grad.data_ptr(), d16.data_ptr(), dbias.data_ptr(), _stream()),
+            "quad_head_fold")
+
+
 def loss_cat_scale(y_true, scale):
     B, H, W, Cc = y_true.shape
     L.check(L.load().usseg_loss_cat_scale(y_true.data_ptr(), B, H * W, Cc, scale.data_ptr(), _stream()), "loss_cat_scale")
