@@ -34,7 +34,13 @@ from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 # already fused with the pool that follows it)
 # per-stage lazy weight gradients in the encoder's backward pass: off - the side stream already carries the decoder's (and the ViT
 # blocks') weight gradients beside this encoder, and more forks made Arch B 1 % and cfg4 3 % slower
-_STAGE_LAZY = os.environ.get("USSEG_ENC_LAZY", "0") != "0"
+# bit s-1: the weight gradients of encoder stage s run on the side stream beside the next stage's backward-data chain (ops.lazy_wgrads).
+# Default 12 = the 16x16 and 32x32 stages (their launches are latency-bound and overlap well: 3.010 -> 2.984 ms); stage 2 or 1 on the side
+# stream costs more than it hides (3.03 / 3.06 ms), all four 3.12 ms - the side stream still carries the decoder's weight gradients then.
+# (with the ViT bottleneck - TBI_TransUNet.py, 512x512 - the side stream carries the ViT's weight gradients instead and 12 is 2.5 % slower than 0:
+# the wrapper sets ``ResNest.stage_lazy`` to 0 there.)  USSEG_ENC_LAZY overrides both.
+_STAGE_LAZY_ENV = os.environ.get("USSEG_ENC_LAZY")
+_STAGE_LAZY = int(_STAGE_LAZY_ENV) if _STAGE_LAZY_ENV is not None else 12
 _FOLD_BN = os.environ.get("USSEG_FOLD_BN", "1") != "0"
 # the cardinal group + shortcut of a stage as ONE launch (csrc/cardinal.hip); 0 = the six unfused launches (the cross-check of the tests)
 _FUSED_CARDINAL = os.environ.get("USSEG_FUSED_CARDINAL", "1") != "0"
@@ -476,17 +482,18 @@ class ResNest(nn.Module):
         d_x3, d_x2, d_x1 = d_feats
         # the pool backward in front of a stage also sums its output over the pixels: that stage's concats_2 bias gradient
         # each stage's weight gradients run on the side stream beside the next stage's backward-data chain (ops.lazy_wgrads)
-        lazy = ops.lazy_wgrads if _STAGE_LAZY else contextlib.nullcontext
-        with lazy():
+        mask = getattr(self, "stage_lazy", _STAGE_LAZY)
+        lazy = lambda st: ops.lazy_wgrads() if (mask >> (st - 1)) & 1 else contextlib.nullcontext()
+        with lazy(4):
             d = self.conv_4.backward(d_x4)
         d = self.conv4_pool.backward(d, add=d_x3, db=self.conv_3.concats_2.bias.grad)
-        with lazy():
+        with lazy(3):
             d = self.conv_3.backward(d, bias_done=True)
         d = self.conv3_pool.backward(d, add=d_x2, db=self.conv_2.concats_2.bias.grad)
-        with lazy():
+        with lazy(2):
             d = self.conv_2.backward(d, bias_done=True)
         d = self.conv2_pool.backward(d, add=d_x1, db=self.conv_1.concats_2.bias.grad)
-        with lazy():
+        with lazy(1):
             d = self.conv_1.backward(d, bias_done=True)
         a = KERAS_LRELU_ALPHA
         if self._pool_fused:

@@ -75,6 +75,7 @@ class Embeddings(nn.Module):
         # :100; TBI_TransUNet.py:107 builds its own copy: BatchNormalization for LayerNormalization and a 256-channel conv_4 (:368)
         norm, widths = ("bn", (64, 128, 256, 256)) if transunet else ("ln", (64, 128, 256, 512))
         self.hybrid_model = ResNest(img_size[0], img_size[1], in_channels, radix=3, ksize=3, kpaths=3, norm=norm, widths=widths)
+        self.hybrid_model.stage_lazy = _ENC._STAGE_LAZY           # (Transformer.__init__ clears it when a ViT follows the embedding)
         self.patch_embeddings = Conv2D(widths[3], hidden_size, 1, init="glorot")                          # :106
 
     def forward(self, x, feature_slots=None):
@@ -281,6 +282,8 @@ class Transformer(nn.Module):
         super().__init__()
         self.embeddings = Embeddings(img_size=img_size, in_channels=in_channels, transunet=transunet)
         self.encoder = Encoder(img_size[0], img_size[1], wDecay=wDecay) if use_vit else None
+        if self.encoder is not None and _ENC._STAGE_LAZY_ENV is None:
+            self.embeddings.hybrid_model.stage_lazy = 0       # the side stream carries the ViT's weight gradients (ResNest.py of this repo, _STAGE_LAZY)
 
     def forward(self, input_ids, feature_slots=None, need_weights=True):
         embedding_output, features = self.embeddings.forward(input_ids, feature_slots)
