@@ -37,6 +37,18 @@ def test_bad_arguments_return_errors_without_touching_a_gpu():
     assert lib.usseg_conv2d_fwd(C.byref(d), 16, 16, None, None, 0, 16, None) == -1
     with pytest.raises(_lib.UssegError):
         _lib.check(-1, "conv2d_fwd")
+    # the fused stage entry points: an unsupported channel configuration and a null pointer are argument errors, not launches
+    cd = _lib.CardinalDesc(1, 8, 8, 48, 3, 3, 10, 16, 32, 64, 48, 16, 32, 64, 1e-3, 0.3)      # Cin = 48: no fused instantiation
+    assert lib.usseg_cardinal_supported(C.byref(cd)) == 0
+    args21 = [16] * 21
+    assert lib.usseg_cardinal_fwd(C.byref(cd), *args21) == -1 and b"no fused kernel" in lib.usseg_last_error()
+    cd = _lib.CardinalDesc(1, 8, 8, 32, 3, 3, 10, 16, 32, 64, 32, 16, 32, 64, 1e-3, 0.3)
+    assert lib.usseg_cardinal_supported(C.byref(cd)) == 1
+    bwd = [16, 32, 16, 64] + [16] * 12 + [3.0, 16, None, 80] + [16] * 11            # dcat is NULL
+    assert lib.usseg_cardinal_bwd(C.byref(cd), *bwd) == -1 and b"null pointer" in lib.usseg_last_error()
+    bwd[18] = 16
+    bwd[19] = 72                                                                     # ldc < Up + Oc
+    assert lib.usseg_cardinal_bwd(C.byref(cd), *bwd) == -1 and b"strides" in lib.usseg_last_error()
 
 
 def test_product_has_no_cpu_fallback():
