@@ -266,6 +266,14 @@ int usseg_norm_act_fwd_gap(const UssegNormDesc* d, const void* x, const float* g
 int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, const void* dout, const float* gamma, const float* beta,
                           const float* mean, const float* var, int32_t B, const float* sa_s, const float* sa_dg, float sa_mult,
                           void* dx, float* dgamma, float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
+/* Two INDEPENDENT LayerNormalization + LeakyReLU backward passes as ONE launch: A plain (a residual_S stage's shortcut norm, ResNest.py:100-101),
+ * B with the split-attention re-weighting's backward folded in as in usseg_norm_act_bwd_sa (conv2_bn, ResNest.py:143-144 behind :194-197).
+ * Same results as the two calls (bitwise: the same tile kernel runs both roles).  USSEG_ERR_UNSUPPORTED, and nothing launched, when the pair
+ * has no instantiation (channel widths other than a stage of ResNest.py, tensors below 32k pixels): the caller then makes the two calls. */
+int usseg_norm_act_bwd_pair(const UssegNormDesc* da, const void* xa, const void* dya, const float* gamma_a, const float* beta_a, void* dxa,
+                            float* dgamma_a, float* dbeta_a, float* dbias_a, const UssegNormDesc* db, const void* xb, const void* doutb,
+                            const float* gamma_b, const float* beta_b, int32_t B, const float* sa_s, const float* sa_dg, float sa_mult, void* dxb,
+                            float* dgamma_b, float* dbeta_b, float* dbias_b, float* ws, usseg_stream_t stream);
 /* The encoder stem as ONE launch (ResNest.py:39-47): Conv2D(1->16) + LeakyReLU -> Conv2D(16->32) + inference BatchNormalization (its scale
  * folded into the packed operand w2, its shift = b2) + LeakyReLU -> Conv2D(32->32) -> BatchNormalization + LeakyReLU -> AveragePooling2D(2,2).
  * x [B,H,W,8 physical channels]; w1 [16][72], w2 [32][144], w3 [32][288]: the packed forward operands of usseg_conv2d_fwd; b1 [16], b2 [32],

@@ -1016,3 +1016,38 @@ def test_fused_cardinal_backward_equals_the_unfused_launches(gen, cin, cv11, cvk
     names = ("dgamma2", "dbeta2", "dbias2", "dgamma1", "dbeta1", "dbias1", "dgamma_sc", "dbeta_sc", "dbias_sc")
     for nm, f_, u_ in zip(names, gf, gu):
         assert rel(f_, u_) < (2e-3 if "1" in nm else 1e-4), (nm, rel(f_, u_))
+
+
+@pytest.mark.parametrize("oc,cvkk,B,H,W", [(64, 10, 2, 128, 128), (128, 21, 4, 96, 96), (64, 10, 1, 64, 64)])
+def test_paired_layernorm_backward_is_the_bits_of_the_two_launches(gen, oc, cvkk, B, H, W):
+    """usseg_norm_act_bwd_pair (the shortcut norm's backward and conv2_bn's backward with the re-weighting folded in, one launch, two workgroup
+    roles on the same tile loop) against the two launches it replaces: dx tensors and the six gradient vectors are bit-identical; a pair without
+    an instantiation (here: fewer than 32k pixels) reports False and launches nothing."""
+    from ultrasound_modeling_amd import ops
+    P, V = 3, 3 * cvkk
+    Vp = (V + 7) // 8 * 8
+    bfz = lambda *s: torch.randn(*s, generator=gen).to(torch.bfloat16)
+    xa, dya = bfz(B, H, W, oc).to(DEV), bfz(B, H, W, oc).to(DEV)
+    xb = torch.zeros(B, H, W, Vp, dtype=torch.bfloat16)
+    xb[..., :V] = bfz(B, H, W, V)
+    db_ = torch.zeros(B, H, W, Vp, dtype=torch.bfloat16)
+    db_[..., :V] = bfz(B, H, W, V)
+    xb, db_ = xb.to(DEV), db_.to(DEV)
+    padv = lambda n, np_, sc, off=0.0: torch.cat([off + sc * torch.randn(n, generator=gen), torch.zeros(np_ - n)]).to(DEV)
+    ga, ba, gb, bb = padv(oc, oc, 0.2, 1.0), padv(oc, oc, 0.1), padv(V, Vp, 0.2, 1.0), padv(V, Vp, 0.1)
+    sa_s, sa_dg = torch.rand(B, V, generator=gen).to(DEV), (0.05 * torch.randn(B, V, generator=gen)).to(DEV)
+    z = lambda n: torch.zeros(n, device=DEV)
+    gp = [z(oc), z(oc), z(oc), z(Vp), z(Vp), z(Vp)]
+    dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+    took = ops.norm_act_bwd_pair(xa, dya, oc, ga, ba, dxa, gp[0], gp[1], gp[2], xb, db_, V, P, gb, bb, dxb, gp[3], gp[4], gp[5], sa_s, sa_dg, 3.0, 1e-3, 0.3)
+    if B * H * W < 32768:
+        assert not took
+        return
+    assert took
+    gu = [z(oc), z(oc), z(oc), z(Vp), z(Vp), z(Vp)]
+    dxa_u = ops.norm_act_bwd(xa, dya, oc, ga, ba, torch.empty_like(xa), gu[0], gu[1], 0, 1, 1e-3, ops.ACT_LRELU, 0.3, dbias=gu[2])
+    dxb_u = ops.norm_act_bwd_sa(xb, db_, V, gb, bb, torch.empty_like(xb), gu[3], gu[4], 0, P, 1e-3, ops.ACT_LRELU, 0.3, sa_s, sa_dg, 3.0, dbias=gu[5])
+    torch.cuda.synchronize()
+    assert torch.equal(dxa, dxa_u) and torch.equal(dxb, dxb_u)
+    for f_, u_ in zip(gp, gu):
+        assert rel(f_, u_) < 1e-5        # (the partial rows are summed over a different number of workgroups)

@@ -49,6 +49,7 @@ _FUSED_CARDINAL_BWD = os.environ.get("USSEG_FUSED_CARDINAL_BWD", "1") != "0"    
 # stage has few tiles per CU (16x16 and 32x32 at batch 16: 49 vs 64 and 58 vs 71 us) and loses to the streaming norm kernels on the large stages
 # (125 vs 66 us at 64x64, 201 vs 92 us at 128x128: 16 rounds of 10-us tiles).
 _CARD_BWD_MAX_PX = int(os.environ.get("USSEG_CARD_BWD_MAX_PX", "32768"))
+_LN_PAIR = os.environ.get("USSEG_LN_PAIR", "1") != "0"      # shortcut norm backward + conv2_bn backward of the large stages in one launch
 _FUSED_STEM = os.environ.get("USSEG_FUSED_STEM", "1") != "0"             # the stem (three convs, two norms, pool) as one launch (csrc/stem.hip)
 _MERGED_DGRAD = os.environ.get("USSEG_MERGED_DGRAD", "1") != "0"     # one backward-data GEMM for a stage's grouped 1x1 and shortcut 1x1
 
@@ -296,9 +297,11 @@ class _CardinalGroup:
                          KERAS_LN_EPS, KERAS_LRELU_ALPHA)
         ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(u, dv, self.k, self.dil, self._maps()[1]), u, dv)
 
-    def backward(self, dout, dx_residual=None, du_raw_out=None):
+    def backward(self, dout, dx_residual=None, du_raw_out=None, shortcut=None):
         """``du_raw_out``: write the gradient w.r.t. the grouped 1x1 conv's output there (a channel slice of the stage's [du_raw | dsc_raw]
-        buffer) and leave the 1x1 backward-data pass to the caller (one GEMM for the cardinal group AND the shortcut: residual_S.backward)."""
+        buffer) and leave the 1x1 backward-data pass to the caller (one GEMM for the cardinal group AND the shortcut: residual_S.backward).
+        ``shortcut`` = (norm layer, dsc, dx slice, conv bias grad): the shortcut norm's backward rides in the same launch as conv2_bn's where the
+        pair has an instantiation (``ops.norm_act_bwd_pair``); otherwise it runs here as its own launch."""
         x, u_raw, u, v_raw, y, g, s, ws = self._saved
         B, H, W, _, _ = ops.geom(x)
         dev = x.device
@@ -307,8 +310,19 @@ class _CardinalGroup:
         d = self._sa_desc(B, H * W)
         # the re-weighting's backward (dy = radix*s*dout + dg) is formed inside the norm backward: no dy tensor, no apply pass
         sa_s, sa_dg = ops.splitattn_bwd(d, y, dout, self._mlp_params(), self.mlp_g, g, s, ws, None)
-        dv = ops.norm_act_bwd_sa(v_raw, dout, self.V, self.g2, self.be2, torch.empty_like(v_raw), self.dg2, self.dbe2, self.nmode, self.ngroups,
-                                 KERAS_LN_EPS, ACT_LRELU, a, sa_s, sa_dg, float(self.radix), *self.st2, dbias=self.db2)
+        dv = torch.empty_like(v_raw)
+        paired = False
+        if shortcut is not None:
+            scn, dsc, dx_sc, dbias_sc = shortcut
+            if _LN_PAIR and not self.bn and scn._act == (ACT_LRELU, a):
+                paired = ops.norm_act_bwd_pair(scn._x, dsc, scn.C, scn.gamma.data, scn.beta.data, dx_sc, scn.gamma.grad, scn.beta.grad, dbias_sc,
+                                               v_raw, dout, self.V, self.ngroups, self.g2, self.be2, dv, self.dg2, self.dbe2, self.db2, sa_s, sa_dg,
+                                               float(self.radix), KERAS_LN_EPS, a)
+            if not paired:
+                scn.backward(dsc, dx=dx_sc, dbias=dbias_sc)
+        if not paired:
+            ops.norm_act_bwd_sa(v_raw, dout, self.V, self.g2, self.be2, dv, self.dg2, self.dbe2, self.nmode, self.ngroups,
+                                KERAS_LN_EPS, ACT_LRELU, a, sa_s, sa_dg, float(self.radix), *self.st2, dbias=self.db2)
         # grouped 3x3: dense wgrad into scratch, keep the diagonal blocks
         # grouped 3x3: the dense [T][Up][Vp] gradient is never materialised - only the diagonal blocks are scattered
         ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(u, dv, self.k, self.dil, self._maps()[1]), u, dv)
@@ -384,8 +398,7 @@ class residual_S(nn.Module):
             if _FUSED_CARDINAL_BWD and g.fused_ok(sc) and B * H * W < _CARD_BWD_MAX_PX:
                 g.backward_fused(d_c1, dout, sc, self.convtmp_scbn, dcat)
             else:
-                self.convtmp_scbn.backward(dout, dx=dcat[..., g.Up:], dbias=sc.bias.grad)
-                g.backward(d_c1, du_raw_out=dcat[..., :g.Up])
+                g.backward(d_c1, du_raw_out=dcat[..., :g.Up], shortcut=(self.convtmp_scbn, dout, dcat[..., g.Up:], sc.bias.grad))
             # x^T . [du_raw | dsc_raw]: the weight gradients of the paths' 1x1 convs and of the shortcut conv in one launch (four mapped blocks)
             ops.wgrad_later(lambda: ops.conv2d_wgrad_mapped(x, dcat, 1, 1, self._wcat_map()), x, dcat)
             return ops.conv2d_dgrad(dcat, self.wcat_d, 1, 1, ops.new_act(B, H, W, g.cin_p, x.device))

@@ -156,6 +156,7 @@ _PROTOS = {
     "usseg_accuracy": (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "usseg_norm_act_bwd_res": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_norm_act_bwd_sa": (C.c_int, [P(NormDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_norm_act_bwd_pair": (C.c_int, [P(NormDesc)] + [c_vp] * 8 + [P(NormDesc)] + [c_vp] * 4 + [c_i32, c_vp, c_vp, c_f32] + [c_vp] * 6),
     "usseg_splitattn_apply_fwd": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_vp, c_vp]),
     "usseg_splitattn_apply_bwd_reduce": (C.c_int, [P(SplitAttnDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "usseg_splitattn_mlp_bwd_ws_floats": (c_i64, [P(SplitAttnDesc)]),

@@ -1204,6 +1204,47 @@ int launch_bwd(CardBwd& p, float* dg2, float* dbe2, float* db2, float* dg1, floa
   return usseg_check_launch("cardinal_bwd");
 }
 
+// Two INDEPENDENT LayerNorm backward passes in one launch (even workgroups: A, odd: B): the shortcut norm's and the conv2_bn (+ split-attention
+// re-weighting) backward of a residual_S stage read different tensors and both stream at 3.5-4 TB/s alone - side by side they share one
+// dispatch (every dispatch that consumes its predecessor's output costs ~5-9 us at batch 16) and fill the memory system better.
+struct LnPair {
+  LnTileArgs a, b;
+  int32_t ntiles_a, ntiles_b, G;
+};
+template <int CPA, int CGA, int NGA, bool FA, int CPB, int CGB, int NGB, bool FB>
+__global__ __launch_bounds__(256) void ln_bwd_pair_kernel(const LnPair P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int blk = blockIdx.x >> 1;
+  if (blockIdx.x & 1) lnb_tile_loop<CPB, CGB, NGB, FB>(P.b, P.ntiles_b, lds, blk, P.G);
+  else lnb_tile_loop<CPA, CGA, NGA, FA>(P.a, P.ntiles_a, lds, blk, P.G);
+#endif
+}
+template <int CPA, int CGA, int NGA, bool FA, int CPB, int CGB, int NGB, bool FB>
+int launch_ln_pair(LnPair& P, float* const* ga, float* const* gb, float* caller_ws, hipStream_t s) {
+  using CA = LnbCfg<CPA, CGA, NGA, FA>;
+  using CB = LnbCfg<CPB, CGB, NGB, FB>;
+  constexpr int LDS = CA::LDS_B > CB::LDS_B ? CA::LDS_B : CB::LDS_B;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)ln_bwd_pair_kernel<CPA, CGA, NGA, FA, CPB, CGB, NGB, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const int per_cu = LDS > 80 * 1024 ? 1 : (LDS > 40 * 1024 ? 2 : 4);      // workgroups of EACH role per CU
+  const int most = P.ntiles_a > P.ntiles_b ? P.ntiles_a : P.ntiles_b;
+  int G = 128 * per_cu;
+  if (G > most) G = most;
+  if (G > USSEG_REDUCE_MAX_BLOCKS) G = USSEG_REDUCE_MAX_BLOCKS;
+  P.G = G;
+  const int64_t na = (int64_t)G * 3 * CA::CPH, nb = (int64_t)G * 3 * CB::CPH;
+  P.a.ws = usseg_defer_reduce_ws(s, caller_ws, na);
+  P.b.ws = usseg_defer_reduce_ws(s, caller_ws + na, nb);
+  hipLaunchKernelGGL((ln_bwd_pair_kernel<CPA, CGA, NGA, FA, CPB, CGB, NGB, FB>), dim3(2 * G), dim3(256), LDS, s, P);
+  usseg_launch_reduce_finish(P.a.ws, 1, G, 3, CA::CPH, P.a.C, 1.f, ga[0], ga[1], ga[2], s, 0);
+  usseg_launch_reduce_finish(P.b.ws, 1, G, 3, CB::CPH, P.b.C, 1.f, gb[0], gb[1], gb[2], s, 0);
+  return 1;
+}
+
 }  // namespace
 
 int usseg_try_ln_bwd_tile(const LnTileArgs& a, float* dgamma, float* dbeta, float* dbias, float* caller_ws, hipStream_t s) {
@@ -1222,6 +1263,22 @@ int usseg_try_ln_bwd_tile(const LnTileArgs& a, float* dgamma, float* dbeta, floa
   LNB(4, 10, 3) LNB(8, 21, 3) LNB(16, 42, 3) LNB(32, 85, 3)       // conv2_bn (:143), also with the split-attention re-weighting folded in
   if (!fuse) { LNB(8, 64, 1) LNB(16, 128, 1) LNB(32, 256, 1) LNB(64, 512, 1) }   // convtmp_scbn (:100), DecoderCup.bn1 (Decoder.py:112)
 #undef LNB
+  return 0;
+}
+
+// A = the shortcut norm (one group of Oc channels), B = conv2_bn with the re-weighting's backward folded in (3 groups of cvkk): the two
+// stages whose tensors are large enough for the tile kernels (ResNest.py stages 1 and 2 at 256x256).  0: no instantiation, nothing launched.
+int usseg_try_ln_bwd_pair(const LnTileArgs& a, float* const* ga, const LnTileArgs& b, float* const* gb, float* caller_ws, hipStream_t s) {
+  static const int off = getenv("USSEG_LN_PAIR") && atoi(getenv("USSEG_LN_PAIR")) == 0;
+  static const int64_t min_px = getenv("USSEG_LN_TILE_MIN") ? atoll(getenv("USSEG_LN_TILE_MIN")) : 32768;
+  if (off || a.M < min_px || b.M < min_px || a.M >= (1ll << 31) || b.M >= (1ll << 31)) return 0;
+  if (a.sa_s || !b.sa_s || b.HW % 64 != 0 || a.G != 1 || b.G != 3) return 0;
+  LnPair P;
+  P.a = a; P.b = b;
+  P.ntiles_a = (int)((a.M + 63) / 64); P.ntiles_b = (int)((b.M + 63) / 64);
+  const int cgb = b.C / 3;
+  if (a.Cphys == 64 && a.C == 64 && b.Cphys == 32 && cgb == 10 && b.C == 30) return launch_ln_pair<8, 64, 1, false, 4, 10, 3, true>(P, ga, gb, caller_ws, s);
+  if (a.Cphys == 128 && a.C == 128 && b.Cphys == 64 && cgb == 21 && b.C == 63) return launch_ln_pair<16, 128, 1, false, 8, 21, 3, true>(P, ga, gb, caller_ws, s);
   return 0;
 }
 

@@ -395,6 +395,8 @@ struct LnTileArgs {
   float eps, alpha;
 };
 int usseg_try_ln_bwd_tile(const LnTileArgs& a, float* dgamma, float* dbeta, float* dbias, float* caller_ws, hipStream_t s);
+// two independent LayerNorm + LeakyReLU backward passes in one launch (cardinal.hip); g* = {dgamma, dbeta, dbias}; 0 if no instantiation
+int usseg_try_ln_bwd_pair(const LnTileArgs& a, float* const* ga, const LnTileArgs& b, float* const* gb, float* caller_ws, hipStream_t s);
 int usseg_prof_start(int kind, hipStream_t s);
 void usseg_prof_stop(int kind, int slot, hipStream_t s);
 

@@ -556,6 +556,38 @@ extern "C" int usseg_norm_act_bwd_sa(const UssegNormDesc* d, const void* x, cons
   return usseg_check_launch("norm_act_bwd_sa");
 }
 
+// Two independent LayerNormalization + LeakyReLU backward passes as ONE launch: A plain (the shortcut norm of a residual_S stage,
+// ResNest.py:100-101), B with the split-attention re-weighting's backward folded in (conv2_bn, :143-144 behind :194-197).  Returns
+// USSEG_ERR_UNSUPPORTED without launching anything when the pair has no instantiation (the caller then issues the two calls).
+extern "C" int usseg_norm_act_bwd_pair(const UssegNormDesc* da, const void* xa, const void* dya, const float* gamma_a, const float* beta_a, void* dxa,
+                                       float* dgamma_a, float* dbeta_a, float* dbias_a, const UssegNormDesc* db, const void* xb, const void* doutb,
+                                       const float* gamma_b, const float* beta_b, int32_t B, const float* sa_s, const float* sa_dg, float sa_mult,
+                                       void* dxb, float* dgamma_b, float* dbeta_b, float* dbias_b, float* ws, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(da && db && xa && dya && gamma_a && beta_a && dxa && dgamma_a && dbeta_a && dbias_a && xb && doutb && gamma_b && beta_b && sa_s && sa_dg &&
+                      dxb && dgamma_b && dbeta_b && dbias_b && ws, "norm bwd pair: null pointer");
+  USSEG_CHECK_ARG(da->mode == 0 && db->mode == 0 && da->act == USSEG_ACT_LRELU && db->act == USSEG_ACT_LRELU && B > 0 && db->M % B == 0 && da->M > 0 && db->M > 0,
+                  "norm bwd pair: LayerNormalization + LeakyReLU only");
+  auto fill = [](const UssegNormDesc* d, const void* x, const void* dy, void* dx, const float* g, const float* b_, LnTileArgs& t) {
+    t = {};
+    t.x = (const bf16_t*)x; t.dy = (const bf16_t*)dy; t.dx = (bf16_t*)dx; t.gamma = g; t.beta = b_;
+    t.M = d->M; t.HW = d->M; t.C = d->C; t.Cphys = d->Cphys; t.G = d->G > 0 ? d->G : 1;
+    t.ldx = d->ldx; t.lddy = d->ldy; t.lddx = d->lddx > 0 ? d->lddx : d->ldx; t.eps = d->eps; t.alpha = d->alpha;
+  };
+  LnTileArgs ta, tb;
+  fill(da, xa, dya, dxa, gamma_a, beta_a, ta);
+  fill(db, xb, doutb, dxb, gamma_b, beta_b, tb);
+  USSEG_CHECK_ARG(ta.ldx % 8 == 0 && ta.lddy % 8 == 0 && ta.lddx % 8 == 0 && tb.ldx % 8 == 0 && tb.lddy % 8 == 0 && tb.lddx % 8 == 0 && ta.lddx >= ta.Cphys &&
+                      tb.lddx >= tb.Cphys, "norm bwd pair: bad strides");
+  tb.HW = db->M / B; tb.sa_s = sa_s; tb.sa_dg = sa_dg; tb.sa_mult = sa_mult; tb.sa_cy = db->C;
+  float* ga[3] = {dgamma_a, dbeta_a, dbias_a};
+  float* gb[3] = {dgamma_b, dbeta_b, dbias_b};
+  if (!usseg_try_ln_bwd_pair(ta, ga, tb, gb, ws, (hipStream_t)stream)) {
+    usseg_set_error("norm bwd pair: no fused instantiation for this pair of norms");
+    return USSEG_ERR_UNSUPPORTED;
+  }
+  return usseg_check_launch("norm_act_bwd_pair");
+}
+
 // ---- inference BatchNorm + activation + 2x2 average pool in one pass (the stem's convtmp_2bn -> LeakyReLU -> conv1_pool,
 // ResNest.py:45-47; TBI_ResNest.py:90-92): the activated full-resolution tensor is consumed by the pool only, so it is never
 // written (forward) and the pool's backward never materialises the upsampled gradient (backward).  Values are rounded to bf16

@@ -531,6 +531,25 @@ def norm_act_bwd_sa(x, dout, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G,
     return dx
 
 
+def norm_act_bwd_pair(xa, dya, Ca, gamma_a, beta_a, dxa, dgamma_a, dbeta_a, dbias_a, xb, doutb, Cb, Gb, gamma_b, beta_b, dxb, dgamma_b, dbeta_b,
+                      dbias_b, sa_s, sa_dg, sa_mult, eps, alpha) -> bool:
+    """A plain LayerNormalization + LeakyReLU backward (A: one group) and one with the split-attention re-weighting folded in (B: ``Gb`` groups, as
+    ``norm_act_bwd_sa``) as ONE launch; False - nothing launched - when the pair has no fused instantiation (the caller makes the two calls)."""
+    Ba, Ha, Wa, Cpa, ldxa = geom(xa)
+    Bb, Hb, Wb, Cpb, ldxb = geom(xb)
+    da = NormDesc(Ba * Ha * Wa, Ca, Cpa, ldxa, geom(dya)[4], 1, 0, eps, ACT_LRELU, alpha, geom(dxa)[4])
+    db = NormDesc(Bb * Hb * Wb, Cb, Cpb, ldxb, geom(doutb)[4], Gb, 0, eps, ACT_LRELU, alpha, geom(dxb)[4])
+    gamma_a, beta_a, gamma_b, beta_b = (_readable(t, n) for t, n in ((gamma_a, Cpa), (beta_a, Cpa), (gamma_b, Cpb), (beta_b, Cpb)))
+    rc = L.load().usseg_norm_act_bwd_pair(C.byref(da), xa.data_ptr(), dya.data_ptr(), gamma_a.data_ptr(), beta_a.data_ptr(), dxa.data_ptr(),
+                                          dgamma_a.data_ptr(), dbeta_a.data_ptr(), dbias_a.data_ptr(), C.byref(db), xb.data_ptr(), doutb.data_ptr(),
+                                          gamma_b.data_ptr(), beta_b.data_ptr(), Bb, sa_s.data_ptr(), sa_dg.data_ptr(), float(sa_mult), dxb.data_ptr(),
+                                          dgamma_b.data_ptr(), dbeta_b.data_ptr(), dbias_b.data_ptr(), reduce_ws(xa.device).data_ptr(), _stream())
+    if rc == -2:        # USSEG_ERR_UNSUPPORTED
+        return False
+    L.check(rc, "norm_act_bwd_pair")
+    return True
+
+
 def norm_act_bwd(x, dy, C_logical, gamma, beta, dx, dgamma, dbeta, mode, G=1, eps=1e-3, act=ACT_NONE, alpha=0.0, mean=None,
                  var=None, dbias=None, mask=None):
     B, H, W, Cphys, ldx = geom(x)
