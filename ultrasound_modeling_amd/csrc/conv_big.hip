@@ -204,9 +204,13 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
 // RES: y = act(conv + bias) + residual.  The residual tile of a group is loaded into registers at the top of the group's LAST
 // chunk step - before that step's MFMAs and in program order before the next step's DMA, so its latency hides under the MFMAs -
 // and the compiler's own wait before the adds drains (only then, once per group) the prefetch DMA issued after it.
+// Up to 4 jobs of identical plan (the dilation branches of a decoder stage: same tensors' shapes, other dilation / weights / output slice)
+// share one launch, blockIdx.z = job: a job's workgroups are dispatched after its predecessor's, so the jobs still stream one after the other
+// - what is saved is the dispatch boundary between them (cache write-back, ramp-down and ramp-up: 5-9 us each at batch 16).
 template <int NT, int NS, bool RES = false>
-__global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigJob p, const int fast_wait) {
+__global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, const int fast_wait) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  const BigJob& p = P.job[blockIdx.z];
   constexpr int BN = 16 * NT;
   constexpr int W_BYTES = 9 * BN * 64;
   constexpr int NPW = 9 * BN / 16;            // W pieces per chunk
@@ -477,17 +481,23 @@ struct BigGeom {   // what big_fill_job needs, so that a job can be re-filled fo
 };
 
 template <int NT, int NS, bool RES = false>
-static void stream_launch_t(const BigJob& p, dim3 grid, size_t dyn, int fast_wait, hipStream_t s) {
+static void stream_launch_t(const BigParams& P, dim3 grid, size_t dyn, int fast_wait, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_stream_kernel<NT, NS, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);   // + 1 KB static
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_stream_kernel<NT, NS, RES>), grid, dim3(256), dyn, s, p, fast_wait);
+  hipLaunchKernelGGL((conv_stream_kernel<NT, NS, RES>), grid, dim3(256), dyn, s, P, fast_wait);
 }
 
-// Streaming kernel for one job whose weights fit in LDS and whose launch has enough pixel groups to amortise them.
-static int stream_plan_and_launch(const BigGeom& g, const float* epi_scale, int dry, hipStream_t s) {
+// Plan of the streaming kernel for one job whose weights fit in LDS and whose launch has enough pixel groups to amortise them.
+struct StreamPlan {
+  BigJob job;
+  int nt, PX, res, fast_wait;
+  size_t dyn;
+  unsigned wgx, gy;
+};
+static int stream_plan(const BigGeom& g, const float* epi_scale, StreamPlan& sp) {
   static const int mode = getenv("USSEG_STREAM") ? atoi(getenv("USSEG_STREAM")) : 1;
   static const int px_env = getenv("USSEG_STREAM_PX") ? atoi(getenv("USSEG_STREAM_PX")) : 0;
   // read per call (not cached): the parity tests use these two to drive small shapes through many steps per workgroup
@@ -505,7 +515,7 @@ static int stream_plan_and_launch(const BigGeom& g, const float* epi_scale, int 
   const size_t wbytes = (size_t)nchunks * 9 * 16 * nt * 64;
   if (wbytes > 40960) return 0;
   const int gy = (g.Nout + 16 * nt - 1) / (16 * nt);
-  BigJob p;
+  BigJob& p = sp.job;
   for (int PX = 256; PX >= 128; PX >>= 1) {
     if (px_env && PX != px_env) continue;
     if (!big_fill_job(p, g.x, g.w, g.y, g.bias, g.res, g.B, g.H, g.W, g.d, g.Cin, g.ldx, g.Nout, g.ldy, g.ldr, g.Nw, g.Kw, g.act, g.alpha,
@@ -525,33 +535,44 @@ static int stream_plan_and_launch(const BigGeom& g, const float* epi_scale, int 
     if (per_wg * nchunks < min_steps && !px_env) continue;   // too few steps to amortise the weights: the tiled kernels win
     if (per_wg > 64) { wgx = ((gpx + 63) / 64) * 8; per_wg = 64; }
     // the in-order wait on "all but the youngest NS*NT operations" needs every step to issue exactly that many stores
-    const int fast_wait = g.Nout % (16 * nt) == 0 && !g.res;   // (the residual variant's own loads are in the queue too)
-    if (dry) return 1;
-    const dim3 grid(wgx, gy, 1);
-    const int slot = usseg_prof_start(1, s);
-    if (g.res) {
-      if (PX == 256) {
-        if (nt == 1) stream_launch_t<1, 4, true>(p, grid, dyn, fast_wait, s);
-        else if (nt == 2) stream_launch_t<2, 4, true>(p, grid, dyn, fast_wait, s);
-        else stream_launch_t<4, 4, true>(p, grid, dyn, fast_wait, s);
-      } else {
-        if (nt == 1) stream_launch_t<1, 2, true>(p, grid, dyn, fast_wait, s);
-        else if (nt == 2) stream_launch_t<2, 2, true>(p, grid, dyn, fast_wait, s);
-        else stream_launch_t<4, 2, true>(p, grid, dyn, fast_wait, s);
-      }
-    } else if (PX == 256) {
-      if (nt == 1) stream_launch_t<1, 4>(p, grid, dyn, fast_wait, s);
-      else if (nt == 2) stream_launch_t<2, 4>(p, grid, dyn, fast_wait, s);
-      else stream_launch_t<4, 4>(p, grid, dyn, fast_wait, s);
-    } else {
-      if (nt == 1) stream_launch_t<1, 2>(p, grid, dyn, fast_wait, s);
-      else if (nt == 2) stream_launch_t<2, 2>(p, grid, dyn, fast_wait, s);
-      else stream_launch_t<4, 2>(p, grid, dyn, fast_wait, s);
-    }
-    usseg_prof_stop(1, slot, s);
+    sp.fast_wait = g.Nout % (16 * nt) == 0 && !g.res;   // (the residual variant's own loads are in the queue too)
+    sp.nt = nt; sp.PX = PX; sp.res = g.res != nullptr; sp.dyn = dyn; sp.wgx = (unsigned)wgx; sp.gy = (unsigned)gy;
     return 1;
   }
   return 0;
+}
+// jobs[0..n) share one plan: one launch, blockIdx.z = job
+static void stream_launch(const StreamPlan* sp, int n, hipStream_t s) {
+  BigParams P;
+  for (int j = 0; j < n; ++j) P.job[j] = sp[j].job;
+  for (int j = n; j < 4; ++j) P.job[j] = sp[0].job;
+  const dim3 grid(sp[0].wgx, sp[0].gy, (unsigned)n);
+  const int nt = sp[0].nt, PX = sp[0].PX, fast_wait = sp[0].fast_wait;
+  const size_t dyn = sp[0].dyn;
+  const int slot = usseg_prof_start(1, s);
+  if (sp[0].res) {
+    if (PX == 256) {
+      if (nt == 1) stream_launch_t<1, 4, true>(P, grid, dyn, fast_wait, s);
+      else if (nt == 2) stream_launch_t<2, 4, true>(P, grid, dyn, fast_wait, s);
+      else stream_launch_t<4, 4, true>(P, grid, dyn, fast_wait, s);
+    } else {
+      if (nt == 1) stream_launch_t<1, 2, true>(P, grid, dyn, fast_wait, s);
+      else if (nt == 2) stream_launch_t<2, 2, true>(P, grid, dyn, fast_wait, s);
+      else stream_launch_t<4, 2, true>(P, grid, dyn, fast_wait, s);
+    }
+  } else if (PX == 256) {
+    if (nt == 1) stream_launch_t<1, 4>(P, grid, dyn, fast_wait, s);
+    else if (nt == 2) stream_launch_t<2, 4>(P, grid, dyn, fast_wait, s);
+    else stream_launch_t<4, 4>(P, grid, dyn, fast_wait, s);
+  } else {
+    if (nt == 1) stream_launch_t<1, 2>(P, grid, dyn, fast_wait, s);
+    else if (nt == 2) stream_launch_t<2, 2>(P, grid, dyn, fast_wait, s);
+    else stream_launch_t<4, 2>(P, grid, dyn, fast_wait, s);
+  }
+  usseg_prof_stop(1, slot, s);
+}
+static bool stream_same_plan(const StreamPlan& a, const StreamPlan& b) {
+  return a.nt == b.nt && a.PX == b.PX && a.res == b.res && a.fast_wait == b.fast_wait && a.dyn == b.dyn && a.wgx == b.wgx && a.gy == b.gy;
 }
 
 // Chooses the tile (pixels per workgroup, channel tile) and launches; 0 if no tiling fits or the launch would be too small.
@@ -564,10 +585,17 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
   if (!mode) return 0;
   {   // HBM-bound jobs whose weights fit in LDS: the streaming kernel, one full-chip launch per job
     static const int multi = getenv("USSEG_STREAM_MULTI") ? atoi(getenv("USSEG_STREAM_MULTI")) : 1;
-    bool all = njobs == 1 || multi;
-    for (int j = 0; j < njobs && all; ++j) all = stream_plan_and_launch(g[j], usseg_epi_scale[j], 1, s) != 0;
+    static const int merge = getenv("USSEG_STREAM_MERGE") ? atoi(getenv("USSEG_STREAM_MERGE")) : 1;   // jobs of one plan in ONE launch (0: a launch per job)
+    bool all = (njobs == 1 || multi) && njobs <= 4;
+    StreamPlan sp[4];
+    for (int j = 0; j < njobs && all; ++j) all = stream_plan(g[j], usseg_epi_scale[j], sp[j]) != 0;
     if (all) {
-      for (int j = 0; j < njobs; ++j) (void)stream_plan_and_launch(g[j], usseg_epi_scale[j], 0, s);
+      for (int j = 0; j < njobs;) {
+        int n = 1;
+        while (merge && j + n < njobs && stream_same_plan(sp[j], sp[j + n])) ++n;
+        stream_launch(sp + j, n, s);
+        j += n;
+      }
       return 1;
     }
   }
