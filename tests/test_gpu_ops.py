@@ -1051,3 +1051,33 @@ def test_paired_layernorm_backward_is_the_bits_of_the_two_launches(gen, oc, cvkk
     assert torch.equal(dxa, dxa_u) and torch.equal(dxb, dxb_u)
     for f_, u_ in zip(gp, gu):
         assert rel(f_, u_) < 1e-5        # (the partial rows are summed over a different number of workgroups)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,q", [(2, 64, 64, 64, 16), (1, 128, 128, 128, 16), (2, 32, 48, 32, 16)])
+def test_streaming_conv_jobs_of_one_plan_in_one_launch(gen, monkeypatch, B, H, W, Cin, q):
+    """conv_stream with blockIdx.z = job (the three dilation branches of a decoder stage whose weights fit in LDS): the merged launch gives
+    the bits of one launch per job (USSEG_STREAM_MERGE=0), and both agree with the fp64 oracle."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    dil = (2, 4, 8)
+    holder, ws, bs = torch.nn.ModuleList(), [], []
+    for j in range(3):
+        c = Conv2D(Cin, q, 3, dil[j])
+        w = rnd(gen, 3, 3, Cin, q, scale=1.0 / math.sqrt(9 * Cin))
+        b = rnd(gen, q, scale=0.5)
+        c.kernel.data.copy_(w); c.bias.data.copy_(b)
+        holder.append(c); ws.append(w); bs.append(b)
+    finalize(holder)
+    x = rnd(gen, B, H, W, Cin)
+    xd = to_dev_padded(x)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("USSEG_STREAM_MERGE", flag)
+        out = torch.zeros(B, H, W, 3 * q, dtype=torch.bfloat16, device=DEV)
+        ops.conv2d_fwd_multi([(xd, c.wp_f, c.bias.data, c.k, c.dil, out[..., j * q:(j + 1) * q], ops.ACT_LRELU, 0.3) for j, c in enumerate(holder)])
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    for j in range(3):
+        ref = torch.nn.functional.leaky_relu(O.conv2d_same(x, ws[j], bs[j], dil[j]), 0.3)
+        assert rel(outs[0][..., j * q:(j + 1) * q], bf(ref)) < REL_BF16, j

@@ -585,7 +585,8 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
   if (!mode) return 0;
   {   // HBM-bound jobs whose weights fit in LDS: the streaming kernel, one full-chip launch per job
     static const int multi = getenv("USSEG_STREAM_MULTI") ? atoi(getenv("USSEG_STREAM_MULTI")) : 1;
-    static const int merge = getenv("USSEG_STREAM_MERGE") ? atoi(getenv("USSEG_STREAM_MERGE")) : 1;   // jobs of one plan in ONE launch (0: a launch per job)
+    const char* merge_env = getenv("USSEG_STREAM_MERGE");      // read per call: the parity test flips it inside one process
+    const int merge = merge_env ? atoi(merge_env) : 1;         // jobs of one plan in ONE launch (0: a launch per job)
     bool all = (njobs == 1 || multi) && njobs <= 4;
     StreamPlan sp[4];
     for (int j = 0; j < njobs && all; ++j) all = stream_plan(g[j], usseg_epi_scale[j], sp[j]) != 0;
