@@ -1188,8 +1188,9 @@ int launch_bwd(CardBwd& p, float* dg2, float* dbe2, float* db2, float* dg1, floa
   int G = g_env > 0 ? g_env : 256 * per_cu;
   if (G > most) G = most;
   if (G > USSEG_REDUCE_MAX_BLOCKS) G = USSEG_REDUCE_MAX_BLOCKS;
-  p.G = G;
   constexpr int VP = Cfg::VP, UP = Cfg::UP;
+  while (G > 1 && (int64_t)G * 3 * (VP + UP + OC) > (int64_t)USSEG_REDUCE_MAX_BLOCKS * 3 * 512) G >>= 1;   // the three partial-row regions fit usseg_reduce_ws_floats()
+  p.G = G;
   // three partial-row regions (private ones while the finishing reductions are deferred); caller_ws holds all three otherwise
   const int64_t n2 = (int64_t)G * 3 * VP, n1 = (int64_t)G * 3 * UP, nsc = (int64_t)G * 3 * OC;
   p.ws2 = usseg_defer_reduce_ws(s, caller_ws, n2);
