@@ -602,8 +602,10 @@ class ResNest(TrainStepDriver):
             probs = self._train_body(x, y)                                                     # :43-46 (no clipping: clip_norm None)
         if getattr(self, "_acc", None) is None or self._acc.device != probs.device:
             self._acc = torch.zeros(ops.ACC_FLOATS, dtype=torch.float32, device=probs.device)
-        accuracy = ops.accuracy(probs, y, self._acc).clone()                                   # :48-51 (metric only): one pass, one count
-        return self._loss_map.clone().reshape(self.height, self.width), accuracy, probs
+        accuracy = ops.accuracy(probs, y, self._acc)                                           # :48-51 (metric only): one pass, one count
+        if train and self._graph is not None:   # replayed step: loss map / accuracy / probabilities are static buffers, valid until the next call
+            return self._loss_map.reshape(self.height, self.width), accuracy, probs     # (two clones = two more dispatches behind every replay)
+        return self._loss_map.clone().reshape(self.height, self.width), accuracy.clone(), probs
 
     def modules(self):
         return self.resModel.modules()
