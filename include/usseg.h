@@ -466,6 +466,17 @@ typedef struct UssegLossDesc {
 #define USSEG_ACC_FLOATS 2050
 int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* logits, const float* y_true, const float* scale,
                                float* probs, float* loss, void* dlogits, usseg_stream_t stream);
+/* The quad-form head conv (bias included), its softmax and the loss of loss_kind 0 in ONE launch: replaces usseg_quad_bias_expand +
+ * usseg_conv2d_fwd (fp32 quad logits) + usseg_softmax_loss_fwd_bwd (quad_w != 0) - the reference's
+ * Conv2DTranspose(num_classes, 3, strides 2) -> Softmax -> CategoricalCrossentropy (Decoder.py:119-121,142; VisionTransformer.py:205,225-229).
+ *   x [B,h,w,Cin_phys] bf16 (stride ldx); wq [16][9*Cin_phys] bf16: the quad operand (rows = parity class*4 + class, K = stencil tap*Cin_phys + channel);
+ *   bias [C]; y_true [B,2h,2w,C] fp32 or NULL (probabilities only); probs [B,2h,2w,C] fp32; loss: USSEG_ACC_FLOATS floats ([0] is overwritten);
+ *   dlogits [B,h,w,16] bf16 in the quad layout or NULL.  USSEG_ERR_UNSUPPORTED (nothing launched) when ceil(h/16)*ceil(w/16)*B exceeds the
+ *   slots of the ordered sum, or Cin_phys is neither 72 (Decoder.py: the last block's 16 channels + the 56 re-injected ones) nor 16: the caller
+ *   then runs the three calls. */
+int usseg_head_quad_softmax_loss(const void* x, int32_t B, int32_t h, int32_t w, int32_t Cin_phys, int32_t ldx, const void* wq, const float* bias, int32_t C,
+                                 const float* y_true, float* probs, float* loss, void* dlogits, float label_smoothing, float clip_eps,
+                                 float inv_global_batch, usseg_stream_t stream);
 /* The same two losses evaluated on PROBABILITIES, as the reference's public methods take them:
  * loss_kind 0 = VisionTransformer.compute_loss(y_true, y_pred) (VisionTransformer.py:225-227: Keras normalises the
  * probabilities by their class sum, clips to [clip_eps, 1-clip_eps], -sum_c y_smoothed*log p, summed / global batch into *loss);

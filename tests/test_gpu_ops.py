@@ -1081,3 +1081,49 @@ def test_streaming_conv_jobs_of_one_plan_in_one_launch(gen, monkeypatch, B, H, W
     for j in range(3):
         ref = torch.nn.functional.leaky_relu(O.conv2d_same(x, ws[j], bs[j], dil[j]), 0.3)
         assert rel(outs[0][..., j * q:(j + 1) * q], bf(ref)) < REL_BF16, j
+
+
+@pytest.mark.parametrize("B,h,w,C,k,cin", [(2, 32, 32, 3, 3, 72), (1, 20, 36, 3, 3, 16), (3, 16, 5, 3, 3, 72), (2, 48, 16, 2, 4, 40), (1, 64, 64, 4, 3, 16)])
+def test_fused_quad_head_softmax_loss_equals_its_three_launches(gen, B, h, w, C, k, cin):
+    """usseg_head_quad_softmax_loss (quad-form head conv + bias + softmax + CategoricalCrossentropy + d loss / d logits in one launch) against
+    usseg_quad_bias_expand + usseg_conv2d_fwd (fp32 quad logits) + usseg_softmax_loss_fwd_bwd on ragged sizes, and the probabilities against
+    the fp64 oracle's transposed conv + softmax."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2DTranspose, QuadHead
+    head = Conv2DTranspose(cin, C, k)
+    q = QuadHead(head)
+    finalize(head)
+    wk = rnd(gen, k, k, C, cin, scale=1.0 / math.sqrt(k * k * cin))
+    bk = rnd(gen, C, scale=0.5)
+    head.kernel.data.copy_(wk); head.bias.data.copy_(bk)
+    q.on_finalize(DEV)
+    x = rnd(gen, B, h, w, cin)
+    xd = to_dev_padded(x)
+    y = torch.softmax(torch.randn(B, 2 * h, 2 * w, C, generator=gen), -1).to(DEV)
+    inv = 1.0 / 7.0
+    # unfused
+    logits = q.forward(xd)
+    probs_u = torch.empty(B, 2 * h, 2 * w, C, device=DEV)
+    loss_u = torch.zeros(ops.ACC_FLOATS, device=DEV)
+    dl_u = ops.new_act(B, h, w, 16, DEV)
+    ops.softmax_loss(logits, y, probs_u, loss_u, dl_u, HW=4 * h * w, C_classes=C, loss_kind=0, label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=inv,
+                     quad_w=2 * w)
+    # fused
+    probs_f = torch.empty_like(probs_u)
+    loss_f = torch.zeros(ops.ACC_FLOATS, device=DEV)
+    dl_f = ops.new_act(B, h, w, 16, DEV)
+    took = q.forward_loss(xd, y, probs_f, loss_f, dl_f, label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=inv)
+    if xd.shape[-1] not in (16, 72):
+        assert not took           # no instantiation for this input width: nothing launched, the caller runs the three launches
+        return
+    assert took
+    probs_n = torch.empty_like(probs_u)
+    assert q.forward_loss(xd, None, probs_n, None, None)            # probabilities only
+    torch.cuda.synchronize()
+    assert rel(probs_f, probs_u) < 1e-5 and torch.equal(probs_n, probs_f)
+    assert abs(loss_f[0].item() - loss_u[0].item()) < 1e-5 * abs(loss_u[0].item())
+    assert rel(dl_f, dl_u) < REL_BF16
+    if C < 4:
+        assert dl_f.reshape(B, h, w, 4, 4)[..., C:].abs().max().item() == 0          # the pad classes of every parity slot
+    ref = torch.softmax(O.conv2d_transpose_s2_same(x, wk, bk), -1)
+    assert rel(probs_f, ref) < 2e-3

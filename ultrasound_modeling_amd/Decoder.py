@@ -274,7 +274,7 @@ class DecoderCup(nn.Module):
         gh, gw = self.grid
         return [blk.skip_slot(B, gh * 2 ** i, gw * 2 ** i, device) for i, blk in enumerate(self.blocks)]
 
-    def forward(self, hidden_states, features: Optional[List[torch.Tensor]] = None, return_logits=False):
+    def forward(self, hidden_states, features: Optional[List[torch.Tensor]] = None, return_logits=False, return_head_input=False):
         assert features is not None, "this implementation is built for the skip-connected configuration the drivers use"
         B = hidden_states.shape[0]
         gh, gw = self.grid
@@ -296,6 +296,8 @@ class DecoderCup(nn.Module):
             x = cats[i]
         Ho, Wo = 2 * x.shape[1], 2 * x.shape[2]
         self.out_hw = (Ho, Wo)
+        if return_head_input:       # the caller runs head + softmax + loss as one launch (QuadHead.forward_loss)
+            return x
         # :142; logits fp32: [B,Ho,Wo,4] or, in quad form, [B,Ho/2,Wo/2,16] (softmax_loss indexes it through quad_w)
         logits = self._head_forward(x) if self.quad_head else self.head.forward(x, out_f32=True)
         self._logits = logits

@@ -27,6 +27,8 @@ from .Decoder import DecoderBlock, DecoderCup
 from .flat import AdamClip, FlatParams
 from .layers import BatchNormalization, Conv2D, LayerNormalization, _Workspace
 from .ResNest import ResNest, cardinal, residual_S
+
+_FUSED_HEAD = os.environ.get("USSEG_FUSED_HEAD", "1") != "0"      # quad-form head conv + softmax + loss as one launch (csrc/attn_loss_optim.hip)
 from .ops import BF16, roundup
 from .step import TrainStepDriver
 
@@ -410,8 +412,10 @@ class VisionTransformer(TrainStepDriver, nn.Module):
 
     def _forward_loss(self, x, y, with_grad: bool):
         hidden, _, features = self.transformer.forward(x, feature_slots=self.decoder.prepare(x.shape[0], self.device), need_weights=False)
-        logits = self.decoder.forward(hidden, features, return_logits=True)
-        B = logits.shape[0]
+        fused = _FUSED_HEAD and self.decoder.quad_head
+        xh = self.decoder.forward(hidden, features, return_head_input=True) if fused else None
+        logits = None if fused else self.decoder.forward(hidden, features, return_logits=True)
+        B = (xh if fused else logits).shape[0]
         H, W = self.decoder.out_hw
         qw = self.decoder.quad_w                 # head in quad form: logits / dlogits are [B,H/2,W/2,16]
         probs = torch.empty((B, H, W, self.num_classes), dtype=torch.float32, device=self.device)
@@ -420,6 +424,11 @@ class VisionTransformer(TrainStepDriver, nn.Module):
             dlogits = ops.new_act(B, H // 2, W // 2, 16, self.device) if qw else ops.new_act(B, H, W, 8, self.device)
         # :205,:227 sum / GLOBAL batch; TBI_TransUNet.py:546 (default reduction): mean over the B*H*W pixels of the batch
         scale = 1.0 / float(B * H * W) if self.transunet else 1.0 / float(self.batch_size)
+        if fused:       # head conv + softmax + loss in one launch (:142, :205, :225-229); falls back to the three launches if it has no kernel
+            if self.decoder._quad.forward_loss(xh, y, probs, self._loss, dlogits, label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=scale):
+                return probs, dlogits
+            logits = self.decoder._head_forward(xh)
+            self.decoder._logits = logits
         ops.softmax_loss(logits, y, probs, self._loss, dlogits, HW=H * W, C_classes=self.num_classes, loss_kind=0,
                          label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=scale, quad_w=qw)
         return probs, dlogits

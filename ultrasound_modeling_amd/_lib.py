@@ -166,6 +166,7 @@ _PROTOS = {
                                           P(SplitAttnGrads), c_vp, c_vp]),
     "usseg_splitattn_apply_bwd_dy": (C.c_int, [P(SplitAttnDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "usseg_softmax_loss_fwd_bwd": (C.c_int, [P(LossDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_head_quad_softmax_loss": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),
     "usseg_loss_from_probs": (C.c_int, [P(LossDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_quad_bias_expand": (C.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "usseg_space_to_depth2": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp]),

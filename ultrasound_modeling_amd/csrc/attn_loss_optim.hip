@@ -718,6 +718,183 @@ extern "C" int usseg_softmax_loss_fwd_bwd(const UssegLossDesc* d, const float* l
   return usseg_check_launch("softmax_loss");
 }
 
+// ---- the quad-form head, its softmax and the loss in ONE launch -------------------------------------------------------------------
+// DecoderCup's head (Conv2DTranspose(classes <= 4, 3 or 4 taps, strides 2), Decoder.py:119-121,142) in its quad form is a 3x3 stride-1 conv at
+// the INPUT resolution with 16 outputs = (output parity class)*4 + class (usseg.h, "quad form"); softmax and CategoricalCrossentropy follow
+// per output pixel (VisionTransformer.py:205,225-229).  Unfused that was conv (writes 64 B of fp32 logits per input pixel) -> softmax + loss
+// (reads them back): 26 + 28 us and 134 MB per 16-image step for 0.6 GFLOP.  Here a workgroup stages a 16x16-pixel tile (+1 halo) of the
+// 16-channel input in LDS, runs K = 144 on MFMA with the weight rows as the A operand - so a lane ends up with the 4 consecutive outputs
+// of ONE parity class of ONE pixel, i.e. the logits of one output pixel - and finishes softmax, probabilities, loss term and d loss / d logits in
+// registers.  The loss is the ordered grid-wide sum of the workgroup totals (bitwise reproducible).
+struct HeadQuad {
+  const bf16_t* x; const bf16_t* wq; const float* bias; const float* y_true;
+  float* probs; float* loss; bf16_t* dl;
+  int32_t B, h, w, ldx, tiles_x, C;
+  float label_smoothing, clip_eps, inv_global_batch;
+};
+template <int CC, int CP>
+__global__ __launch_bounds__(256) void head_quad_loss_kernel(const HeadQuad p) {      // (72 channels: 192 VGPRs, two workgroups per CU; a bound of three spills)
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TW = 16, HWD = TW + 2, CH = CP / 8, KTOT = 9 * CP, KS = (KTOT + 31) / 32, NIT = (HWD * HWD * CH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16_t XT[HWD * HWD * CP];        // the halo tile [18*18][CP]
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y, tyi = blockIdx.x / p.tiles_x, txi = blockIdx.x - tyi * p.tiles_x;
+  const int ty0 = tyi * TW, tx0 = txi * TW;
+  // every global load of the tile is issued before the first LDS store (a load -> store loop pays one memory latency per trip: 12 trips);
+  // zeros outside the image: the conv's 'same' padding
+  uint4 xv[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int it = tid + i * 256;
+    const int hp = it / CH, c = it - hp * CH;
+    const int hy = hp / HWD, hx = hp - hy * HWD;
+    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const bool ok = it < HWD * HWD * CH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+    xv[i] = ok ? *reinterpret_cast<const uint4*>(p.x + (((int64_t)b * p.h + gy) * p.w + gx) * p.ldx + c * 8) : make_uint4(0, 0, 0, 0);
+  }
+  // the labels of this lane's four output pixels: independent of the conv, so their loads fly under the tile staging and the MFMAs
+  const int pa = q >> 1, pb = q & 1;           // this lane's output parity
+  const int H2 = 2 * p.h, W2 = 2 * p.w;
+  float ytv[4][CC];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gy = ty0 + wv + 4 * i, gx = tx0 + r;
+    const bool ok = p.y_true != nullptr && gy < p.h && gx < p.w;
+    const int64_t m = ok ? ((int64_t)b * H2 + 2 * gy + pa) * W2 + 2 * gx + pb : 0;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) ytv[i][c] = ok ? p.y_true[m * CC + c] : 0.f;
+  }
+  // weight fragments, all K steps, in registers: A[n = r][k = ks*32 + q*8 ..]; k = tap*CP + channel; the K tail (k >= KTOT) is zero
+  bf16x8_t a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k0 = ks * 32 + q * 8;
+    a[ks] = *reinterpret_cast<const bf16x8_t*>(p.wq + r * KTOT + (k0 < KTOT ? k0 : 0));
+  }
+  if ((KTOT & 31) != 0) {      // (only the last step has a tail; zeroed here, once, not behind every load)
+    const int k0 = (KS - 1) * 32 + q * 8;
+    if (k0 >= KTOT) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[KS - 1][e] = (__bf16)0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int it = tid + i * 256;
+    const int hp = it / CH, c = it - hp * CH;
+    if (it < HWD * HWD * CH) *reinterpret_cast<uint4*>(XT + hp * CP + c * 8) = xv[i];
+  }
+  __syncthreads();
+  float bias[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bias[c] = c < CC ? p.bias[c] : 0.f;
+  float lsum = 0.f;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // B[k][pixel r of row wv + 4i]: the K tail reads a valid (clamped) pixel chunk against a zero weight fragment
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k0 = ks * 32 + q * 8;
+    const int kc = k0 < KTOT ? k0 : 0;
+    const int tap = kc / CP, c0 = kc - tap * CP, ty = tap / 3, tx = tap - ty * 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x8_t bx = *reinterpret_cast<const bf16x8_t*>(XT + ((wv + 4 * i + ty) * HWD + (r + tx)) * CP + c0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bx, acc[i], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gy = ty0 + wv + 4 * i, gx = tx0 + r;
+    if (gy < p.h && gx < p.w) {
+      const int64_t m = ((int64_t)b * H2 + 2 * gy + pa) * W2 + 2 * gx + pb;
+      float z[4], pr[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < CC; ++c) { z[c] = acc[i][c] + bias[c]; mx = fmaxf(mx, z[c]); }
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < CC; ++c) { pr[c] = __expf(z[c] - mx); sum += pr[c]; }
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int c = 0; c < CC; ++c) { pr[c] *= inv; p.probs[m * CC + c] = pr[c]; }
+      if (p.y_true) {       // CategoricalCrossentropy(label_smoothing) on probabilities: the arithmetic of softmax_loss_pixel, loss_kind 0
+        float u[4], dLdp[4];
+        const float* yt = ytv[i];
+        float S = 0.f, ubar = 0.f, l = 0.f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) S += pr[c];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+          const float ys = yt[c] * (1.f - p.label_smoothing) + p.label_smoothing / (float)CC;
+          const float qq = pr[c] / S;
+          const float qc = fminf(fmaxf(qq, p.clip_eps), 1.f - p.clip_eps);
+          l -= ys * __logf(qc);
+          u[c] = (qq > p.clip_eps && qq < 1.f - p.clip_eps) ? -ys / qc : 0.f;
+          ubar += u[c] * qq;
+        }
+        lsum += l * p.inv_global_batch;
+        if (p.dl) {
+          float dot = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < CC; ++c) { dLdp[c] = (u[c] - ubar) / S * p.inv_global_batch; dot += dLdp[c] * pr[c]; }
+#pragma unroll
+          for (int c = 0; c < CC; ++c) o[c] = pr[c] * (dLdp[c] - dot);
+          uint2 v;
+          v.x = pack2bf(o[0], o[1]); v.y = pack2bf(o[2], o[3]);
+          *reinterpret_cast<uint2*>(p.dl + (((int64_t)b * p.h + gy) * p.w + gx) * 16 + 4 * q) = v;
+        }
+      }
+    }
+  }
+  if (p.y_true) {
+    for (int msk = 32; msk >= 1; msk >>= 1) lsum += __shfl_xor(lsum, msk, 64);
+    if (lane == 0) red[wv] = lsum;
+    __syncthreads();
+    grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), p.loss, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+  }
+#endif
+}
+template <int CC, int CP>
+static void head_quad_launch(const HeadQuad& p, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((head_quad_loss_kernel<CC, CP>), grid, dim3(256), 0, s, p);
+}
+template <int CP>
+static void head_quad_launch_c(const HeadQuad& p, dim3 grid, hipStream_t s) {
+  switch (p.C) {
+    case 1: head_quad_launch<1, CP>(p, grid, s); break;
+    case 2: head_quad_launch<2, CP>(p, grid, s); break;
+    case 3: head_quad_launch<3, CP>(p, grid, s); break;
+    default: head_quad_launch<4, CP>(p, grid, s); break;
+  }
+}
+extern "C" int usseg_head_quad_softmax_loss(const void* x, int32_t B, int32_t h, int32_t w, int32_t Cin_phys, int32_t ldx, const void* wq, const float* bias, int32_t C,
+                                            const float* y_true, float* probs, float* loss, void* dlogits, float label_smoothing, float clip_eps,
+                                            float inv_global_batch, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(x && wq && bias && probs && B > 0 && h > 0 && w > 0 && Cin_phys >= 8 && Cin_phys % 8 == 0 && ldx >= Cin_phys && ldx % 8 == 0 && C >= 1 && C <= 4,
+                  "head_quad_softmax_loss: bad arguments");
+  USSEG_CHECK_ARG(!y_true || loss, "head_quad_softmax_loss: loss pointer required with y_true");
+  USSEG_CHECK_ARG(!dlogits || y_true, "head_quad_softmax_loss: dlogits needs y_true");
+  HeadQuad p = {};
+  p.x = (const bf16_t*)x; p.wq = (const bf16_t*)wq; p.bias = bias; p.y_true = y_true; p.probs = probs; p.loss = loss; p.dl = (bf16_t*)dlogits;
+  p.B = B; p.h = h; p.w = w; p.ldx = ldx; p.C = C; p.tiles_x = (w + 15) / 16;
+  p.label_smoothing = label_smoothing; p.clip_eps = clip_eps; p.inv_global_batch = inv_global_batch;
+  const int64_t tiles = (int64_t)p.tiles_x * ((h + 15) / 16);
+  // instantiated for the head widths of the models (Decoder.py: 16 channels + the re-injected 56 = 72; 16 for a plain head); more workgroups
+  // than the ordered sum has slots, or another width: the caller runs conv + softmax_loss
+  if (tiles * B > USSEG_ACC_FLOATS - 2 || B > 65535 || (Cin_phys != 16 && Cin_phys != 72)) {
+    usseg_set_error("head_quad_softmax_loss: no fused kernel for this size");
+    return USSEG_ERR_UNSUPPORTED;
+  }
+  const dim3 grid((unsigned)tiles, (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin_phys == 72) head_quad_launch_c<72>(p, grid, s);
+  else head_quad_launch_c<16>(p, grid, s);
+  return usseg_check_launch("head_quad_softmax_loss");
+}
+
 // compute_loss / my_loss_cat on probabilities (the reference's public loss methods): same arithmetic as the fused kernel above
 __device__ __forceinline__ float loss_from_probs_pixel(const UssegLossDesc& d, int64_t m, const float* probs, const float* y_true,
                                                        const float* scale) {

@@ -292,6 +292,14 @@ class QuadHead:
         self._x = self.head._x = x
         return ops.conv2d_fwd(x, self.wq_f, self.bias16, 3, 1, logits, out_f32=True)
 
+    def forward_loss(self, x, y_true, probs, loss, dlogits, **kw) -> bool:
+        """The head conv, its softmax and the loss in ONE launch (csrc/attn_loss_optim.hip head_quad_loss_kernel); leaves the state ``forward``
+        leaves.  False - nothing done - when there is no fused kernel for this size (ordered-sum slots, LDS)."""
+        if not ops.head_quad_softmax_loss(x, self.wq_f, self.head.bias.data, self.head.cout, y_true, probs, loss, dlogits, **kw):
+            return False
+        self._x = self.head._x = x
+        return True
+
     def backward(self, dl4, need_dx=True):
         """dl4: bf16 [B,h,w,16] gradient of the quad-form logits -> dx [B,h,w,cin]."""
         h, x = self.head, self._x

@@ -873,6 +873,19 @@ def softmax_loss(logits, y_true, probs, loss, dlogits, *, HW, C_classes, loss_ki
                                                 _ptr(dlogits), _stream()), "softmax_loss")
 
 
+def head_quad_softmax_loss(x, wq, bias, C_classes, y_true, probs, loss, dlogits, *, label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=1.0) -> bool:
+    """The quad-form head conv + softmax + loss (loss_kind 0) in one launch; x [B,h,w,Cin_phys] bf16, wq [16][9*Cin_phys], probs [B,2h,2w,C] fp32,
+    dlogits bf16 [B,h,w,16] or None.  False - nothing launched - when there is no fused kernel for the size (ordered-sum slots, LDS)."""
+    B, h, w, Cx, ldx = geom(x)
+    assert tuple(wq.shape) == (16, 9 * Cx) and (loss is None or loss.numel() >= ACC_FLOATS)
+    rc = L.load().usseg_head_quad_softmax_loss(x.data_ptr(), B, h, w, Cx, ldx, wq.data_ptr(), bias.data_ptr(), C_classes, _ptr(y_true), probs.data_ptr(),
+                                               _ptr(loss), _ptr(dlogits), label_smoothing, clip_eps, inv_global_batch, _stream())
+    if rc == -2:
+        return False
+    L.check(rc, "head_quad_softmax_loss")
+    return True
+
+
 def loss_from_probs(probs, y_true, loss, *, HW, C_classes, loss_kind=0, label_smoothing=0.1, clip_eps=1e-7, inv_global_batch=1.0, scale=None):
     """The reference's public loss methods on PROBABILITIES (compute_loss / my_loss_cat); ``loss`` (pre-zeroed) accumulates."""
     assert probs.dtype == torch.float32 and y_true.dtype == torch.float32 and probs.is_contiguous() and y_true.is_contiguous()
