@@ -85,6 +85,10 @@ def algorithmic_flops(net, arch):
         fused_ids = {}      # id(conv) -> passes of it (forward = 1, backward-data = 1) that run inside a fused tile kernel
         if getattr(enc, "_stem_fused", False):
             fused_ids.update({id(enc.conv1): 1, id(enc.convtmp_1): 1, id(enc.convtmp_2): 1})
+        from ultrasound_modeling_amd import VisionTransformer as _VT
+        dec = net.decoder
+        if _VT._FUSED_HEAD and dec.quad_head and dec.head.cin_p in (16, 72):      # head conv + softmax + loss (usseg_head_quad_softmax_loss)
+            fused_ids[id(dec.head)] = 1
         for m in net.modules():
             if isinstance(m, residual_S):
                 g_ = m._group

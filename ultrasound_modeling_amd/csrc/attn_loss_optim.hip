@@ -890,8 +890,10 @@ extern "C" int usseg_head_quad_softmax_loss(const void* x, int32_t B, int32_t h,
   }
   const dim3 grid((unsigned)tiles, (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
+  const int slot = usseg_prof_start(4, s);       // timed with the fused tile kernels (a conv + what follows it in one launch)
   if (Cin_phys == 72) head_quad_launch_c<72>(p, grid, s);
   else head_quad_launch_c<16>(p, grid, s);
+  usseg_prof_stop(4, slot, s);
   return usseg_check_launch("head_quad_softmax_loss");
 }
 
