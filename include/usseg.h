@@ -283,6 +283,16 @@ int usseg_norm_act_bwd_pair(const UssegNormDesc* da, const void* xa, const void*
 int usseg_stem_fwd(int32_t B, int32_t H, int32_t W, const void* x, int32_t ldx, const void* w1, const float* b1, const void* w2, const float* b2,
                    const void* w3, const float* b3, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                    float alpha, void* y1, void* t1, void* c2, void* pooled, usseg_stream_t stream);
+/* A stem conv's 3x3 backward-data pass + the backward of the layer in front of it, in ONE launch (GradientTape through ResNest.py:41-44 /
+ * :39-41): dy [B,H,W,32] -> dx_in = conv3x3_backward_data(dy, wd) (wd = the packed operand of usseg_conv2d_dgrad, [Co][9*32]) -> then
+ *   mode 2 (Co = 32): the folded inference BatchNormalization + LeakyReLU backward from the ACTIVATED tensor yact the forward stored
+ *                     (= usseg_norm_act_bwd mode 2: dx, dgamma += , dbeta +=, dbias += sum dx);
+ *   mode 0 (Co = 16): LeakyReLU backward from the activated tensor + column sums (= usseg_act_bwd_colsum: dx, dbias +=).
+ * The intermediate gradient never goes to HBM (it stays fp32 in registers: the unfused pair rounds it to bf16 in between).
+ * USSEG_ERR_UNSUPPORTED - nothing launched - for any other (Co, mode).  ws: usseg_reduce_ws_floats() floats. */
+int usseg_conv3_dgrad_actbwd(int32_t B, int32_t H, int32_t W, const void* dy, int32_t lddy, const void* wd, int32_t Co, const void* yact, int32_t ldy,
+                             int32_t mode, const float* gamma, const float* beta, const float* var, float eps, float alpha, void* dx,
+                             int32_t lddx, float* dgamma, float* dbeta, float* dbias, float* ws, usseg_stream_t stream);
 /* One residual_S stage's cardinal group AND shortcut as ONE launch (SURVEY.md section 2.2 "K3"; ResNest.py:136-147 per path - the `kpaths`
  * paths share the input, :99-101 shortcut): replaces, in the implicit TensorFlow graph of the reference, Conv2D(1x1) -> LayerNormalization ->
  * LeakyReLU -> Conv2D(3x3) -> LayerNormalization -> LeakyReLU (+ the reduce_mean of :179) per path and Conv2D(1x1) -> LayerNormalization ->

@@ -1127,3 +1127,59 @@ def test_fused_quad_head_softmax_loss_equals_its_three_launches(gen, B, h, w, C,
         assert dl_f.reshape(B, h, w, 4, 4)[..., C:].abs().max().item() == 0          # the pad classes of every parity slot
     ref = torch.softmax(O.conv2d_transpose_s2_same(x, wk, bk), -1)
     assert rel(probs_f, ref) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 20, 36), (3, 16, 5), (1, 64, 48)])
+@pytest.mark.parametrize("mode", [2, 0])
+def test_fused_stem_dgrad_with_the_backward_in_front_of_it(gen, mode, B, H, W):
+    """usseg_conv3_dgrad_actbwd (csrc/stem.hip): a stem conv's backward-data pass + folded-BatchNorm / LeakyReLU backward (mode 2, 32 channels) or
+    LeakyReLU backward + column sums (mode 0, 16 channels) in one launch against the two launches it replaces (usseg_conv2d_dgrad, then
+    usseg_norm_act_bwd mode 2 / usseg_act_bwd_colsum), on ragged sizes.  The fused form keeps the intermediate gradient in fp32 where the pair
+    stores it in bf16, so both are also held against a float64 restatement of the chain."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    co = 32 if mode == 2 else 16
+    conv = Conv2D(co, 32, 3)
+    finalize(conv)
+    conv.kernel.data.copy_(rnd(gen, 3, 3, co, 32, scale=1.0 / math.sqrt(9 * co)))
+    conv.repack()
+    dy = to_dev_padded(rnd(gen, B, H, W, 32))
+    yact = to_dev_padded(rnd(gen, B, H, W, co))                      # the stored activated output of the layer in front (any sign)
+    f = lambda n, sc, off=0.0: (off + sc * torch.randn(n, generator=gen)).to(DEV)
+    gamma, beta, var = f(co, 0.2, 1.0), f(co, 0.1), (0.5 + torch.rand(co, generator=gen)).to(DEV)
+    mean = f(co, 0.1)
+    z = lambda: torch.zeros(co, device=DEV)
+    dgf, dbf, dbif = z(), z(), z()
+    dxf = torch.empty_like(yact)
+    if mode == 2:
+        took = ops.conv3_dgrad_actbwd(dy, conv.wp_d, yact, dxf, 2, 0.3, dbif, gamma, beta, var, 1e-3, dgf, dbf)
+    else:
+        took = ops.conv3_dgrad_actbwd(dy, conv.wp_d, yact, dxf, 0, 0.3, dbif)
+    assert took
+    din = ops.conv2d_dgrad(dy, conv.wp_d, 3, 1, torch.empty_like(yact))
+    dgu, dbu, dbiu = z(), z(), z()
+    if mode == 2:
+        dxu = ops.norm_act_bwd(yact, din, co, gamma, beta, torch.empty_like(yact), dgu, dbu, 2, 1, 1e-3, ops.ACT_LRELU, 0.3, mean, var, dbias=dbiu)
+    else:
+        dxu = ops.act_bwd_colsum(yact, din, torch.empty_like(yact), ops.ACT_LRELU, 0.3, dbiu, co)
+    torch.cuda.synchronize()
+    # float64 restatement of the chain on the same bf16 inputs: the fused launch (fp32 intermediate) sits well inside the bar, the pair (bf16
+    # intermediate: 2^-9 per element, which a sum over random signs does not average away) only just; fused against pair at the pair's noise
+    F = torch.nn.functional
+    w64 = conv.kernel.detach().to(torch.bfloat16).double().cpu().permute(3, 2, 0, 1)                  # [32, co, 3, 3]
+    d64 = F.conv_transpose2d(dy[..., :32].double().cpu().permute(0, 3, 1, 2), w64, padding=1).permute(0, 2, 3, 1)
+    y64 = yact[..., :co].double().cpu()
+    if mode == 2:
+        g64, b64, r64 = gamma.double().cpu(), beta.double().cpu(), (var.double().cpu() + 1e-3).rsqrt()
+        dh = d64 * torch.where(y64 > 0, 1.0, 0.3)
+        xh = (torch.where(y64 >= 0, y64, y64 / 0.3) - b64) / g64
+        dx64 = dh * g64 * r64
+        refs = {"dgamma": ((dh * xh).sum((0, 1, 2)), dgf, dgu), "dbeta": (dh.sum((0, 1, 2)), dbf, dbu), "dbias": (dx64.sum((0, 1, 2)), dbif, dbiu)}
+    else:
+        dx64 = d64 * torch.where(y64 >= 0, 1.0, 0.3)
+        refs = {"dbias": (dx64.to(torch.bfloat16).double().sum((0, 1, 2)), dbif, dbiu)}      # usseg_act_bwd_colsum sums the STORED values
+    assert rel(dxf[..., :co], dx64) < 3e-3, rel(dxf[..., :co], dx64)
+    assert rel(dxf, dxu) < 4e-3, rel(dxf, dxu)
+    for name, (r64_, fused, pair) in refs.items():
+        assert rel(fused, r64_) < 1.5e-3, (name, rel(fused, r64_))
+        assert rel(fused, pair) < 4e-3, (name, rel(fused, pair))

@@ -50,6 +50,7 @@ _FUSED_CARDINAL_BWD = os.environ.get("USSEG_FUSED_CARDINAL_BWD", "1") != "0"    
 # (125 vs 66 us at 64x64, 201 vs 92 us at 128x128: 16 rounds of 10-us tiles).
 _CARD_BWD_MAX_PX = int(os.environ.get("USSEG_CARD_BWD_MAX_PX", "32768"))
 _LN_PAIR = os.environ.get("USSEG_LN_PAIR", "1") != "0"      # shortcut norm backward + conv2_bn backward of the large stages in one launch
+_FUSED_STEM_BWD = os.environ.get("USSEG_FUSED_STEM_BWD", "1") != "0"     # stem backward-data passes fused with the norm / activation backward in front
 _FUSED_STEM = os.environ.get("USSEG_FUSED_STEM", "1") != "0"             # the stem (three convs, two norms, pool) as one launch (csrc/stem.hip)
 _MERGED_DGRAD = os.environ.get("USSEG_MERGED_DGRAD", "1") != "0"     # one backward-data GEMM for a stage's grouped 1x1 and shortcut 1x1
 
@@ -513,14 +514,29 @@ class ResNest(nn.Module):
             d = self.convtmp_2bn.backward_pool(d, dbias=self.convtmp_2.bias.grad)
         else:
             d = self.convtmp_2bn.backward(self.conv1_pool.backward(d), dbias=self.convtmp_2.bias.grad)
-        d = self.convtmp_2.backward(d, skip_bias=True)
-        if self._fold:
-            d = self.convtmp_1bn.backward_folded(self._t1, d, ACT_LRELU, a, dbias=self.convtmp_1.bias.grad)
+        bn1, c1, c2 = self.convtmp_1bn, self.convtmp_1, self.convtmp_2
+        # :44 backwards + :41-43 backwards as ONE launch (csrc/stem.hip dgrad_actbwd_kernel): convtmp_2's backward-data pass, then the folded
+        # BatchNorm + LeakyReLU backward from the stored activation; the intermediate gradient never goes to HBM
+        dn = torch.empty_like(self._t1) if (_FUSED_STEM_BWD and self._fold) else None
+        if dn is not None and ops.conv3_dgrad_actbwd(d, c2.wp_d, self._t1, dn, 2, a, c1.bias.grad, bn1.gamma.data, bn1.beta.data, bn1.moving_variance_p,
+                                                     bn1.eps, bn1.gamma.grad, bn1.beta.grad):
+            c2.backward(d, need_dx=False, skip_bias=True)          # its weight gradient only
+            d = dn
         else:
-            d = self.convtmp_1bn.backward(d, dbias=self.convtmp_1.bias.grad)
-        d = self.convtmp_1.backward(d, skip_bias=True)
-        # LeakyReLU': sign(y) == sign(pre); the same pass sums its output over the pixels = conv1's bias gradient
-        d = ops.act_bwd_colsum(self._y1, d, torch.empty_like(d), ACT_LRELU, KERAS_LRELU_ALPHA, self.conv1.bias.grad, self.conv1.cout)
+            d = c2.backward(d, skip_bias=True)
+            if self._fold:
+                d = bn1.backward_folded(self._t1, d, ACT_LRELU, a, dbias=c1.bias.grad)
+            else:
+                d = bn1.backward(d, dbias=c1.bias.grad)
+        # :41 backwards + :40 backwards likewise: convtmp_1's backward-data pass + LeakyReLU' (sign(y) == sign(pre)) + the column sums of the
+        # result = conv1's bias gradient
+        dn = torch.empty_like(self._y1) if _FUSED_STEM_BWD else None
+        if dn is not None and ops.conv3_dgrad_actbwd(d, c1.wp_d, self._y1, dn, 0, KERAS_LRELU_ALPHA, self.conv1.bias.grad):
+            c1.backward(d, need_dx=False, skip_bias=True)
+            d = dn
+        else:
+            d = c1.backward(d, skip_bias=True)
+            d = ops.act_bwd_colsum(self._y1, d, torch.empty_like(d), ACT_LRELU, KERAS_LRELU_ALPHA, self.conv1.bias.grad, self.conv1.cout)
         self.conv1.backward(d, need_dx=False, skip_bias=True)
         return None
 

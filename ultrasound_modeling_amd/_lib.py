@@ -149,6 +149,8 @@ _PROTOS = {
     # fused encoder stem (ResNest.py:39-47): three convs, two BatchNorms, the activations and the pool
     "usseg_stem_fwd": (C.c_int, [c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32,
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "usseg_conv3_dgrad_actbwd": (C.c_int, [c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32,
+                                           c_vp, c_vp, c_vp, c_vp, c_vp]),
     "usseg_cardinal_supported": (c_i32, [P(CardinalDesc)]),
     "usseg_cardinal_fwd": (C.c_int, [P(CardinalDesc)] + [c_vp] * 21),
     # ... and its backward pass: (re-weighting + conv2_bn) backward -> grouped 3x3 backward-data -> conv1_bn backward | shortcut norm backward

@@ -757,6 +757,23 @@ def stem_fwd(x, w1, b1, w2, b2, w3, b3, gamma, beta, mean, var, eps, alpha):
     return y1, t1, c2, pooled
 
 
+def conv3_dgrad_actbwd(dy, wd, yact, dx, mode, alpha, dbias, gamma=None, beta=None, var=None, eps=1e-3, dgamma=None, dbeta=None) -> bool:
+    """3x3 backward-data of a 32-output-channel stem conv + the backward of the layer in front of it in one launch: mode 2 = folded inference
+    BatchNorm + LeakyReLU from the activated tensor ``yact`` (32 channels), mode 0 = LeakyReLU + column sums (16 channels).  False - nothing
+    launched - when there is no fused kernel for the shape."""
+    B, H, W, Cdy, lddy = geom(dy)
+    Co = yact.shape[-1]
+    if Cdy != 32 or tuple(wd.shape) != (roundup(Co, 16), 9 * 32):
+        return False
+    rc = L.load().usseg_conv3_dgrad_actbwd(B, H, W, dy.data_ptr(), lddy, wd.data_ptr(), Co, yact.data_ptr(), geom(yact)[4], mode, _ptr(gamma), _ptr(beta),
+                                           _ptr(var), eps, alpha, dx.data_ptr(), geom(dx)[4], _ptr(dgamma), _ptr(dbeta), dbias.data_ptr(),
+                                           reduce_ws(dy.device).data_ptr(), _stream())
+    if rc == -2:
+        return False
+    L.check(rc, "conv3_dgrad_actbwd")
+    return True
+
+
 # ------------------------------------------------------------------------------------------------ fused cardinal group (K3)
 def cardinal_desc(B, H, W, Cin, P, cv11, cvkk, Up, Vp, Oc, ldx, ldu, ldv, ldsc, eps, alpha) -> CardinalDesc:
     return CardinalDesc(B, H, W, Cin, P, cv11, cvkk, Up, Vp, Oc, ldx, ldu, ldv, ldsc, eps, alpha)
