@@ -20,7 +20,7 @@ struct RJob {
 };
 struct RBatch {
   int32_t njobs, pad;
-  RJob job[48];
+  RJob job[63];      // 63 x 64 B + 8 B: the 4 KB of kernel arguments
 };
 
 // workgroup = 16 outputs x 16 row slices: the nb partial rows of an output are summed by 16 threads in parallel
@@ -183,7 +183,7 @@ static void flush_reduce(DeferCtx& c) {
   while (i < c.rj.size()) {
     RBatch b = {};
     int gx = 1;
-    while (i < c.rj.size() && b.njobs < 48 && !rjob_shares_dst(b, c.rj[i])) {
+    while (i < c.rj.size() && b.njobs < 63 && !rjob_shares_dst(b, c.rj[i])) {
       b.job[b.njobs] = c.rj[i++];
       if (b.job[b.njobs].nblocks > gx) gx = b.job[b.njobs].nblocks;
       ++b.njobs;
