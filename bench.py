@@ -412,6 +412,8 @@ def main():
         dev = torch.device("cpu")
         args.no_graph, args.profile_steps, args.no_cpu_baseline = True, 0, True
     else:
+        if os.environ.get("USSEG_BENCH_SHARE_GPU") == "1":      # rehearsal hook (with USSEG_DIST_BACKEND=gloo): more ranks than GPUs
+            local %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     arch = args.arch

@@ -29,7 +29,9 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            # USSEG_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks (the ranks then
+            # share a device and the exchange goes through host memory - correctness only, never a measurement)
+            backend = os.environ.get("USSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
