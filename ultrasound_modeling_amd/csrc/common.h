@@ -11,6 +11,25 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // one MFMA A/B fr
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // one 16x16 accumulator fragment
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
+// Exact floor(n / d) for 0 <= n < 2^20, d >= 1, with r = fdiv_rcp(d): cvt + fma + cvt (+ a multiply-subtract for the remainder) instead
+// of the ~20-instruction sequence (three of them quarter-rate 32-bit multiplies) the compiler emits for a runtime integer division.
+// The tile / patch decodes of the kernel prologues are chains of 6-7 such divisions per staged item: ~1700 instructions = 3 us of
+// pure VALU time in front of the first load of every conv_big workgroup before this.  ((n + 0.5) / d is at least 0.5 / d away from any
+// integer, more than the error of the 1-ulp reciprocal and the one rounded multiply for n < 2^20.)
+// Written as cvt(2n + 1) * (0.5 / d) with the multiply in inline assembly: the SLP vectoriser would otherwise turn two neighbouring
+// decodes into a v_pk_mul_f32 with a broadcast operand - the one packed-fp32 producer form this toolchain leaves unpadded in front of a
+// dependent instruction (Makefile: NOPK; the build's isa_check found exactly that pair in the first version of this helper).
+__device__ __forceinline__ float fdiv_rcp(int d) { return 0.5f * __builtin_amdgcn_rcpf((float)d); }   // v_rcp_f32: 1 ulp
+__device__ __forceinline__ int fdiv(int n, float r) {
+  float x;
+  asm("v_mul_f32_e32 %0, %1, %2" : "=v"(x) : "v"((float)(2 * n + 1)), "v"(r));
+  return (int)x;
+}
+__device__ __forceinline__ void fdivmod(int n, int d, float r, int& q, int& rem) {
+  q = fdiv(n, r);
+  rem = n - __mul24(q, d);      // (n < 2^20: both factors are far inside 24 bits)
+}
+
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950

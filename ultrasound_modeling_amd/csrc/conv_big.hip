@@ -61,6 +61,9 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
   const int HW2 = p.PW + 2, HPP = (p.PH + 2) * HW2, NHP = p.NV * HPP;
   const int a_bytes = p.npa * 1024, stage_bytes = a_bytes + W_BYTES;
   const int dd = p.d * p.d;
+  // (all decodes below: indices of halo pixels / patches / tiles, far below 2^21)
+  const float r_hpp = fdiv_rcp(HPP), r_hw2 = fdiv_rcp(HW2), r_tpv = fdiv_rcp(p.tiles_per_v), r_tx = fdiv_rcp(p.tiles_x), r_dd = fdiv_rcp(dd),
+              r_d = fdiv_rcp(p.d);
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -72,17 +75,19 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
     const int hp = 16 * (wv + NW * it) + (lane >> 2);
     uint32_t off = OOB_OFF;
     if (hp < NHP) {
-      int pi = hp / HPP, rem = hp - pi * HPP;
-      int hy = rem / HW2, hx = rem - hy * HW2;
+      int pi, rem, hy, hx;
+      fdivmod(hp, HPP, r_hpp, pi, rem);
+      fdivmod(rem, HW2, r_hw2, hy, hx);
       int gp = blockIdx.x * p.NV + pi;
       if (gp < p.npatches) {
-        int v = gp / p.tiles_per_v, tt = gp - v * p.tiles_per_v;
-        int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-        int b = v / dd, ab = v - b * dd;
-        int la = ab / p.d, lb = ab - la * p.d;
-        int ly = ty * p.PH + hy - 1, lx = tx * p.PW + hx - 1;
-        if ((unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl)
-          off = (uint32_t)(((b * p.H + la + p.d * ly) * p.W + lb + p.d * lx) * p.ldx + slot_q * 8) * 2u;
+        int v, tt, ty, tx, b, ab, la, lb;
+        fdivmod(gp, p.tiles_per_v, r_tpv, v, tt);
+        fdivmod(tt, p.tiles_x, r_tx, ty, tx);
+        fdivmod(v, dd, r_dd, b, ab);
+        fdivmod(ab, p.d, r_d, la, lb);
+        int ly = __mul24(ty, p.PH) + hy - 1, lx = __mul24(tx, p.PW) + hx - 1;
+        if ((unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl)   // (24-bit multiplies: full rate; every factor is an image coordinate, a pixel index < 2^24 or a row stride)
+          off = (uint32_t)(__mul24(__mul24(__mul24(b, p.H) + la + __mul24(p.d, ly), p.W) + lb + __mul24(p.d, lx), p.ldx) + slot_q * 8) * 2u;
       }
     }
     a_off[it] = off;
@@ -130,19 +135,21 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
 #pragma unroll
   for (int a = 0; a < NS; ++a) {
     int s = wv * NS + a;
-    int pi = s / spp, sl = s - pi * spp;
-    int r = pl / p.PW, c = pl - r * p.PW;
+    int pi, sl, r, c;
+    fdivmod(s, spp, fdiv_rcp(spp), pi, sl);
+    fdivmod(pl, p.PW, fdiv_rcp(p.PW), r, c);
     int row = sl * rows_per_strip + r;
     hb[a] = pi * HPP + row * HW2 + c;
     int gp = blockIdx.x * p.NV + pi;
     ovalid[a] = gp < p.npatches;
     int gpc = ovalid[a] ? gp : 0;
-    int v = gpc / p.tiles_per_v, tt = gpc - v * p.tiles_per_v;
-    int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-    int b = v / dd, ab = v - b * dd;
-    int la = ab / p.d, lb = ab - la * p.d;
-    int iy = la + p.d * (ty * p.PH + row), ix = lb + p.d * (tx * p.PW + c);
-    opix[a] = ((int64_t)b * p.H + iy) * p.W + ix;
+    int v, tt, ty, tx, b, ab, la, lb;
+    fdivmod(gpc, p.tiles_per_v, r_tpv, v, tt);
+    fdivmod(tt, p.tiles_x, r_tx, ty, tx);
+    fdivmod(v, dd, r_dd, b, ab);
+    fdivmod(ab, p.d, r_d, la, lb);
+    int iy = la + __mul24(p.d, __mul24(ty, p.PH) + row), ix = lb + __mul24(p.d, __mul24(tx, p.PW) + c);
+    opix[a] = (int64_t)(__mul24(__mul24(b, p.H) + iy, p.W) + ix);     // (pixel index < 2^24: the launcher's 32-bit-offset check)
   }
   const int w_lane = pl * 64 + ((qk ^ (((pl >> 2) & 1) << 1)) << 4);
 
@@ -226,6 +233,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
   char* const wlds = lds;
   char* const alds = lds + p.nchunks * W_BYTES;
   const int dd = p.d * p.d;
+  const float r_nch = fdiv_rcp(p.nchunks);
+  const float r_hw2 = fdiv_rcp(HW2), r_tpv = fdiv_rcp(p.tiles_per_v), r_tx = fdiv_rcp(p.tiles_x), r_dd = fdiv_rcp(dd), r_d = fdiv_rcp(p.d);
 
   const int ngroups = p.npatches;
   const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3, nj = gridDim.x >> 3;   // gridDim.x is a multiple of 8
@@ -255,10 +264,11 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
   // group table
   for (int i = tid; i < ng; i += 256) {
     const int g = g_lo + i * nj;
-    const int v = g / p.tiles_per_v, tt = g - v * p.tiles_per_v;
-    const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-    const int b = v / dd, ab = v - b * dd;
-    const int la = ab / p.d, lb = ab - la * p.d;
+    int v, tt, ty, tx, b, ab, la, lb;
+    fdivmod(g, p.tiles_per_v, r_tpv, v, tt);
+    fdivmod(tt, p.tiles_x, r_tx, ty, tx);
+    fdivmod(v, dd, r_dd, b, ab);
+    fdivmod(ab, p.d, r_d, la, lb);
     const int64_t org = (((int64_t)(b * p.H + la + p.d * (ty * p.PH - 1))) * p.W + lb + p.d * (tx * p.PW - 1)) * p.ldx * 2;
     s_grp[i][0] = (int)(uint32_t)org;          // may wrap below zero: only in-image lanes (true offset >= 0) use it
     s_grp[i][1] = (b * p.H + la + p.d * ty * p.PH) * p.W + lb + p.d * tx * p.PW;
@@ -271,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int hp = 16 * (wv + 4 * it) + (lane >> 2);
-    const int hy = hp / HW2, hx = hp - hy * HW2;
+    int hy, hx;
+    fdivmod(hp, HW2, r_hw2, hy, hx);
     a_hy[it] = hp < NHP ? hy : -(1 << 20);     // never in range
     a_hx[it] = hx;
     a_rel[it] = (uint32_t)(((p.d * hy) * p.W + p.d * hx) * p.ldx + cq) * 2u;
@@ -283,7 +294,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
 #pragma unroll
   for (int a = 0; a < NS; ++a) {
     const int sl = wv * NS + a;
-    const int r = pl / p.PW, c = pl - r * p.PW;
+    int r, c;
+    fdivmod(pl, p.PW, fdiv_rcp(p.PW), r, c);
     const int row = sl * rows_per_strip + r;
     hb[a] = row * HW2 + c;
     orel[a] = p.d * row * p.W + p.d * c;
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
   __syncthreads();                             // group table visible
 
   auto issue_a = [&](int s) {
-    const int gl = s / p.nchunks, ck = s - gl * p.nchunks;
+    const int gl = __builtin_amdgcn_readfirstlane(fdiv(s, r_nch)), ck = s - gl * p.nchunks;
     char* abuf = alds + (s & 1) * a_bytes;
     const uint32_t org = (uint32_t)s_grp[gl][0] + ck * 64;
     const int lym1 = s_grp[gl][2], lxm1 = s_grp[gl][3];
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
   const int total = ng * p.nchunks;
   issue_a(0);
   for (int s = 0; s < total; ++s) {
-    const int gl = s / p.nchunks, ck = s - gl * p.nchunks;
+    const int gl = __builtin_amdgcn_readfirstlane(fdiv(s, r_nch)), ck = s - gl * p.nchunks;
     // step s has landed: everything older than the previous step's NS*NT stores is complete (vmcnt retires in order)
     // (a bare s_barrier: __syncthreads() would prepend its own vmcnt(0) and drain the stores after all)
     if (fast_wait && s > 0 && ck == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NS * NT) : "memory");
@@ -410,6 +422,7 @@ static int big_fill_job(BigJob& p, const bf16_t* x, const bf16_t* w, void* y, co
   const int NHP = NV * (PH + 2) * (PW + 2);
   if (NHP > (PX == 256 ? 576 : 288)) return 0;
   if ((int64_t)B * H * W * ldx >= (1ll << 30) || (int64_t)Nw * Kw >= (1ll << 30)) return 0;   // byte offsets < 2^31
+  if ((int64_t)B * H * W >= (1ll << 24) || (int64_t)B * d * d * (Hl / PH) * (Wl / PW) >= (1ll << 20)) return 0;   // 24-bit multiplies / fdiv() in the kernels' tile decodes
   p = {};
   p.x = x; p.w = w; p.y = y; p.bias = bias; p.res = res;
   p.H = H; p.W = W; p.d = d; p.Hl = Hl; p.Wl = Wl; p.PH = PH; p.PW = PW; p.NV = NV;

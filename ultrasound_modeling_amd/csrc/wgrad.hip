@@ -26,6 +26,13 @@ struct WgradParams {
   WgMap map;   // where the result goes (identity: out[t][m][n])
   float* ws;   // partial slabs [split][ntaps][Ma][Nb] (plain stores, summed + scattered by wgrad_finish_kernel) or NULL (atomics)
   int32_t ntaps;
+  // wgrad_dma_kernel: workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so with grid = (split, tile, tap) the
+  // taps / channel tiles that read the SAME pixel range land in different XCDs at different times and every one of them pulls its
+  // operand rows through HBM / MALL again (Arch A's 4x4 up-convs: 16 taps x (x + a quarter of dy) = 2.1 GB for 234 MB of operands,
+  // the launch ran at the memory rate).  With the remap, XCD c owns a contiguous run of the (split, tile, tap) items in tap-fastest
+  // order: the items of one pixel range start together on one XCD and re-use its L2.
+  int32_t xcd_remap;
+  int32_t lw, lh;   // log2(Wg), log2(Hg) when both are powers of two (the pixel decode of a DMA piece is then two shifts), else -1
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
@@ -180,11 +187,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // batched form (attention): blockIdx.z = b1*nb2 + b2 selects the operand / output bases instead of the tap
-  const int t = p.nb2 > 0 ? 0 : (int)blockIdx.z;
-  const int bz1 = p.nb2 > 0 ? (int)blockIdx.z / p.nb2 : 0, bz2 = p.nb2 > 0 ? (int)blockIdx.z - bz1 * p.nb2 : 0;
-  const int mt = blockIdx.y / p.ntiles, nt = blockIdx.y - mt * p.ntiles;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;    // (split, tile, tap)
+  if (p.xcd_remap) {     // dispatch order L -> XCD L % 8, slot L / 8 -> item (split-major, tile, tap-fastest) of that XCD's contiguous run
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+    const int L = bx + gx * (by + gy * bz);
+    const int c = L & 7, q = total >> 3, r = total & 7;
+    const int item = c * q + (c < r ? c : r) + (L >> 3);
+    const int u = item / gz;
+    bz = item - u * gz;
+    bx = u / gy;
+    by = u - bx * gy;
+  }
+  const int t = p.nb2 > 0 ? 0 : bz;
+  const int bz1 = p.nb2 > 0 ? bz / p.nb2 : 0, bz2 = p.nb2 > 0 ? bz - bz1 * p.nb2 : 0;
+  const int mt = by / p.ntiles, nt = by - mt * p.ntiles;
   const int m0 = mt * BT, n0 = nt * BT;
-  const int64_t k_begin = (int64_t)blockIdx.x * p.chunk;
+  const int64_t k_begin = (int64_t)bx * p.chunk;
   int64_t k_end = k_begin + p.chunk;
   if (k_end > p.M) k_end = p.M;
   if (k_begin >= k_end) return;
@@ -209,32 +227,58 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
   const bool linear = p.asy == 1 && p.asx == 1 && p.bsy == 1 && p.bsx == 1 && ady == 0 && adx == 0 && bdy == 0 && bdx == 0 &&
                       p.Ha == p.Hg && p.Wa == p.Wg && p.Hb == p.Hg && p.Wb == p.Wg;
   int kpos = 0;   // pixel offset (within the split) of the step being issued
+  // linear path: the byte offsets of this lane's pieces advance by a constant per K step (the per-piece form cost two quarter-rate
+  // v_mul_lo_u32, a 64-bit compare and an exec-mask region per operand: ~34 issue slots per piece pair against 6 here)
+  int lin_m[IT];
+  uint32_t lin_a[IT], lin_b[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    lin_m[it] = (int)k_begin + RPI * (wv + 4 * it) + lrow;                    // M < 2^24 (launcher)
+    lin_a[it] = ((uint32_t)lin_m[it] * (uint32_t)p.lda + (uint32_t)a_c) * 2u;
+    lin_b[it] = ((uint32_t)lin_m[it] * (uint32_t)p.ldb + (uint32_t)b_c) * 2u;
+  }
+  const uint32_t lin_sa = 128u * (uint32_t)p.lda, lin_sb = 128u * (uint32_t)p.ldb;   // 64 pixels x 2 bytes
+  const int k_end_i = (int)k_end;
   auto issue = [&](int stage) {
     char* const sa = lds_raw + stage * STAGE;
     char* const sb = sa + OPB;
+    if (linear) {   // dense layers / 1x1 at stride 1: grid pixel == operand pixel for both operands, nothing out of range
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int j = wv + 4 * it;
+        const bool pv = lin_m[it] < k_end_i;
+        wg_dma16(ra, sa + j * 1024, (pv & a_cok) ? lin_a[it] : WGRAD_OOB);
+        wg_dma16(rb, sb + j * 1024, (pv & b_cok) ? lin_b[it] : WGRAD_OOB);
+        lin_m[it] += 64; lin_a[it] += lin_sa; lin_b[it] += lin_sb;
+      }
+      kpos += 64;
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int j = wv + 4 * it;
       const int64_t m = k_begin + kpos + RPI * j + lrow;
       const bool pv = m < k_end;
       const int mm = pv ? (int)m : 0;
-      if (linear) {   // dense layers / 1x1 at stride 1: grid pixel == operand pixel for both operands, nothing out of range
-        wg_dma16(ra, sa + j * 1024, (pv & a_cok) ? (uint32_t)(mm * p.lda + a_c) * 2u : WGRAD_OOB);
-        wg_dma16(rb, sb + j * 1024, (pv & b_cok) ? (uint32_t)(mm * p.ldb + b_c) * 2u : WGRAD_OOB);
-        continue;
-      }
       // (image, row, column) of grid pixel mm: float-reciprocal quotients corrected by one step either way (mm < 2^24)
       // 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24: full rate; v_mul_lo_u32 issues at a quarter of it and there were twelve
       // per piece - more issue time than the step's MFMAs): every factor here is a pixel index or a count below 2^23 (the launcher
       // checks the pixel counts), the last products are taken modulo 2^32 like the 32-bit form
-      int b = (int)((float)mm * rcp_hw);
-      int rem = mm - __mul24(b, HWg);
-      if (rem < 0) { --b; rem += HWg; }
-      if (rem >= HWg) { ++b; rem -= HWg; }
-      int gy = (int)((float)rem * rcp_w);
-      int gx = rem - __mul24(gy, p.Wg);
-      if (gx < 0) { --gy; gx += p.Wg; }
-      if (gx >= p.Wg) { ++gy; gx -= p.Wg; }
+      int b, gy, gx;
+      if (p.lw >= 0) {     // (uniform) power-of-two grid: every feature map of the models here
+        gx = mm & (p.Wg - 1);
+        gy = (mm >> p.lw) & (p.Hg - 1);
+        b = mm >> (p.lw + p.lh);
+      } else {
+        b = (int)((float)mm * rcp_hw);
+        int rem = mm - __mul24(b, HWg);
+        if (rem < 0) { --b; rem += HWg; }
+        if (rem >= HWg) { ++b; rem -= HWg; }
+        gy = (int)((float)rem * rcp_w);
+        gx = rem - __mul24(gy, p.Wg);
+        if (gx < 0) { --gy; gx += p.Wg; }
+        if (gx >= p.Wg) { ++gy; gx -= p.Wg; }
+      }
       const int ay = __mul24(gy, p.asy) + ady, ax = __mul24(gx, p.asx) + adx;
       const int by = __mul24(gy, p.bsy) + bdy, bx = __mul24(gx, p.bsx) + bdx;
       const bool in_a = ((unsigned)ay < (unsigned)p.Ha) & ((unsigned)ax < (unsigned)p.Wa);
@@ -302,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
 
   // lane holds D[n_local = 4g + r][m_local = li] of each tile: 16 bytes of the slab, or four atomics into the (mapped) gradient
   float* out = p.out + (int64_t)t * p.Ma * p.Nb + bz1 * p.os1 + bz2 * p.os2;
-  float* slab = p.ws ? p.ws + ((int64_t)blockIdx.x * p.ntaps + t) * p.Ma * p.Nb : nullptr;
+  float* slab = p.ws ? p.ws + ((int64_t)bx * p.ntaps + t) * p.Ma * p.Nb : nullptr;
   const bool vec_ok = (p.Nb & 3) == 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -408,6 +452,15 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
   static const int dbg = getenv("USSEG_WGRAD_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[wgrad] M %lld (B %d Hg %d Wg %d) Ma %d Nb %d taps %d tm %d splits %lld chunk %lld slab %s asy %d bsy %d lda %d ldb %d\n", (long long)p.M, p.B, p.Hg, p.Wg,
                    p.Ma, p.Nb, ntaps, tm, (long long)splits, (long long)p.chunk, p.ws ? "yes" : "no", p.asy, p.bsy, p.lda, p.ldb);
+  {
+    static const int pow2_env = getenv("USSEG_WGRAD_POW2") ? atoi(getenv("USSEG_WGRAD_POW2")) : 1;
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    p.lw = pow2_env ? lg(p.Wg) : -1;
+    p.lh = pow2_env ? lg(p.Hg) : -1;
+    if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
+  }
+  static const int xcd_env = getenv("USSEG_WGRAD_XCD") ? atoi(getenv("USSEG_WGRAD_XCD")) : 1;
+  p.xcd_remap = dma && xcd_env && p.nb2 <= 0 && (int64_t)splits * p.mtiles * p.ntiles * ntaps < (1ll << 30) && (p.mtiles * p.ntiles * ntaps > 1);
   if (dma) {
     if (tm == 2) wgrad_dma_launch_t<2, 2>(p, grid, s);
     else wgrad_dma_launch_t<1, 3>(p, grid, s);

@@ -33,6 +33,10 @@ struct WgHaloParams {
 // blockIdx.z = job: the same number of workgroups with a third of the split-K slabs per job.
 struct WgHaloMulti {
   WgHaloParams job[4];
+  // workgroups go to the 8 XCDs round-robin in dispatch order (x = split fastest): the channel tiles / jobs that stage the SAME pixel
+  // groups would run in different XCDs at different times.  Remapped, XCD c owns a contiguous run of the (split, job, tile) items in
+  // tile-fastest order, so the items of one pixel range share that XCD's L2 (see WgradParams::xcd_remap).
+  int32_t xcd_remap;
 };
 
 // PF: the next pixel group's operands are loaded into registers while the current group computes (the small tile shapes
@@ -42,7 +46,18 @@ struct WgHaloMulti {
 template <int WVM, int WM, int WN, bool PF, int NTG, bool MASKED>
 __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel(const WgHaloMulti P) {
   constexpr int NTHR = 256 * NTG, TPG = NTG == 1 ? 9 : 5;   // threads, taps per group
-  const WgHaloParams& p = P.job[blockIdx.z];
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;    // (split, tile, job)
+  if (P.xcd_remap) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+    const int L = bx + gx * (by + gy * bz);
+    const int c = L & 7, q = total >> 3, r = total & 7;
+    const int item = c * q + (c < r ? c : r) + (L >> 3);
+    const int u = item / gy;
+    by = item - u * gy;
+    bx = u / gz;
+    bz = u - bx * gz;
+  }
+  const WgHaloParams& p = P.job[bz];
   constexpr int MAXHP = 288;
   constexpr int WVN = 4 / WVM;
   constexpr int BMc = 16 * WM * WVM, BNc = 16 * WN * WVN;      // channels per workgroup tile
@@ -63,7 +78,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
 
   const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, tg = tid >> 8;   // tile wave, tap group
   const int t0 = tg * TPG;
-  const int mt = blockIdx.y / p.ntiles_n, nt = blockIdx.y - mt * p.ntiles_n;
+  const int mt = by / p.ntiles_n, nt = by - mt * p.ntiles_n;
   const int m0 = mt * BMc, n0 = nt * BNc;
   const int HW2 = p.PW + 2, HPP = (p.PH + 2) * HW2, NHP = p.NV * HPP;
   const int rps = 16 / p.PW, spp = (p.PH * p.PW) >> 4;
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     return __builtin_bit_cast(bf16x8_t, v);
   };
 
-  const int g_begin = blockIdx.x * p.groups_per_block;
+  const int g_begin = bx * p.groups_per_block;
   int g_end = g_begin + p.groups_per_block;
   if (g_end > p.ngroups) g_end = p.ngroups;
 
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
   // channels of one input channel = one 16-byte store into the [9][Ma][Nb] slab (80 -> 20 store instructions per lane for
   // the 64x64 tile).  With a partials workspace every split stores its own slab with plain stores (summed by
   // wgrad_finish_kernel); without one it falls back to atomics.
-  float* dst = p.ws ? p.ws + (int64_t)blockIdx.x * 9 * p.Ma * p.Nb : p.out;
+  float* dst = p.ws ? p.ws + (int64_t)bx * 9 * p.Ma * p.Nb : p.out;
   const bool vec_ok = (p.Nb & 3) == 0;
 #pragma unroll
   for (int tt = 0; tt < TPG; ++tt)
@@ -464,6 +479,8 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     for (int c = 0; c < 4; ++c) P.job[0].tapmask[c] = usseg_tap_mask.mask[c];
   }
   const dim3 grid(splits, tiles, njobs);
+  static const int xcd_env = getenv("USSEG_WGHALO_XCD") ? atoi(getenv("USSEG_WGHALO_XCD")) : 1;
+  P.xcd_remap = xcd_env && tiles * njobs > 1;
   static const int dbg = getenv("USSEG_WGRAD_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[wgrad_halo] B %d H %d W %d d %d Ma %d Nb %d jobs %d shape %d tiles %d ngroups %d splits %d gpb %d max_splits %d traffic_cap %lld slab_MB %.2f in_MB %.2f\n",
                    gm[0].B, gm[0].H, gm[0].W, gm[0].d, Ma, Nb, njobs, shape, tiles, ngroups, splits, gpb, max_splits, (long long)traffic_cap, slab_bytes / 1e6, in_bytes / 1e6);
