@@ -30,6 +30,18 @@ __device__ __forceinline__ void fdivmod(int n, int d, float r, int& q, int& rem)
   rem = n - __mul24(q, d);      // (n < 2^20: both factors are far inside 24 bits)
 }
 
+// Pixel-index variant: exact for 0 <= n < 2^23 and any d >= 1 with r1 = fdiv_rcp1(d) - the float quotient is within one of the true one
+// (n / d * 1.5 * 2^-23 < 1 for d >= 3, exact reciprocals for d = 1, 2) and is corrected by one step either way: ~9 instructions.
+__device__ __forceinline__ float fdiv_rcp1(int d) { return __builtin_amdgcn_rcpf((float)d); }
+__device__ __forceinline__ void fdivmod_px(int n, int d, float r1, int& q, int& rem) {
+  float x;
+  asm("v_mul_f32_e32 %0, %1, %2" : "=v"(x) : "v"((float)n), "v"(r1));
+  q = (int)x;
+  rem = n - __mul24(q, d);
+  if (rem < 0) { --q; rem += d; }
+  if (rem >= d) { ++q; rem -= d; }
+}
+
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950

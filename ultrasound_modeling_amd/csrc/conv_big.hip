@@ -422,7 +422,7 @@ static int big_fill_job(BigJob& p, const bf16_t* x, const bf16_t* w, void* y, co
   const int NHP = NV * (PH + 2) * (PW + 2);
   if (NHP > (PX == 256 ? 576 : 288)) return 0;
   if ((int64_t)B * H * W * ldx >= (1ll << 30) || (int64_t)Nw * Kw >= (1ll << 30)) return 0;   // byte offsets < 2^31
-  if ((int64_t)B * H * W >= (1ll << 24) || (int64_t)B * d * d * (Hl / PH) * (Wl / PW) >= (1ll << 20)) return 0;   // 24-bit multiplies / fdiv() in the kernels' tile decodes
+  if ((int64_t)B * H * W >= (1ll << 23) || (int64_t)B * d * d * (Hl / PH) * (Wl / PW) >= (1ll << 20)) return 0;   // signed 24-bit multiplies / fdiv() in the kernels' tile decodes
   p = {};
   p.x = x; p.w = w; p.y = y; p.bias = bias; p.res = res;
   p.H = H; p.W = W; p.d = d; p.Hl = Hl; p.Wl = Wl; p.PH = PH; p.PW = PW; p.NV = NV;

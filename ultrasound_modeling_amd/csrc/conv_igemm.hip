@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int HWg = p.Hg * p.Wg;
+  const float r_hw = fdiv_rcp1(HWg), r_w = fdiv_rcp1(p.Wg);   // pixel decodes: fdivmod_px (common.h), M < 2^23 by the launcher
   // Conv2DTranspose forward: blockIdx.z = output-parity class, which owns tap-table entries [4c, 4c+4) and its own output pixels
   const int cls = p.cls_mode ? (int)blockIdx.z : 0;
   const int tbase = cls * 4;
@@ -271,11 +272,12 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
     const int64_t m = m0 + 8 * (wv + 4 * it) + lrow;
     pv[it] = m < p.M;
     const int mm = pv[it] ? (int)m : 0;
-    const int b = mm / HWg, rem = mm - b * HWg;
-    const int gy = rem / p.Wg, gx = rem - gy * p.Wg;
-    py[it] = gy * p.isy;
-    px[it] = gx * p.isx;
-    abase[it] = ((b * p.Hi + py[it]) * p.Wi + px[it]) * p.ldx;
+    int b, rem, gy, gx;
+    fdivmod_px(mm, HWg, r_hw, b, rem);
+    fdivmod_px(rem, p.Wg, r_w, gy, gx);
+    py[it] = __mul24(gy, p.isy);
+    px[it] = __mul24(gx, p.isx);
+    abase[it] = __mul24(__mul24(__mul24(b, p.Hi) + py[it], p.Wi) + px[it], p.ldx);
   }
   int wrow[W_IT];
   bool wok[W_IT];
@@ -373,11 +375,10 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
     int64_t m = m0 + wv * 32 + a * 16 + frow;
     ovalid[a] = m < p.M;
     int mm = ovalid[a] ? (int)m : 0;
-    int b = mm / HWg;
-    int rem = mm - b * HWg;
-    int gy = rem / p.Wg;
-    int gx = rem - gy * p.Wg;
-    opix[a] = ((int64_t)(b * p.Ho + gy * p.osy + oay)) * p.Wo + gx * p.osx + oax;
+    int b, rem, gy, gx;
+    fdivmod_px(mm, HWg, r_hw, b, rem);
+    fdivmod_px(rem, p.Wg, r_w, gy, gx);
+    opix[a] = (int64_t)(__mul24(__mul24(b, p.Ho) + __mul24(gy, p.osy) + oay, p.Wo) + __mul24(gx, p.osx) + oax);   // (output pixels < 2^23: launcher)
   }
   const EpiArgs e = {p.scale, p.bias, p.res, p.y, p.ldy, p.ldr, p.Nout, p.act, p.alpha, p.out_f32, p.accumulate};
   const int nbase = n0 + g * 4;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
   }
   const int n0 = blockIdx.y * BN;
   const int HWg = p.Hg * p.Wg;
+  const float r_hw = fdiv_rcp1(HWg), r_w = fdiv_rcp1(p.Wg);   // pixel decodes: fdivmod_px (common.h), M < 2^23 by the launcher
   const int ntaps = p.ntaps;
   const int ntile = (int)((p.M + BM - 1) / BM);
   const int my_tiles = ((int)blockIdx.x < ntile) ? (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -448,11 +450,12 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
       const int64_t m = m0 + 8 * (wv + 4 * it) + lrow;
       pv[it] = m < p.M;
       const int mm = pv[it] ? (int)m : 0;
-      const int b = mm / HWg, rem = mm - b * HWg;
-      const int gy = rem / p.Wg, gx = rem - gy * p.Wg;
-      py[it] = gy * p.isy;
-      px[it] = gx * p.isx;
-      abase[it] = ((b * p.Hi + py[it]) * p.Wi + px[it]) * p.ldx;
+      int b, rem, gy, gx;
+      fdivmod_px(mm, HWg, r_hw, b, rem);
+      fdivmod_px(rem, p.Wg, r_w, gy, gx);
+      py[it] = __mul24(gy, p.isy);
+      px[it] = __mul24(gx, p.isx);
+      abase[it] = __mul24(__mul24(__mul24(b, p.Hi) + py[it], p.Wi) + px[it], p.ldx);
     }
   };
   decode_rows(0);
@@ -550,11 +553,10 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
       int64_t m = m0 + wv * 32 + a * 16 + frow;
       ovalid[a] = m < p.M;
       int mm = ovalid[a] ? (int)m : 0;
-      int b = mm / HWg;
-      int rem = mm - b * HWg;
-      int gy = rem / p.Wg;
-      int gx = rem - gy * p.Wg;
-      opix[a] = ((int64_t)(b * p.Ho + gy * p.osy + p.oay)) * p.Wo + gx * p.osx + p.oax;
+      int b, rem, gy, gx;
+      fdivmod_px(mm, HWg, r_hw, b, rem);
+      fdivmod_px(rem, p.Wg, r_w, gy, gx);
+      opix[a] = (int64_t)(__mul24(__mul24(b, p.Ho) + __mul24(gy, p.osy) + p.oay, p.Wo) + __mul24(gx, p.osx) + p.oax);
     }
     conv_epilogue<2, NT, true>(e, ec, acc, opix, ovalid, nbase, 0);
   }
@@ -605,7 +607,8 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
   {   // plain mode with a K loop worth a stage ring: the LDS-DMA variant
     static const int dma = getenv("USSEG_IGEMM_DMA") ? atoi(getenv("USSEG_IGEMM_DMA")) : 1;
     const int64_t nb = cdiv64(p.M, (int64_t)p.Hg * p.Wg);
-    const bool fits = nb * p.Hi * p.Wi * p.ldx * 2 < 0x7fff0000ll && (int64_t)p.Nw * p.Kw * 2 < 0x7fff0000ll;
+    const bool fits = nb * p.Hi * p.Wi * p.ldx * 2 < 0x7fff0000ll && (int64_t)p.Nw * p.Kw * 2 < 0x7fff0000ll &&
+                      p.M < (1 << 23) && nb * p.Hi * p.Wi < (1 << 23) && nb * p.Ho * p.Wo < (1 << 23);   // fdivmod_px / signed 24-bit multiplies in the row decodes
     const int k_chunks = p.cls_mode ? 4 * p.cpt : p.ntaps * p.cpt;   // a parity class has up to four taps
     static const int dma_min = getenv("USSEG_IGEMM_DMA_MIN") ? atoi(getenv("USSEG_IGEMM_DMA_MIN")) : 4;
     static const int dma_batched = getenv("USSEG_IGEMM_DMA_BATCHED") ? atoi(getenv("USSEG_IGEMM_DMA_BATCHED")) : 1;

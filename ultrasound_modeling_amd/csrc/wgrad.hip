@@ -193,9 +193,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
     const int L = bx + gx * (by + gy * bz);
     const int c = L & 7, q = total >> 3, r = total & 7;
     const int item = c * q + (c < r ? c : r) + (L >> 3);
-    const int u = item / gz;
+    const int u = __builtin_amdgcn_readfirstlane(fdiv(item, fdiv_rcp(gz)));     // (the launcher keeps remapped grids below 2^20 workgroups)
     bz = item - u * gz;
-    bx = u / gy;
+    bx = __builtin_amdgcn_readfirstlane(fdiv(u, fdiv_rcp(gy)));
     by = u - bx * gy;
   }
   const int t = p.nb2 > 0 ? 0 : bz;
@@ -460,7 +460,7 @@ static int launch_wgrad(WgradParams& p, int ntaps, float* ws, int64_t ws_floats,
     if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
   }
   static const int xcd_env = getenv("USSEG_WGRAD_XCD") ? atoi(getenv("USSEG_WGRAD_XCD")) : 1;
-  p.xcd_remap = dma && xcd_env && p.nb2 <= 0 && (int64_t)splits * p.mtiles * p.ntiles * ntaps < (1ll << 30) && (p.mtiles * p.ntiles * ntaps > 1);
+  p.xcd_remap = dma && xcd_env && p.nb2 <= 0 && (int64_t)splits * p.mtiles * p.ntiles * ntaps < (1ll << 20) && (p.mtiles * p.ntiles * ntaps > 1);
   if (dma) {
     if (tm == 2) wgrad_dma_launch_t<2, 2>(p, grid, s);
     else wgrad_dma_launch_t<1, 3>(p, grid, s);

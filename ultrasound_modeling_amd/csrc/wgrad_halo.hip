@@ -52,9 +52,9 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     const int L = bx + gx * (by + gy * bz);
     const int c = L & 7, q = total >> 3, r = total & 7;
     const int item = c * q + (c < r ? c : r) + (L >> 3);
-    const int u = item / gy;
+    const int u = __builtin_amdgcn_readfirstlane(fdiv(item, fdiv_rcp(gy)));     // (grids are far below 2^20 workgroups)
     by = item - u * gy;
-    bx = u / gz;
+    bx = __builtin_amdgcn_readfirstlane(fdiv(u, fdiv_rcp(gz)));
     bz = u - bx * gz;
   }
   const WgHaloParams& p = P.job[bz];
@@ -78,10 +78,14 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
 
   const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, tg = tid >> 8;   // tile wave, tap group
   const int t0 = tg * TPG;
-  const int mt = by / p.ntiles_n, nt = by - mt * p.ntiles_n;
-  const int m0 = mt * BMc, n0 = nt * BNc;
   const int HW2 = p.PW + 2, HPP = (p.PH + 2) * HW2, NHP = p.NV * HPP;
   const int rps = 16 / p.PW, spp = (p.PH * p.PW) >> 4;
+  // tile / patch decodes with fdiv() (common.h): every index here is a tile, patch or halo-pixel number far below 2^20
+  const float r_hpp = fdiv_rcp(HPP), r_hw2 = fdiv_rcp(HW2), r_spp = fdiv_rcp(spp), r_pw = fdiv_rcp(p.PW), r_tpv = fdiv_rcp(p.tiles_per_v),
+              r_tx = fdiv_rcp(p.tiles_x), r_dd = fdiv_rcp(p.d * p.d), r_d = fdiv_rcp(p.d);
+  int mt, nt;
+  fdivmod(by, p.ntiles_n, fdiv_rcp(p.ntiles_n), mt, nt);
+  const int m0 = mt * BMc, n0 = nt * BNc;
 
   // ---- fixed per-thread staging geometry
   int x_geo[X_IT];  // (patch << 16) | (halo row << 8) | halo col, or -1
@@ -91,9 +95,10 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     int hp = idx / XCH;
     x_geo[it] = -1;
     if (hp < NHP) {
-      int pi = hp / HPP, rem = hp - pi * HPP;
-      int hy = rem / HW2;
-      x_geo[it] = (pi << 16) | (hy << 8) | (rem - hy * HW2);
+      int pi, rem, hy, hx;
+      fdivmod(hp, HPP, r_hpp, pi, rem);
+      fdivmod(rem, HW2, r_hw2, hy, hx);
+      x_geo[it] = (pi << 16) | (hy << 8) | hx;
     }
   }
   int y_geo[Y_IT];  // (patch << 16) | (row << 8) | col
@@ -102,8 +107,9 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     int idx = tid + NTHR * it;
     int pk = (idx / YCH) & 127;  // 0..127 (threads past the tile are masked at the load)
     int s = pk >> 4, pl = pk & 15;
-    int pi = s / spp, sl = s - pi * spp;
-    int r = pl / p.PW, c = pl - r * p.PW;
+    int pi, sl, r, c;
+    fdivmod(s, spp, r_spp, pi, sl);
+    fdivmod(pl, p.PW, r_pw, r, c);
     y_geo[it] = (pi << 16) | ((sl * rps + r) << 8) | c;
   }
   const int xq = tid % XCH, yq = tid % YCH;  // NTHR % XCH == 0 and NTHR % YCH == 0, so the chunk column is fixed
@@ -115,12 +121,12 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
     const int hy = (x_geo[it] >> 8) & 255, hx = x_geo[it] & 255;
-    x_rel[it] = (p.xvd * hy * p.xvW + p.xvd * hx) * p.ldx + m0 + xq * 8;
+    x_rel[it] = __mul24(__mul24(__mul24(p.xvd, hy), p.xvW) + __mul24(p.xvd, hx), p.ldx) + m0 + xq * 8;
   }
 #pragma unroll
   for (int it = 0; it < Y_IT; ++it) {
     const int row = (y_geo[it] >> 8) & 255, col = y_geo[it] & 255;
-    y_rel[it] = (p.yvd * row * p.yvW + p.yvd * col) * p.lddy + n0 + yq * 8;
+    y_rel[it] = __mul24(__mul24(__mul24(p.yvd, row), p.yvW) + __mul24(p.yvd, col), p.lddy) + n0 + yq * 8;
   }
 
   // ---- fragment addressing (fixed): K index 8g + 4h + tq of a 32-pixel step is pixel 16h + 4g + tq (same permutation for x and dy)
@@ -133,8 +139,9 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
     for (int h = 0; h < 2; ++h) {
       int pk = 32 * ks + 16 * h + 4 * g + tq;   // one read (fixed h) = one 16-pixel strip
       int s = pk >> 4, pl = pk & 15;
-      int pi = s / spp, sl = s - pi * spp;
-      int r = pl / p.PW, c = pl - r * p.PW;
+      int pi, sl, r, c;
+      fdivmod(s, spp, r_spp, pi, sl);
+      fdivmod(pl, p.PW, r_pw, r, c);
       xb[ks][h] = (pi * HPP + (sl * rps + r) * HW2 + c) * XS + wm * 16 * WM + 4 * tp;
       yb[ks][h] = pk * YS + wn * 16 * WN + 4 * tp;
     }
@@ -167,15 +174,18 @@ __global__ __launch_bounds__(256 * NTG, NTG == 1 ? 2 : 1) void wgrad_halo_kernel
       int gp = (grp0 + gi) * p.NV + pi;
       int valid = gp < p.npatches && (grp0 + gi) < g_end;
       int gpc = valid ? gp : 0;
-      int v = gpc / p.tiles_per_v, tt = gpc - v * p.tiles_per_v;
-      int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-      int dd = p.d * p.d;
-      int b = v / dd, ab = v - b * dd;
-      const int la = ab / p.d, lb = ab - la * p.d, ly0 = ty * p.PH, lx0 = tx * p.PW;
+      int v, tt, ty, tx, b, ab, la, lb;
+      fdivmod(gpc, p.tiles_per_v, r_tpv, v, tt);
+      fdivmod(tt, p.tiles_x, r_tx, ty, tx);
+      fdivmod(v, p.d * p.d, r_dd, b, ab);
+      fdivmod(ab, p.d, r_d, la, lb);
+      const int ly0 = __mul24(ty, p.PH), lx0 = __mul24(tx, p.PW);
       // [0] x offset of halo pixel (0,0) (may be "negative": only in-image items use it), [1] dy offset of patch pixel (0,0),
       // [2] ly0 - 1 (far out of range for an invalid patch: every bounds test then fails), [3] lx0 - 1, [4] valid
-      tab[tid][0] = (int)(((int64_t)(b * p.xvH + p.xva + la + p.xvd * (ly0 - 1)) * p.xvW + p.xvb + lb + p.xvd * (lx0 - 1)) * p.ldx);
-      tab[tid][1] = (int)(((int64_t)(b * p.yvH + p.yva + la + p.yvd * ly0) * p.yvW + p.yvb + lb + p.yvd * lx0) * p.lddy);
+      // (24-bit multiplies: pixel indices are below 2^24 and element offsets below 2^31 - the launcher's checks - so the low 32 bits are exact;
+      //  a "negative" halo origin wraps exactly as the 64-bit form truncated to int did)
+      tab[tid][0] = __mul24(__mul24(__mul24(b, p.xvH) + p.xva + la + __mul24(p.xvd, ly0 - 1), p.xvW) + p.xvb + lb + __mul24(p.xvd, lx0 - 1), p.ldx);
+      tab[tid][1] = __mul24(__mul24(__mul24(b, p.yvH) + p.yva + la + __mul24(p.yvd, ly0), p.yvW) + p.yvb + lb + __mul24(p.yvd, lx0), p.lddy);
       tab[tid][2] = valid ? ly0 - 1 : -(1 << 24);
       tab[tid][3] = lx0 - 1;
       tab[tid][4] = valid;
@@ -408,6 +418,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     p.ldx = q.ldx; p.lddy = q.lddy; p.Ma = Ma; p.Nb = Nb;
     if (p.ngroups != P.job[0].ngroups) return 0;
     if ((int64_t)q.B * p.xvH * p.xvW * q.ldx >= (1ll << 31) || (int64_t)q.B * p.yvH * p.yvW * q.lddy >= (1ll << 31)) return 0;   // 32-bit element offsets
+    if ((int64_t)q.B * p.xvH * p.xvW >= (1ll << 23) || (int64_t)q.B * p.yvH * p.yvW >= (1ll << 23) || p.npatches >= (1 << 20)) return 0;   // signed 24-bit multiplies / fdiv() in the kernel's decodes
   }
   if (ws) ws = usseg_defer_wgrad_ws(s, ws, ws_floats, &ws_floats);   // deferred finishing: a private region of the step's workspace
   // tile shape by channel counts: 64x64, 32x32 (both small), 64x16 / 64x32 (few output channels, e.g. the decoder branches)
