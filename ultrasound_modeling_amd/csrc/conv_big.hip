@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
     }
   };
 
+  issue(0, 0);     // the first chunk flies under the output-pixel decode below (~300 instructions that nothing before the MFMAs needs)
   // ---- this lane's NS output pixels (one per 16-pixel strip of the wave)
   const int pl = lane & 15, qk = lane >> 4;
   const int rows_per_strip = 16 / p.PW, spp = (p.PH * p.PW) >> 4;
@@ -160,7 +161,6 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
     for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const bool dbuf = p.nstages == 2;
-  issue(0, 0);
   for (int ck = 0; ck < p.nchunks; ++ck) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // chunk ck has landed for every wave; everyone is done reading the other stage
