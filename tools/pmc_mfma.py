@@ -24,7 +24,7 @@ arch = sys.argv[4] if len(sys.argv) > 4 else "B"
 
 
 def family(k):
-    if k.startswith(("igemm", "conv_halo", "conv_big", "conv_stream", "cardinal", "stem_fwd", "head_quad_loss")):
+    if k.startswith(("igemm", "conv_halo", "conv_big", "conv_stream", "cardinal", "stem_fwd", "dgrad_actbwd", "head_quad_loss")):
         return "conv forward / backward-data"
     if k.startswith("wgrad") and "finish" not in k:
         return "weight gradients"

@@ -21,7 +21,7 @@ steps = int(sys.argv[3])
 arch = sys.argv[5] if len(sys.argv) > 5 else "B"
 batch = int(sys.argv[6]) if len(sys.argv) > 6 else {"B": 16, "A": 32, "T": 8, "S": 16}[arch]
 # the launches bench.py times as the conv family (usseg_prof kind 1): every conv kernel + the fused cardinal / stem launches that carry convs
-fam = lambda k: k.startswith(("igemm", "conv_halo", "conv_big", "conv_stream", "cardinal_fwd", "cardinal_bwd", "stem_fwd", "head_quad_loss"))
+fam = lambda k: k.startswith(("igemm", "conv_halo", "conv_big", "conv_stream", "cardinal_fwd", "cardinal_bwd", "stem_fwd", "dgrad_actbwd", "head_quad_loss"))
 out = {"arch": arch, "per_gpu_batch": batch, "hw": 256, "steps_profiled": steps, "kernels": {}}
 cb = cl = 0.0
 for k in sorted(set(fetch) | set(write)):

@@ -27,6 +27,7 @@ for r in step:
     if d < 13.0:
         small_n += 1; small_t += d
     key = ("conv fwd/dgrad" if n.startswith(("conv_", "igemm")) else "fused cardinal group (1x1+LN+3x3+LN | shortcut)" if n.startswith("cardinal") else
+           "fused stem / head tiles (stem chain, dgrad + act backward, head + loss)" if n.startswith(("stem_fwd", "dgrad_actbwd", "head_quad_loss")) else
            "weight gradients" if n.startswith("wgrad") else "norm/act" if n.startswith(("norm_act", "act_", "ln_bwd", "bn_act")) else
            "split attention" if n.startswith("sa_") else "other")
     fam[key] += d

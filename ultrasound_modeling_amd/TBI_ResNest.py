@@ -353,15 +353,21 @@ class _ResModel(nn.Module):
         self._r2 = g("conv2_1_1").forward(t)                                           # :85
         t = ops.act_fwd(self._r2, torch.empty_like(self._r2), ACT_ELU, a)              # :87
         self._pools = [AveragePooling2D() for _ in range(6)]
+        # tf.concat([up_i, pool_(5-i)]) of the decoder (:110-122) costs nothing: pool_1..pool_5 are written straight into the skip slices
+        # of the five concat buffers (16-byte aligned channel offsets; every consumer takes a channel stride)
+        B0, H0, W0 = x.shape[0], x.shape[1], x.shape[2]
+        skips = (512, 256, 128, 64, 32)
+        cats = [ops.new_act(B0, H0 >> (5 - i), W0 >> (5 - i), oc + sk, x.device) for i, ((_, oc, _), sk) in enumerate(zip(self.UPS, skips))]
+        slot = lambda j: cats[4 - j][..., self.UPS[4 - j][1]:]          # where pooled[j] (pool_(j+1)) lives
         bn = g("conv2_1_2bn")
         self._pool_fused = not bn.training_mode
         if self._pool_fused:   # :88-92 BN + ELU + pool_1 in one pass: the activated 256x256 tensor feeds the pool only
-            pooled = [bn.forward_pool(g("conv2_1_2").forward(t), ACT_ELU, a)]
+            pooled = [bn.forward_pool(g("conv2_1_2").forward(t), ACT_ELU, a, out=slot(0))]
         else:
             t = bn.forward(g("conv2_1_2").forward(t), ACT_ELU, a)                      # :88-91
-            pooled = [self._pools[0].forward(t)]                                       # pool_1 (:92)
+            pooled = [self._pools[0].forward(t, out=slot(0))]                          # pool_1 (:92)
         for i, st in enumerate(self._build()):                                         # :93-107
-            pooled.append(self._pools[i + 1].forward(st.forward(pooled[-1])))
+            pooled.append(self._pools[i + 1].forward(st.forward(pooled[-1]), out=slot(i + 1) if i + 1 < 5 else None))
         # pooled = [pool1(32ch), pool2(64), pool3(128), pool4(256), pool5(512), pool6(512)]
         u = pooled[5]
         self._cats, self._masks, self._upraw = [], [], []
@@ -369,12 +375,12 @@ class _ResModel(nn.Module):
             skip = pooled[4 - i]
             B, H, W, _, _ = ops.geom(u)
             raw = self._qt[name].forward(u) if name in self._qt else g(name + "_t_conv").forward(u)   # :210
-            cat = ops.new_act(B, 2 * H, 2 * W, oc + skip.shape[3], u.device)
+            cat = cats[i]
+            assert cat.shape[1] == 2 * H and cat.shape[3] == oc + skip.shape[3] and skip.data_ptr() == cat[..., oc:].data_ptr()
             mask = self._mask(i, raw) if drop else None
             bn = g(name + "_bn")
             ops.norm_act_fwd(raw, oc, bn.gamma.data, bn.beta.data, cat[..., :oc], 1, 1, KERAS_BN_EPS, ACT_RELU, 0.0, bn.moving_mean_p,
                              bn.moving_variance_p, mask=mask)                          # :213-218
-            ops.copy_channels(skip, cat[..., oc:])                                     # tf.concat (:110-122)
             self._cats.append(cat); self._masks.append(mask); self._upraw.append(raw)
             u = cat
         B, H, W = u.shape[0], 2 * u.shape[1], 2 * u.shape[2]

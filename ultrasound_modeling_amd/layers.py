@@ -482,12 +482,12 @@ class BatchNormalization(LayerNormalization):
             ops.bn_finalize_stats(s, s2, B * H * W, self.C, self.momentum, self._bmean, self._bvar, self.moving_mean_p, self.moving_variance_p)
         return super().forward(x, act, alpha, out)
 
-    def forward_pool(self, x, act=ACT_NONE, alpha=0.0):
+    def forward_pool(self, x, act=ACT_NONE, alpha=0.0, out=None):
         """BN (inference mode) + activation + AveragePooling2D(2,2) in one launch: -> the POOLED tensor [B,H/2,W/2,C].  Only for
         a BN whose activated output feeds nothing but the pool (the stems: ResNest.py:45-47, TBI_ResNest.py:90-92)."""
         assert not self.training_mode
         self._x, self._act = x, (act, alpha)
-        return ops.bn_act_pool_fwd(x, self.C, self.gamma.data, self.beta.data, self.moving_mean_p, self.moving_variance_p, self.eps, act, alpha)
+        return ops.bn_act_pool_fwd(x, self.C, self.gamma.data, self.beta.data, self.moving_mean_p, self.moving_variance_p, self.eps, act, alpha, out)
 
     def backward_pool(self, dy_pooled, dbias=None):
         """Backward of ``forward_pool``: dy w.r.t. the pooled output -> dx w.r.t. the pre-norm input (no upsampled gradient tensor)."""
