@@ -164,17 +164,25 @@ __device__ __forceinline__ int sa_mv(const float* __restrict__ W, int s_i, int s
   const int Np = No <= 32 ? 32 : (No <= 64 ? 64 : 128), parts = SA_THR / Np;
   const int o = tid & (Np - 1), pt = tid / Np;
   const int per = (Ni + parts - 1) / parts, i0 = pt * per, i1 = i0 + per < Ni ? i0 + per : Ni;
-  float v0 = 0.f, v1 = 0.f;
+  // eight independent weight loads per trip (the kernel is a chain of L2 round trips: what matters is how many loads fly together);
+  // fixed summation order
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
   if (o < No) {
+    const float* w = W + (int64_t)o * s_o;
     int i = i0;
-#pragma unroll 4
-    for (; i + 1 < i1; i += 2) {
-      v0 = fmaf(x[i], W[(int64_t)i * s_i + (int64_t)o * s_o], v0);
-      v1 = fmaf(x[i + 1], W[(int64_t)(i + 1) * s_i + (int64_t)o * s_o], v1);
+    for (; i + 7 < i1; i += 8) {
+      const float w0 = w[(int64_t)i * s_i], w1 = w[(int64_t)(i + 1) * s_i], w2 = w[(int64_t)(i + 2) * s_i], w3 = w[(int64_t)(i + 3) * s_i];
+      const float w4 = w[(int64_t)(i + 4) * s_i], w5 = w[(int64_t)(i + 5) * s_i], w6 = w[(int64_t)(i + 6) * s_i], w7 = w[(int64_t)(i + 7) * s_i];
+      v0 = fmaf(x[i], w0, v0); v1 = fmaf(x[i + 1], w1, v1); v2 = fmaf(x[i + 2], w2, v2); v3 = fmaf(x[i + 3], w3, v3);
+      v0 = fmaf(x[i + 4], w4, v0); v1 = fmaf(x[i + 5], w5, v1); v2 = fmaf(x[i + 6], w6, v2); v3 = fmaf(x[i + 7], w7, v3);
     }
-    if (i < i1) v0 = fmaf(x[i], W[(int64_t)i * s_i + (int64_t)o * s_o], v0);
+    for (; i + 1 < i1; i += 2) {
+      v0 = fmaf(x[i], w[(int64_t)i * s_i], v0);
+      v1 = fmaf(x[i + 1], w[(int64_t)(i + 1) * s_i], v1);
+    }
+    if (i < i1) v0 = fmaf(x[i], w[(int64_t)i * s_i], v0);
   }
-  part[pt * 128 + o] = v0 + v1;
+  part[pt * 128 + o] = (v0 + v1) + (v2 + v3);
   return parts;
 }
 __device__ __forceinline__ float sa_mv_sum(const float* part, int parts, int o) {
@@ -210,11 +218,17 @@ __global__ __launch_bounds__(SA_THR) void sa_mlp_kernel(const SaMlp a) {
     if (c < Cg)
       for (int r = 0; r < R; ++r) {
         const float* gp = a.g + (int64_t)b * a.g_rows * a.g_stride + (p * R + r) * Cg + c;
-        float v0 = 0.f, v1 = 0.f;          // the rows are independent loads: two chains keep them in flight
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;          // the rows are independent loads: eight of them in flight per trip (stage 1 has 256 rows per image)
         int jr = pt;
+        const int64_t st = (int64_t)parts * a.g_stride;
+        for (; jr + 7 * parts < a.g_rows; jr += 8 * parts) {
+          const float* q = gp + (int64_t)jr * a.g_stride;
+          const float r0 = q[0], r1 = q[st], r2 = q[2 * st], r3 = q[3 * st], r4 = q[4 * st], r5 = q[5 * st], r6 = q[6 * st], r7 = q[7 * st];
+          v0 += r0; v1 += r1; v2 += r2; v3 += r3; v0 += r4; v1 += r5; v2 += r6; v3 += r7;
+        }
         for (; jr + parts < a.g_rows; jr += 2 * parts) { v0 += gp[(int64_t)jr * a.g_stride]; v1 += gp[(int64_t)(jr + parts) * a.g_stride]; }
         if (jr < a.g_rows) v0 += gp[(int64_t)jr * a.g_stride];
-        v += v0 + v1;
+        v += (v0 + v1) + (v2 + v3);
       }
     part[pt * 128 + c] = v;
     __syncthreads();
@@ -273,12 +287,19 @@ __global__ __launch_bounds__(SA_THR) void sa_mlp_kernel(const SaMlp a) {
     }
   } else {
     if (a.ds_rows) {      // ds[b][cy] = mult * sum over the reduce kernel's partial rows, in row order
+      const float r_cg = fdiv_rcp(Cg);
       for (int i = tid; i < R * Cg; i += SA_THR) {
-        const int r = i / Cg, c = i - r * Cg;
+        int r, c;
+        fdivmod(i, Cg, r_cg, r, c);
         const float* src = a.ds_rows + (int64_t)b * a.ds_nb * a.ds_cp + (p * R + r) * Cg + c;
-        float t = 0.f;
-        for (int j = 0; j < a.ds_nb; ++j) t += src[(int64_t)j * a.ds_cp];
-        dsl[r * 128 + c] = a.ds_mult * t;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;     // four rows in flight per trip, fixed order
+        int j = 0;
+        for (; j + 3 < a.ds_nb; j += 4) {
+          const float q0 = src[(int64_t)j * a.ds_cp], q1 = src[(int64_t)(j + 1) * a.ds_cp], q2 = src[(int64_t)(j + 2) * a.ds_cp], q3 = src[(int64_t)(j + 3) * a.ds_cp];
+          t0 += q0; t1 += q1; t2 += q2; t3 += q3;
+        }
+        for (; j < a.ds_nb; ++j) t0 += src[(int64_t)j * a.ds_cp];
+        dsl[r * 128 + c] = a.ds_mult * ((t0 + t1) + (t2 + t3));
       }
       __syncthreads();
     }
@@ -301,11 +322,14 @@ __global__ __launch_bounds__(SA_THR) void sa_mlp_kernel(const SaMlp a) {
       __syncthreads();
     }
     // dW2[p][r][j][c] += a[j]*dz[r][c];  da[j] = sum_{r,c} w2*dz
-    for (int idx = tid; idx < R * Hd * Cg; idx += SA_THR) {
-      int c = idx % Cg;
-      int j = (idx / Cg) % Hd;
-      int r = idx / (Cg * Hd);
-      g_w2[idx] = av[j] * dz[r * 128 + c];
+    {
+      const float r_cg = fdiv_rcp(Cg), r_hd = fdiv_rcp(Hd);       // (indices < 2^20: fdiv, common.h)
+      for (int idx = tid; idx < R * Hd * Cg; idx += SA_THR) {
+        int rj, c, r, j;
+        fdivmod(idx, Cg, r_cg, rj, c);
+        fdivmod(rj, Hd, r_hd, r, j);
+        g_w2[idx] = av[j] * dz[r * 128 + c];
+      }
     }
     {
       float v = 0.f;
@@ -341,9 +365,13 @@ __global__ __launch_bounds__(SA_THR) void sa_mlp_kernel(const SaMlp a) {
     }
     __syncthreads();
     for (int j = tid; j < Hd; j += SA_THR) g_b1[j] = dh[j];
-    for (int idx = tid; idx < Cg * Hd; idx += SA_THR) {
-      int j = idx % Hd, c = idx / Hd;
-      g_w1[idx] = gin[c] * dh[j];
+    {
+      const float r_hd = fdiv_rcp(Hd);
+      for (int idx = tid; idx < Cg * Hd; idx += SA_THR) {
+        int c, j;
+        fdivmod(idx, Hd, r_hd, c, j);
+        g_w1[idx] = gin[c] * dh[j];
+      }
     }
     // d g_sum[b][(p*R+r)*Cg + c] = mult/HW * sum_j w1[c][j] dh[j]
     {
