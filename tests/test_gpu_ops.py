@@ -1083,6 +1083,39 @@ def test_streaming_conv_jobs_of_one_plan_in_one_launch(gen, monkeypatch, B, H, W
         assert rel(outs[0][..., j * q:(j + 1) * q], bf(ref)) < REL_BF16, j
 
 
+@pytest.mark.parametrize("B,H,W,Cin,q", [(2, 32, 32, 64, 16), (1, 64, 48, 128, 16), (2, 32, 32, 512, 64), (3, 16, 16, 256, 32), (1, 128, 128, 72, 16), (2, 64, 64, 40, 24)])
+def test_one_by_one_branch_as_fourth_job_of_the_dilated_launch(gen, monkeypatch, B, H, W, Cin, q):
+    """The DecoderBlock's 1x1 branch as a centre-tap-only job of the three dilated 3x3 convs' multi-job launch (conv_big / conv_stream
+    `one_tap`, Decoder.py:61-66): every branch against the fp64 oracle, the dilated branches bit-identical to the three-job launch, and the
+    1x1 branch against its own launch (another kernel with another K chunking: bf16-level agreement)."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    dil = (1, 2, 4, 8)
+    holder, ws, bs = torch.nn.ModuleList(), [], []
+    for j in range(4):
+        k = 1 if j == 0 else 3
+        c = Conv2D(Cin, q, k, dil[j])
+        w = rnd(gen, k, k, Cin, q, scale=1.0 / math.sqrt(k * k * Cin))
+        b = rnd(gen, q, scale=0.5)
+        c.kernel.data.copy_(w); c.bias.data.copy_(b)
+        holder.append(c); ws.append(w); bs.append(b)
+    finalize(holder)
+    x = rnd(gen, B, H, W, Cin)
+    xd = to_dev_padded(x)
+    job = lambda out, j: (xd, holder[j].wp_f, holder[j].bias.data, holder[j].k, holder[j].dil, out[..., j * q:(j + 1) * q], ops.ACT_LRELU, 0.3)
+    out4 = torch.zeros(B, H, W, 4 * q, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d_fwd_multi([job(out4, j) for j in range(4)])
+    out3 = torch.zeros_like(out4)
+    ops.conv2d_fwd(xd, holder[0].wp_f, holder[0].bias.data, 1, 1, out3[..., :q], ops.ACT_LRELU, 0.3)
+    ops.conv2d_fwd_multi([job(out3, j) for j in (1, 2, 3)])
+    torch.cuda.synchronize()
+    assert torch.equal(out4[..., q:], out3[..., q:])
+    assert rel(out4[..., :q], out3[..., :q]) < REL_BF16
+    for j in range(4):
+        ref = torch.nn.functional.leaky_relu(O.conv2d_same(x, ws[j], bs[j], dil[j]), 0.3)
+        assert rel(out4[..., j * q:(j + 1) * q], bf(ref)) < REL_BF16, j
+
+
 @pytest.mark.parametrize("B,h,w,C,k,cin", [(2, 32, 32, 3, 3, 72), (1, 20, 36, 3, 3, 16), (3, 16, 5, 3, 3, 72), (2, 48, 16, 2, 4, 40), (1, 64, 64, 4, 3, 16)])
 def test_fused_quad_head_softmax_loss_equals_its_three_launches(gen, B, h, w, C, k, cin):
     """usseg_head_quad_softmax_loss (quad-form head conv + bias + softmax + CategoricalCrossentropy + d loss / d logits in one launch) against

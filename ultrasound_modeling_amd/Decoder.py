@@ -21,6 +21,7 @@ from .ops import ACT_LRELU, ACT_NONE, BF16, roundup
 
 
 _FUSED_DGRAD = os.environ.get("USSEG_FUSED_DGRAD", "1") != "0"
+_BRANCH4 = os.environ.get("USSEG_BRANCH4", "1") != "0"     # the 1x1 branch of a DecoderBlock stage as a fourth job of its multi-job conv launch
 _QUAD_UP = os.environ.get("USSEG_QUAD_UP", "0") != "0"
 # Inference-mode BatchNorm folded into the producing conv: its scale goes into the PACKED forward operand (W' = W*gamma*rstd per output
 # channel), its shift replaces the bias, LeakyReLU rides in the plain epilogue - no norm launch and no pre-norm tensor in the forward
@@ -137,12 +138,20 @@ class DecoderBlock(nn.Module):
         convs = [getattr(self, f"conv{st}_{j}") for j in range(4)]
         b = self._bn[st]
         sl = lambda t, j: t[j * q:(j + 1) * q]
-        if self._fold:      # the scale is inside wp_f (pack time); the shift is the bias; LeakyReLU in the plain epilogue
+        # the 1x1 branch rides in the dilated branches' launch as a fourth, centre-tap-only job (it reads the same x tile): one dispatch
+        # less per stage on the forward chain.  USSEG_BRANCH4=0: its own launch, as before (the comparison of its test)
+        four = _BRANCH4 and convs[0].k == 1 and convs[0].dil == 1
+        convs[0]._x = x
+        if four:
+            first = (0,)
+        elif self._fold:      # the scale is inside wp_f (pack time); the shift is the bias; LeakyReLU in the plain epilogue
             convs[0].forward(x, out=raw[..., :q], act=ACT_LRELU, alpha=KERAS_LRELU_ALPHA, bias=sl(b["fshift"], 0))
+            first = ()
         else:
             convs[0].forward(x, out=raw[..., :q])
+            first = ()
         jobs = []
-        for j in (1, 2, 3):
+        for j in first + (1, 2, 3):
             c = convs[j]
             c._x = x
             if self._fold:

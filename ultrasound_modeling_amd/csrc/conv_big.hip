@@ -29,6 +29,8 @@ struct BigJob {
   int32_t gx, gy, npa, nstages;   // this job's grid extent; A pieces (16 halo pixels each) per stage; LDS stages (1 or 2)
   uint32_t x_bytes, w_bytes;   // buffer extents for the range-checked DMA
   int32_t mask_ch;             // quad-form transposed conv: channels per parity class (0 = every tap for every channel)
+  int32_t one_tap;             // a 1x1 conv riding in a multi-job launch of 3x3 convs on the same input (the DecoderBlock's first branch): only the centre
+                               // tap exists - its packed operand is [N][Cin] - the other taps' weight rows are zero-filled by the DMA and their MFMAs skipped
   uint16_t tapmask[4];         // stencil taps class c uses (fwd: class of the output-channel tile; dgrad: class of the K chunk)
 };
 struct BigParams {
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
     if (row < 9 * BN) {
       int t = row / BN, n = row - t * BN;
       int tw = p.flip ? 8 - t : t;
-      if (n0 + n < p.Nw) off = (uint32_t)((n0 + n) * p.Kw + tw * p.Cin + slot_q * 8) * 2u;
+      if (p.one_tap) tw = t == 4 ? 0 : -1;
+      if (tw >= 0 && n0 + n < p.Nw) off = (uint32_t)((n0 + n) * p.Kw + tw * p.Cin + slot_q * 8) * 2u;
     }
     w_off[it] = off;
   }
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void conv_big_kernel(const BigParams P) {
     if (dbuf && ck + 1 < p.nchunks) issue(ck + 1, (ck + 1) & 1);
     const char* abuf = lds + (dbuf ? (ck & 1) * stage_bytes : 0);
     const char* wbuf = abuf + a_bytes + w_lane;
-    const uint32_t tmask = p.mask_ch ? p.tapmask[(p.flip ? ck * 32 : n0) / p.mask_ch] : 0x1ffu;   // wave-uniform
+    const uint32_t tmask = p.one_tap ? 0x010u : (p.mask_ch ? p.tapmask[(p.flip ? ck * 32 : n0) / p.mask_ch] : 0x1ffu);   // wave-uniform
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       if (!((tmask >> t) & 1u)) continue;     // this class's weights are identically zero at tap t
@@ -256,8 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
     const int ck = j / NPW, r = j - ck * NPW;
     const int row = 16 * r + (lane >> 2);      // t*BN + n
     const int t = row / BN, n = row - t * BN;
-    const int tw = p.flip ? 8 - t : t;
-    const bool ok = (n0 + n) < p.Nw && (ck * 32 + cq) < p.Cin;
+    int tw = p.flip ? 8 - t : t;
+    if (p.one_tap) tw = t == 4 ? 0 : -1;
+    const bool ok = tw >= 0 && (n0 + n) < p.Nw && (ck * 32 + cq) < p.Cin;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wlds + j * 1024), 16,
                                              ok ? (uint32_t)((n0 + n) * p.Kw + tw * p.Cin + ck * 32 + cq) * 2u : OOB_OFF, 0, 0, 0);
   }
@@ -355,8 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
     }
     const char* abuf = alds + (s & 1) * a_bytes;
     const char* wbuf = wlds + ck * W_BYTES + w_lane;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    auto do_tap = [&](int t) {
       const int toff = (t / 3) * HW2 + (t % 3);
       bf16x8_t xf[NS], wf[NT];
 #pragma unroll
@@ -370,6 +373,11 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
       for (int a = 0; a < NS; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    };
+    if (p.one_tap) do_tap(4);      // (one uniform branch per step: the nine-tap body stays one straight-line block)
+    else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) do_tap(t);
     }
     if (ck != p.nchunks - 1) continue;
     int64_t opix[NS];
@@ -491,6 +499,7 @@ static void big_launch(BigParams& P, int njobs, int nt, int PX, hipStream_t s, i
 struct BigGeom {   // what big_fill_job needs, so that a job can be re-filled for another pixel tile
   const bf16_t* x; const bf16_t* w; void* y; const float* bias; const bf16_t* res;
   int B, H, W, d, Cin, ldx, Nout, ldy, ldr, Nw, Kw, act; float alpha; int out_f32, accumulate, flip;
+  int one_tap = 0;
 };
 
 template <int NT, int NS, bool RES = false>
@@ -535,6 +544,7 @@ static int stream_plan(const BigGeom& g, const float* epi_scale, StreamPlan& sp)
                       g.out_f32, g.accumulate, g.flip, PX, 1))
       continue;
     if (p.NV != 1 || p.PW != 16) continue;
+    p.one_tap = g.one_tap;
     const size_t dyn = wbytes + 2 * (size_t)p.npa * 1024;
     int occ = (int)((160 * 1024 - 2048) / (dyn + 1024));
     if (occ > 4) occ = 4;
@@ -664,7 +674,7 @@ static int big_plan_and_launch(const BigGeom* g, int njobs, hipStream_t s) {
     if (!big_fill_job(P.job[j], g[j].x, g[j].w, g[j].y, g[j].bias, g[j].res, g[j].B, g[j].H, g[j].W, g[j].d, g[j].Cin, g[j].ldx, g[j].Nout,
                       g[j].ldy, g[j].ldr, g[j].Nw, g[j].Kw, g[j].act, g[j].alpha, g[j].out_f32, g[j].accumulate, g[j].flip, best_px))
       return 0;
-  for (int j = 0; j < njobs; ++j) P.job[j].scale = g[j].flip ? nullptr : usseg_epi_scale[j];
+  for (int j = 0; j < njobs; ++j) { P.job[j].scale = g[j].flip ? nullptr : usseg_epi_scale[j]; P.job[j].one_tap = g[j].one_tap; }
   if (usseg_tap_mask.group_ch) {
     // the tile (fwd: 16*nt output channels; dgrad: one 32-channel K chunk) must lie inside one class
     const int unit = g[0].flip ? 32 : 16 * best_nt;
@@ -694,7 +704,11 @@ int usseg_try_launch_conv_big_multi(int njobs, const UssegConvJob* jobs, int fli
     if (flip)
       g[j] = {(const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, nullptr, (const bf16_t*)q.residual, d.B, d.H, d.W, d.dilation, d.Cout, d.ldy,
               d.Cin, d.ldx, q.ldr, roundup(d.Cin, 16), 9 * d.Cout, USSEG_ACT_NONE, 0.f, 0, acc, 1};
-    else
+    else if (d.ksize == 1) {     // rides along as a centre-tap-only job of the 3x3 geometry (dilation 1); its operand is the 1x1 conv's own [N][Cin]
+      g[j] = {(const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, q.bias, (const bf16_t*)q.residual, d.B, d.H, d.W, 1, d.Cin, d.ldx,
+              d.Cout, d.ldy, q.ldr, roundup(d.Cout, 16), d.Cin, d.act, d.alpha, out_f32, acc, 0};
+      g[j].one_tap = 1;
+    } else
       g[j] = {(const bf16_t*)q.x, (const bf16_t*)q.wp, q.y, q.bias, (const bf16_t*)q.residual, d.B, d.H, d.W, d.dilation, d.Cin, d.ldx,
               d.Cout, d.ldy, q.ldr, roundup(d.Cout, 16), 9 * d.Cin, d.act, d.alpha, out_f32, acc, 0};
   }

@@ -753,21 +753,24 @@ extern "C" int usseg_conv2d_dgrad(const UssegConvDesc* d, const void* dy, const 
 
 static int conv_multi(int32_t njobs, const UssegConvJob* jobs, int flip, usseg_stream_t stream) {
   USSEG_CHECK_ARG(jobs && njobs >= 1 && njobs <= 4, "conv multi: 1 <= njobs <= 4");
-  bool all3 = true;
+  bool all3 = true;     // every job a 3x3 - or, forward only, a 1x1 beside at least one 3x3 (it rides along as a centre-tap job: conv_big.hip)
+  int n3 = 0, n1 = 0;
   for (int j = 0; j < njobs; ++j) {
     int rc = check_desc(&jobs[j].desc, false);
     if (rc) return rc;
     USSEG_CHECK_ARG(jobs[j].x && jobs[j].wp && jobs[j].y, "conv multi: null pointer");
     if (flip) USSEG_CHECK_ARG(!(jobs[j].desc.flags & USSEG_OUT_F32) && jobs[j].desc.Cout % 8 == 0, "dgrad needs bf16 dy with Cout % 8 == 0");
-    all3 = all3 && jobs[j].desc.ksize == 3;
+    all3 = all3 && (jobs[j].desc.ksize == 3 || (jobs[j].desc.ksize == 1 && !flip && jobs[j].desc.dilation == 1));
+    n3 += jobs[j].desc.ksize == 3; n1 += jobs[j].desc.ksize == 1;
   }
+  all3 = all3 && n3 >= 1;
   struct ScaleGuard {   // the per-job epilogue multipliers are visible to the launchers only during this call
     ~ScaleGuard() { for (int j = 0; j < 4; ++j) usseg_epi_scale[j] = nullptr; }
   } guard;
   if (njobs > 1 && all3) {
     for (int j = 0; j < njobs; ++j) usseg_epi_scale[j] = flip ? nullptr : jobs[j].scale;
     if (usseg_try_launch_conv_big_multi(njobs, jobs, flip, (hipStream_t)stream)) return usseg_check_launch("conv_big_multi");
-    if (usseg_try_launch_conv_halo_multi(njobs, jobs, flip, (hipStream_t)stream)) return usseg_check_launch("conv_halo_multi");
+    if (n1 == 0 && usseg_try_launch_conv_halo_multi(njobs, jobs, flip, (hipStream_t)stream)) return usseg_check_launch("conv_halo_multi");
   }
   for (int j = 0; j < njobs; ++j) {
     const UssegConvJob& q = jobs[j];
