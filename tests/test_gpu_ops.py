@@ -786,6 +786,37 @@ def test_decoder_stage_multi_job_and_fused_dgrad(gen, B, H, W, Cin, q):
         assert rel(convs[j].kernel.grad, wr[j].grad) < REL_F32, j
 
 
+@pytest.mark.parametrize("B,H,W,chans", [(2, 64, 64, ((32, 32), (16, 32), (1, 16))), (1, 32, 48, ((24, 32), (32, 24), (8, 8))),
+                                         (2, 32, 32, ((64, 128), (24, 64))), (1, 16, 16, ((256, 64), (128, 128)))])
+def test_weight_gradients_of_different_channel_counts_in_one_launch(gen, B, H, W, chans):
+    """usseg_conv2d_wgrad_multi with jobs of DIFFERENT channel counts that take the same tile shape and tile count (the stem's three convs,
+    ResNest.py:39-44; a stage's conv2 and concats_2): each gradient against the fp64 oracle and against its own launch (other split-K counts:
+    fp32-level agreement, not bit equality)."""
+    from ultrasound_modeling_amd import ops
+    from ultrasound_modeling_amd.layers import Conv2D
+    holder = torch.nn.ModuleList([Conv2D(ci, co, 3) for ci, co in chans])
+    finalize(holder)
+    jobs, refs = [], []
+    for c, (ci, co) in zip(holder, chans):
+        x, dy = rnd(gen, B, H, W, ci), rnd(gen, B, H, W, co)
+        wr = torch.zeros(3, 3, ci, co, dtype=torch.float64, requires_grad=True)
+        (O.conv2d_same(x, wr, torch.zeros(co, dtype=torch.float64), 1) * dy).sum().backward()
+        refs.append(wr.grad)
+        c._x = to_dev_padded(x)
+        jobs.append(c.wgrad_job(to_dev_padded(dy)))
+    ops.conv2d_wgrad_multi(jobs)
+    torch.cuda.synchronize()
+    merged = [c.kernel.grad.clone() for c in holder]
+    for c, r in zip(holder, refs):
+        assert rel(c.kernel.grad, r) < REL_F32
+        c.kernel.grad.zero_()
+    for c, job in zip(holder, jobs):
+        ops.conv2d_wgrad_multi([job])
+    torch.cuda.synchronize()
+    for c, m in zip(holder, merged):
+        assert rel(c.kernel.grad, m) < 1e-5
+
+
 def test_deferred_finishing_matches_immediate(gen):
     """usseg_defer_begin/_end: the queued, batched finishing reductions give the same gradients as the immediate ones."""
     from ultrasound_modeling_amd import ops

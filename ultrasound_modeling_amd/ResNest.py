@@ -51,6 +51,7 @@ _FUSED_CARDINAL_BWD = os.environ.get("USSEG_FUSED_CARDINAL_BWD", "1") != "0"    
 _CARD_BWD_MAX_PX = int(os.environ.get("USSEG_CARD_BWD_MAX_PX", "32768"))
 _LN_PAIR = os.environ.get("USSEG_LN_PAIR", "1") != "0"      # shortcut norm backward + conv2_bn backward of the large stages in one launch
 _FUSED_STEM_BWD = os.environ.get("USSEG_FUSED_STEM_BWD", "1") != "0"     # stem backward-data passes fused with the norm / activation backward in front
+_STEM_WGRAD_MERGE = os.environ.get("USSEG_STEM_WGRAD_MERGE", "1") != "0"   # the stem's three weight gradients in one multi-job launch
 _FUSED_STEM = os.environ.get("USSEG_FUSED_STEM", "1") != "0"             # the stem (three convs, two norms, pool) as one launch (csrc/stem.hip)
 _MERGED_DGRAD = os.environ.get("USSEG_MERGED_DGRAD", "1") != "0"     # one backward-data GEMM for a stage's grouped 1x1 and shortcut 1x1
 
@@ -515,15 +516,25 @@ class ResNest(nn.Module):
         else:
             d = self.convtmp_2bn.backward(self.conv1_pool.backward(d), dbias=self.convtmp_2.bias.grad)
         bn1, c1, c2 = self.convtmp_1bn, self.convtmp_1, self.convtmp_2
+        # the three stem weight gradients (32x32, 16x32, 8x16 channels at full resolution: one 32x32 tile each) share ONE launch at the end of
+        # the stem's backward pass instead of three full-chip launches between its backward-data kernels (USSEG_STEM_WGRAD_MERGE=0: as before)
+        wjobs = [] if _STEM_WGRAD_MERGE else None
+        def wg(conv, dy):
+            if wjobs is None:
+                conv.backward(dy, need_dx=False, skip_bias=True)
+            else:
+                wjobs.append(conv.wgrad_job(dy))
         # :44 backwards + :41-43 backwards as ONE launch (csrc/stem.hip dgrad_actbwd_kernel): convtmp_2's backward-data pass, then the folded
         # BatchNorm + LeakyReLU backward from the stored activation; the intermediate gradient never goes to HBM
         dn = torch.empty_like(self._t1) if (_FUSED_STEM_BWD and self._fold) else None
         if dn is not None and ops.conv3_dgrad_actbwd(d, c2.wp_d, self._t1, dn, 2, a, c1.bias.grad, bn1.gamma.data, bn1.beta.data, bn1.moving_variance_p,
                                                      bn1.eps, bn1.gamma.grad, bn1.beta.grad):
-            c2.backward(d, need_dx=False, skip_bias=True)          # its weight gradient only
+            wg(c2, d)                                              # its weight gradient only
             d = dn
         else:
-            d = c2.backward(d, skip_bias=True)
+            if wjobs is not None:
+                wjobs.append(c2.wgrad_job(d))
+            d = c2.backward(d, skip_bias=True, skip_wgrad=wjobs is not None)
             if self._fold:
                 d = bn1.backward_folded(self._t1, d, ACT_LRELU, a, dbias=c1.bias.grad)
             else:
@@ -532,12 +543,17 @@ class ResNest(nn.Module):
         # result = conv1's bias gradient
         dn = torch.empty_like(self._y1) if _FUSED_STEM_BWD else None
         if dn is not None and ops.conv3_dgrad_actbwd(d, c1.wp_d, self._y1, dn, 0, KERAS_LRELU_ALPHA, self.conv1.bias.grad):
-            c1.backward(d, need_dx=False, skip_bias=True)
+            wg(c1, d)
             d = dn
         else:
-            d = c1.backward(d, skip_bias=True)
+            if wjobs is not None:
+                wjobs.append(c1.wgrad_job(d))
+            d = c1.backward(d, skip_bias=True, skip_wgrad=wjobs is not None)
             d = ops.act_bwd_colsum(self._y1, d, torch.empty_like(d), ACT_LRELU, KERAS_LRELU_ALPHA, self.conv1.bias.grad, self.conv1.cout)
-        self.conv1.backward(d, need_dx=False, skip_bias=True)
+        wg(self.conv1, d)
+        if wjobs:
+            keep = [t for job in wjobs for t in job[:2]]
+            ops.wgrad_later(lambda: ops.conv2d_wgrad_multi(wjobs), *keep)
         return None
 
     def bn_fold_jobs(self):

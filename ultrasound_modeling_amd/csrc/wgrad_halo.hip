@@ -377,16 +377,27 @@ struct WgHaloGeom {
   uint32_t tapmask = 0x1ff;
 };
 
-// Launches njobs (1..4) weight gradients of identical (B,H,W,Ma,Nb) - dilations may differ as long as the group counts match -
-// as one grid; returns 0 if the geometry does not fit (the caller then uses the per-tap kernel, one job at a time).
+// Launches njobs (1..4) weight gradients of identical (B,H,W) - dilations may differ as long as the group counts match, channel counts may
+// differ as long as the jobs take the same tile shape and the same number of tiles (the stem's three convs: 32x32, 16x32 and 8x16 channels are
+// one 32x32 tile each) - as one grid; returns 0 if the geometry does not fit (the caller then launches the jobs one at a time).
 static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t ws_floats, hipStream_t s) {
   static const int disabled = getenv("USSEG_NO_HALO") != nullptr;
   if (disabled || njobs < 1 || njobs > 4) return 0;
   WgHaloMulti P;
-  const int Ma = gm[0].Ma, Nb = gm[0].Nb;
+  const int Ma = gm[0].Ma, Nb = gm[0].Nb;     // job 0 decides the tile shape; every job must land in the same shape class with the same tile count
+  auto shape_of = [](int ma, int nb) { return (ma <= 32 && nb <= 32) ? 1 : (nb <= 16 ? 2 : (nb <= 32 ? 3 : 0)); };
+  auto tiles_of = [&](int ma, int nb) {
+    const int sh = shape_of(ma, nb), bm = sh == 1 ? 32 : 64, bn = sh == 0 ? 64 : (sh == 2 ? 16 : 32);
+    return ((ma + bm - 1) / bm) * ((nb + bn - 1) / bn);
+  };
+  int64_t slab_max = 0, slab_sum = 0;
   for (int j = 0; j < njobs; ++j) {
     const WgHaloGeom& q = gm[j];
-    if (q.Ma != Ma || q.Nb != Nb || q.B != gm[0].B || q.H != gm[0].H || q.W != gm[0].W) return 0;
+    if (q.B != gm[0].B || q.H != gm[0].H || q.W != gm[0].W) return 0;
+    if (shape_of(q.Ma, q.Nb) != shape_of(Ma, Nb) || tiles_of(q.Ma, q.Nb) != tiles_of(Ma, Nb)) return 0;
+    if ((q.Ma != Ma || q.Nb != Nb) && (usseg_tap_mask.group_ch || q.tconv_cls >= 0)) return 0;
+    slab_sum += (int64_t)9 * q.Ma * q.Nb;
+    if ((int64_t)9 * q.Ma * q.Nb > slab_max) slab_max = (int64_t)9 * q.Ma * q.Nb;
     const int d = q.d;
     if (d < 1 || q.H % d || q.W % d) return 0;
     const int Hl = q.H / d, Wl = q.W / d;
@@ -415,7 +426,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
       p.xvd = p.yvd = d; p.xvH = p.yvH = q.H; p.xvW = p.yvW = q.W; p.xva = p.xvb = p.yva = p.yvb = 0;
     }
     p.ngroups = (p.npatches + NV - 1) / NV;
-    p.ldx = q.ldx; p.lddy = q.lddy; p.Ma = Ma; p.Nb = Nb;
+    p.ldx = q.ldx; p.lddy = q.lddy; p.Ma = q.Ma; p.Nb = q.Nb;
     if (p.ngroups != P.job[0].ngroups) return 0;
     if ((int64_t)q.B * p.xvH * p.xvW * q.ldx >= (1ll << 31) || (int64_t)q.B * p.yvH * p.yvW * q.lddy >= (1ll << 31)) return 0;   // 32-bit element offsets
     if ((int64_t)q.B * p.xvH * p.xvW >= (1ll << 23) || (int64_t)q.B * p.yvH * p.yvW >= (1ll << 23) || p.npatches >= (1 << 20)) return 0;   // signed 24-bit multiplies / fdiv() in the kernel's decodes
@@ -434,12 +445,15 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   // split-K over pixel chunks: aim for ~256 workgroups (over all jobs; 512 until round 3) with >= 2 chunks each.  With a workspace every
   // split writes its own partial slab (plain stores) and the finishing kernel sums them; fp32 atomics into a 9*64*64 tile
   // from hundreds of workgroups run at the ~1.3 TB/s atomic rate and cost more than the MFMAs (no-workspace fallback only).
-  const int64_t slab = (int64_t)9 * Ma * Nb;
+  const int64_t slab = slab_max;             // per-job slabs may be smaller: the caps below are sized by the largest
   // traffic guard (rocprofv3 FETCH/WRITE_SIZE showed the partial slabs costing ~2 GB/step): keep the slabs written and
   // re-read within 2x the bytes of the operands themselves (swept 1/2/3/4/8/16 with the multi-job launches and the
   // register prefetch in place: 2x is the minimum, 4.95 vs 5.05 ms/step at 8x; sending the deep layers back to the
   // per-tap kernel was slower).
-  const int64_t in_bytes = (int64_t)gm[0].B * gm[0].H * gm[0].W * (Ma + Nb) * 2, slab_bytes = slab * 4;
+  int64_t in_bytes = 0;
+  for (int j = 0; j < njobs; ++j) in_bytes += (int64_t)gm[j].B * gm[j].H * gm[j].W * (gm[j].Ma + gm[j].Nb) * 2;
+  in_bytes /= njobs;
+  const int64_t slab_bytes = slab * 4;
   static const int wg_target = getenv("USSEG_WG_TARGET") ? atoi(getenv("USSEG_WG_TARGET")) : 256;   // round 3 sweep (128 / 192 / 256 / 384 / 512 / 768): 256 is -25 us on Arch B (half the slabs for wgrad_finish), neutral on A / T
   int splits = (wg_target + tiles * njobs - 1) / (tiles * njobs);
   int max_splits = (ngroups + 1) / 2;
@@ -447,7 +461,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   const int64_t traffic_cap = slab_cap * in_bytes / slab_bytes < 4 ? 4 : slab_cap * in_bytes / slab_bytes;
   if (max_splits > traffic_cap) max_splits = (int)traffic_cap;
   if (!ws) max_splits = (ngroups + 15) / 16;
-  else if ((int64_t)max_splits * slab * njobs > ws_floats) max_splits = (int)(ws_floats / (slab * njobs));
+  else if ((int64_t)max_splits * slab_sum > ws_floats) max_splits = (int)(ws_floats / slab_sum);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   {
@@ -474,14 +488,18 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   bool mapped = false;
   for (int j = 0; j < njobs; ++j) mapped = mapped || gm[j].map.nblocks;
   // a mapped destination is scattered by the finishing kernel, so it always goes through a slab
-  const bool use_ws = ws && (splits > 1 || mapped) && (int64_t)splits * slab * njobs <= ws_floats;
+  const bool use_ws = ws && (splits > 1 || mapped) && (int64_t)splits * slab_sum <= ws_floats;
   if (mapped && !use_ws) return 0;
   const int gpb = (ngroups + splits - 1) / splits;
   splits = (ngroups + gpb - 1) / gpb;
-  for (int j = 0; j < njobs; ++j) {
-    P.job[j].ntiles_n = ntn;
-    P.job[j].groups_per_block = gpb;
-    P.job[j].ws = use_ws ? ws + (int64_t)j * splits * slab : nullptr;
+  {
+    int64_t off = 0;
+    for (int j = 0; j < njobs; ++j) {
+      P.job[j].ntiles_n = (gm[j].Nb + bn - 1) / bn;
+      P.job[j].groups_per_block = gpb;
+      P.job[j].ws = use_ws ? ws + off : nullptr;
+      off += (int64_t)splits * 9 * gm[j].Ma * gm[j].Nb;
+    }
   }
   const bool masked = usseg_tap_mask.group_ch != 0 || gm[0].tconv_cls >= 0;
   if (usseg_tap_mask.group_ch) {
@@ -512,7 +530,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
     else { if (masked) hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, false, 1, true>), grid, dim3(256), 0, s, P); else hipLaunchKernelGGL((wgrad_halo_kernel<2, 2, 2, false, 1, false>), grid, dim3(256), 0, s, P); }
   }
   if (use_ws)
-    for (int j = 0; j < njobs; ++j) usseg_launch_wgrad_finish(P.job[j].ws, splits, slab, gm[j].out, gm[j].map, Ma, Nb, s);
+    for (int j = 0; j < njobs; ++j) usseg_launch_wgrad_finish(P.job[j].ws, splits, (int64_t)9 * gm[j].Ma * gm[j].Nb, gm[j].out, gm[j].map, gm[j].Ma, gm[j].Nb, s);
   usseg_prof_stop(2, slot, s);
   return 1;
 }
