@@ -42,6 +42,11 @@ struct IgemmParams {
   int16_t cls_ntaps[4];
   // batched GEMM (attention): blockIdx.z = b1*nb2 + b2 selects operand bases x + b1*xs1 + b2*xs2 etc. (elements)
   int32_t nb2, nbatch;
+  // LDS-DMA kernels: workgroups go to the 8 XCDs round-robin in dispatch order (x = pixel tile fastest), so the channel tiles / parity classes
+  // of ONE pixel tile - which stage the same activation rows - ran in different XCDs and each pulled those rows through HBM / MALL again (the
+  // dense layers of the Swin / ViT configurations: 2-4 channel tiles per token tile).  Remapped, XCD c owns a contiguous run of the
+  // (pixel tile, channel tile, class) items in class- and channel-fastest order (see WgradParams::xcd_remap).
+  int32_t xcd_remap;
   int64_t xs1, xs2, ws1, ws2, ys1, ys2;
 };
 
@@ -246,17 +251,28 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
     s_tap4[tid][2] = (dy * p.Wi + dx) * p.ldx + p.tap_c[tid];
     s_tap4[tid][3] = p.tap_w[tid] * p.cpt * 8;
   }
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  int bx = blockIdx.x, by = blockIdx.y, bzz = blockIdx.z;
+  if (p.xcd_remap) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+    const int L = bx + gx * (by + gy * bzz);
+    const int c = L & 7, q8 = total >> 3, r8 = total & 7;
+    const int item = c * q8 + (c < r8 ? c : r8) + (L >> 3);
+    const int u = __builtin_amdgcn_readfirstlane(fdiv(item, fdiv_rcp(gz)));      // (remapped grids are below 2^20 workgroups: launcher)
+    bzz = item - u * gz;
+    bx = __builtin_amdgcn_readfirstlane(fdiv(u, fdiv_rcp(gy)));
+    by = u - bx * gy;
+  }
+  const int64_t m0 = (int64_t)bx * BM;
+  const int n0 = by * BN;
   const int HWg = p.Hg * p.Wg;
   const float r_hw = fdiv_rcp1(HWg), r_w = fdiv_rcp1(p.Wg);   // pixel decodes: fdivmod_px (common.h), M < 2^23 by the launcher
   // Conv2DTranspose forward: blockIdx.z = output-parity class, which owns tap-table entries [4c, 4c+4) and its own output pixels
-  const int cls = p.cls_mode ? (int)blockIdx.z : 0;
+  const int cls = p.cls_mode ? bzz : 0;
   const int tbase = cls * 4;
   const int ntaps = p.cls_mode ? (int)p.cls_ntaps[cls] : p.ntaps;
   const int oay = p.cls_mode ? (cls >> 1) : p.oay, oax = p.cls_mode ? (cls & 1) : p.oax;
   // batched GEMM (attention): blockIdx.z = b1*nb2 + b2 selects the operand bases (never together with the parity classes)
-  const int bz = (!p.cls_mode && p.nb2 > 0) ? (int)blockIdx.z : 0;
+  const int bz = (!p.cls_mode && p.nb2 > 0) ? bzz : 0;
   const int bz1 = p.nb2 > 0 ? bz / p.nb2 : 0, bz2 = p.nb2 > 0 ? bz - bz1 * p.nb2 : 0;
   const int64_t ybatch = bz1 * p.ys1 + bz2 * p.ys2;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + bz1 * p.xs1 + bz2 * p.xs2), 0, 0x7fffffff, 0x00020000);
@@ -415,12 +431,23 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
     s_tap4[tid][2] = (dy * p.Wi + dx) * p.ldx + p.tap_c[tid];
     s_tap4[tid][3] = p.tap_w[tid] * p.cpt * 8;
   }
-  const int n0 = blockIdx.y * BN;
+  int bx = blockIdx.x, by = blockIdx.y, bzz = blockIdx.z;
+  if (p.xcd_remap) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+    const int L = bx + gx * (by + gy * bzz);
+    const int c = L & 7, q8 = total >> 3, r8 = total & 7;
+    const int item = c * q8 + (c < r8 ? c : r8) + (L >> 3);
+    const int u = __builtin_amdgcn_readfirstlane(fdiv(item, fdiv_rcp(gz)));      // (remapped grids are below 2^20 workgroups: launcher)
+    bzz = item - u * gz;
+    bx = __builtin_amdgcn_readfirstlane(fdiv(u, fdiv_rcp(gy)));
+    by = u - bx * gy;
+  }
+  const int n0 = by * BN;
   const int HWg = p.Hg * p.Wg;
   const float r_hw = fdiv_rcp1(HWg), r_w = fdiv_rcp1(p.Wg);   // pixel decodes: fdivmod_px (common.h), M < 2^23 by the launcher
   const int ntaps = p.ntaps;
   const int ntile = (int)((p.M + BM - 1) / BM);
-  const int my_tiles = ((int)blockIdx.x < ntile) ? (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int my_tiles = (bx < ntile) ? (ntile - bx + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   if (my_tiles == 0) return;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
   int abase[A_IT], py[A_IT], px[A_IT];
   bool pv[A_IT];
   auto decode_rows = [&](int tile_no) {
-    const int64_t m0 = ((int64_t)blockIdx.x + (int64_t)tile_no * gridDim.x) * BM;
+    const int64_t m0 = ((int64_t)bx + (int64_t)tile_no * gridDim.x) * BM;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int64_t m = m0 + 8 * (wv + 4 * it) + lrow;
@@ -544,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_persist_kernel(const IgemmPa
     if (++c_ks < nks) continue;
     c_ks = 0;
     // ---- epilogue of this tile: no loads (bias in registers), the stores fly under the next tile's steps
-    const int64_t m0 = ((int64_t)blockIdx.x + (int64_t)c_tile * gridDim.x) * BM;
+    const int64_t m0 = ((int64_t)bx + (int64_t)c_tile * gridDim.x) * BM;
     ++c_tile;
     int64_t opix[2];
     bool ovalid[2];
@@ -587,7 +614,8 @@ static void igemm_dma_launch_t(const IgemmParams& p, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((igemm_dma_kernel<NT, NSTAGE>), grid, dim3(256), dyn, s, p);
 }
 
-static int launch_igemm(const IgemmParams& p, hipStream_t s) {
+static int launch_igemm(const IgemmParams& p_in, hipStream_t s) {
+  IgemmParams p = p_in;
   if (p.M <= 0) return USSEG_OK;
   dim3 block(256);
   int64_t gx = cdiv64(p.M, 128);
@@ -613,7 +641,13 @@ static int launch_igemm(const IgemmParams& p, hipStream_t s) {
     static const int dma_min = getenv("USSEG_IGEMM_DMA_MIN") ? atoi(getenv("USSEG_IGEMM_DMA_MIN")) : 4;
     static const int dma_batched = getenv("USSEG_IGEMM_DMA_BATCHED") ? atoi(getenv("USSEG_IGEMM_DMA_BATCHED")) : 1;
     const bool bat_ok = p.nb2 <= 0 || (dma_batched && !p.cls_mode && (p.xs1 | p.xs2 | p.ws1 | p.ws2) % 8 == 0);   // 16-byte aligned batch bases
+    static const int xcd_env = getenv("USSEG_IGEMM_XCD") ? atoi(getenv("USSEG_IGEMM_XCD")) : 1;
+    p.xcd_remap = 0;
     if (dma && bat_ok && k_chunks >= dma_min && fits) {
+      // activation-heavy launches only (pixels >= 16 x output channels: the operand worth sharing is the activation tile).  Measured per
+      // configuration (same-box pairs): Arch A 6.71 / 6.75 -> 6.54 / 6.61 ms, cfg5 10.54 / 10.51 -> 10.41 / 10.44, Arch B neutral; on cfg4's token
+      // GEMMs (8192 tokens x 512-2048 channels, weight-heavy) it cost 0.5 %, hence the rule
+      p.xcd_remap = xcd_env && p.nb2 <= 0 && (int64_t)gx * gy * gz < (1ll << 20) && (int64_t)gy * gz > 1 && (xcd_env > 1 || p.M >= 16 * (int64_t)p.Nout);
       // short K loops with several pixel tiles per resident workgroup slot: the persistent form
       static const int persist = getenv("USSEG_IGEMM_PERSIST") ? atoi(getenv("USSEG_IGEMM_PERSIST")) : 1;
       const int nks = (p.ntaps * p.cpt + 7) / 8;
