@@ -374,7 +374,11 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const BigParams P, 
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
     };
-    if (p.one_tap) do_tap(4);      // (one uniform branch per step: the nine-tap body stays one straight-line block)
+    if constexpr (RES || NT == 4) {   // (never a ride-along 1x1 - residual jobs and 64-channel tiles go elsewhere, stream_plan -: no branch here; with it the
+                                      //  64-channel, 256-pixel residual variant spilled 92 registers and the stage-1 concats_2 launch went from 34 to 49 us)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) do_tap(t);
+    } else if (p.one_tap) do_tap(4);      // (one uniform branch per step: the nine-tap body stays one straight-line block)
     else {
 #pragma unroll
       for (int t = 0; t < 9; ++t) do_tap(t);
@@ -544,6 +548,7 @@ static int stream_plan(const BigGeom& g, const float* epi_scale, StreamPlan& sp)
                       g.out_f32, g.accumulate, g.flip, PX, 1))
       continue;
     if (p.NV != 1 || p.PW != 16) continue;
+    if (g.one_tap && (nt == 4 || g.res)) return 0;      // (those instantiations carry no centre-tap path: conv_big takes the launch)
     p.one_tap = g.one_tap;
     const size_t dyn = wbytes + 2 * (size_t)p.npa * 1024;
     int occ = (int)((160 * 1024 - 2048) / (dyn + 1024));
