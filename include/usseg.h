@@ -129,8 +129,10 @@ int usseg_conv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, const void*
 int usseg_tconv2d_wgrad_mapped(const UssegConvDesc* d, const void* x, const void* dy, const UssegWgradDst* dst, float* ws,
                                int64_t ws_floats, usseg_stream_t stream);
 
-/* Several independent 3x3 weight gradients of identical shape in one launch (the DecoderBlock's dilation branches): same
- * semantics as usseg_conv2d_wgrad / usseg_conv2d_wgrad_mapped per job (dst NULL: accumulate into dw; dst set: dw ignored). */
+/* Several independent 3x3 weight gradients in one launch (the DecoderBlock's dilation branches; the stem's three convs, ResNest.py:39-44): same
+ * semantics as usseg_conv2d_wgrad / usseg_conv2d_wgrad_mapped per job (dst NULL: accumulate into dw; dst set: dw ignored).  The jobs share one
+ * grid when they have the same (B, H, W), the same number of 128-pixel groups and - channel counts may differ - the same tile shape and tile
+ * count of the halo kernel; otherwise they are launched one after the other. */
 typedef struct UssegWgradJob {
   UssegConvDesc desc;
   const void* x;
@@ -155,7 +157,9 @@ int usseg_defer_end(usseg_stream_t stream);
  * (Decoder.py:14-25,39-50: the conv2_x / conv3_x / conv4_x layers read the same input and write disjoint channel slices of the
  * concatenated output, Decoder.py:67-75,79-87).  Semantics = usseg_conv2d_fwd / usseg_conv2d_dgrad called once per job
  * in order; the jobs must not depend on each other (disjoint outputs).  1 <= njobs <= 4.  Jobs that cannot share a
- * grid are launched one after the other. */
+ * grid are launched one after the other.  Forward only: a 1x1 job (ksize 1, dilation 1: the block's conv1_x, Decoder.py:11-13) beside at
+ * least one 3x3 job on the same input rides in their launch as a centre-tap-only job of the 3x3 geometry (its wp is the 1x1 conv's own
+ * [N][Cin] operand). */
 typedef struct UssegConvJob {
   UssegConvDesc desc;
   const void* x;        /* fwd: input x;  dgrad: dy */
