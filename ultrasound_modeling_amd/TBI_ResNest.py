@@ -29,6 +29,7 @@ from .layers import (KERAS_BN_EPS, KERAS_ELU_ALPHA, AveragePooling2D, BatchNorma
 from .ops import ACT_ELU, ACT_NONE, ACT_RELU, BF16, roundup
 from .step import TrainStepDriver
 
+_STEM_WGRAD_MERGE = os.environ.get("USSEG_STEM_WGRAD_MERGE", "1") != "0"   # the stem's three weight gradients in one multi-job launch (as ResNest.py's)
 _STAGE_LAZY = os.environ.get("USSEG_STAGE_LAZY", "1") != "0"    # per-stage lazy weight gradients (ops.lazy_wgrads) in the backward pass: -1.5 %
 
 
@@ -450,12 +451,20 @@ class _ResModel(nn.Module):
             d = g("conv2_1_2bn").backward_pool(d, dbias=g("conv2_1_2").bias.grad)
         else:
             d = g("conv2_1_2bn").backward(self._pools[0].backward(d), dbias=g("conv2_1_2").bias.grad)
-        d = g("conv2_1_2").backward(d, skip_bias=True)
+        # the three stem weight gradients (32x32, 16x32, 8x16 channels: one 32x32 tile each) share one launch at the end (as in ResNest.py's stem)
+        wjobs = [g("conv2_1_2").wgrad_job(d)]
+        d = g("conv2_1_2").backward(d, skip_bias=True, skip_wgrad=True)
         # ELU' on the stored pre-activations; the same pass sums its output over the pixels = the conv's bias gradient
         d = ops.act_bwd_colsum(self._r2, d, torch.empty_like(d), ACT_ELU, a, g("conv2_1_1").bias.grad, g("conv2_1_1").cout)
-        d = g("conv2_1_1").backward(d, skip_bias=True)
+        wjobs.append(g("conv2_1_1").wgrad_job(d))
+        d = g("conv2_1_1").backward(d, skip_bias=True, skip_wgrad=True)
         d = ops.act_bwd_colsum(self._r1, d, torch.empty_like(d), ACT_ELU, a, g("Conv1").bias.grad, g("Conv1").cout)
-        g("Conv1").backward(d, need_dx=False, skip_bias=True)
+        wjobs.append(g("Conv1").wgrad_job(d))
+        keep = [t for job in wjobs for t in job[:2]]
+        if _STEM_WGRAD_MERGE:
+            ops.wgrad_later(lambda: ops.conv2d_wgrad_multi(wjobs), *keep)
+        else:
+            ops.wgrad_later(lambda: [ops.conv2d_wgrad_multi([j]) for j in wjobs], *keep)
 
     @staticmethod
     def _add(a, b):
