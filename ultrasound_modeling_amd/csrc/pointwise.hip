@@ -764,14 +764,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* a, int64_t M,
   float s[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; s2[j] = 0.f; }
-  const int64_t ppb = 4 * ppw;
-  for (int64_t base = (int64_t)blockIdx.x * ppb; base < M; base += (int64_t)gridDim.x * ppb) {
-    int64_t m = base + wv * ppw + slot;
-    if (chunk_ok && m < M) {
-      float v[8];
-      unpack8(*reinterpret_cast<const uint4*>(a + m * ld + chunk * 8), v);
+  const int64_t ppb = 4 * ppw, stride = (int64_t)gridDim.x * ppb;
+  // four rows per lane and trip, loaded at clamped addresses before the first use (one load per trip was a chain of 8 dependent HBM latencies)
+  for (int64_t base = (int64_t)blockIdx.x * ppb; base < M; base += 4 * stride) {
+    uint4 raw[4];
+    float okf[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s[j] += v[j]; if (MODE == 1) s2[j] += v[j] * v[j]; }
+    for (int u = 0; u < 4; ++u) {
+      const int64_t m = base + u * stride + wv * ppw + slot;
+      const bool ok = chunk_ok && m < M;
+      okf[u] = ok ? 1.f : 0.f;
+      raw[u] = *reinterpret_cast<const uint4*>(a + (ok ? m : 0) * ld + (chunk_ok ? chunk * 8 : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
+      unpack8(raw[u], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += okf[u] * v[j]; if (MODE == 1) s2[j] += okf[u] * v[j] * v[j]; }
     }
   }
   float* row = ws + (int64_t)blockIdx.x * (MODE + 1) * Cp;
