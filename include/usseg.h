@@ -605,6 +605,9 @@ int usseg_colsum(const void* dy, int64_t M, int32_t C, int32_t ld, float* db, fl
  *        Keras Adam with bias-corrected lr_t (host-computed from the device step counter is avoided: the caller
  *        passes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) through a device scalar so a captured graph can be replayed). */
 int usseg_sumsq(const float* g, int64_t n, float* out, usseg_stream_t stream);
+/* out[0] = sum of n floats through a USSEG_ACC_FLOATS accumulator (see above): the scalar of TBI_ResNest.py's [H,W] loss map
+ * (my_loss_cat, :234-248) that the mirrored step reduces (MainParallel.py:131-134) - reproducible, no framework reduction. */
+int usseg_sum_f32(const float* x, int64_t n, float* out, usseg_stream_t stream);
 /* the same launch also advances the optimiser's device step counter (usseg_adam_advance) in its last workgroup */
 int usseg_sumsq_advance(const float* g, int64_t n, float* out, int32_t* step, float* lr_t_dev, float lr, float beta1, float beta2,
                         usseg_stream_t stream);

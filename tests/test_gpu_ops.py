@@ -920,6 +920,29 @@ def test_accuracy_metric(gen, M, C):
     assert a2.item() == a.item()
 
 
+@pytest.mark.parametrize("M,C", [(300000, 3), (4099, 3)])
+def test_accuracy_metric_four_pixels_per_trip(gen, M, C):
+    """The three-class fast loop of usseg_accuracy (four pixels per thread and trip) with ties and a ragged tail."""
+    from ultrasound_modeling_amd import ops
+    probs = (torch.randint(0, 4, (M, C), generator=gen).float() / 4)        # many exact ties
+    y = torch.nn.functional.one_hot(torch.randint(0, C, (M,), generator=gen), C).float()
+    acc = torch.zeros(ops.ACC_FLOATS, device=DEV)
+    a = ops.accuracy(probs.to(DEV), y.to(DEV), acc)
+    ref = (probs.argmax(-1) == y.argmax(-1)).double().mean()
+    assert abs(a.item() - ref.item()) < 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 255, 65536, 1000003])
+def test_ordered_sum_of_a_loss_map(gen, n):
+    """usseg_sum_f32 (the scalar of TBI_ResNest.py's [H,W] loss map): against the float64 sum, reusable accumulator, same bits on every call."""
+    from ultrasound_modeling_amd import ops
+    x = (torch.rand(n, generator=gen) * 3 - 1).float()
+    acc = torch.zeros(ops.ACC_FLOATS, device=DEV)
+    a = ops.sum_f32(x.to(DEV), acc).item()
+    assert abs(a - x.double().sum().item()) <= 2e-6 * max(1.0, x.abs().double().sum().item())
+    assert ops.sum_f32(x.to(DEV), acc).item() == a
+
+
 # ------------------------------------------------------------------------------------------------ fused tile kernels vs the launches they replace
 @pytest.mark.parametrize("cin,cv11,cvkk,oc", [(32, 3, 10, 64), (64, 7, 21, 128), (128, 14, 42, 256), (256, 28, 85, 512)])
 @pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 8, 8), (3, 16, 5), (2, 4, 4), (1, 20, 36)])

@@ -631,9 +631,15 @@ class ResNest(TrainStepDriver):
     def eval_step(self, x, y):
         """MirroredTrainer-compatible evaluation: -> (sum of the loss map, probs)."""
         loss_map, _, probs = self.step(x, y, train=False)
-        return loss_map.sum(), probs
+        return self._loss_total(loss_map), probs
 
     def train_step(self, x, y):
         """MirroredTrainer-compatible alias: -> (sum of the loss map, probs)."""
         loss_map, _, probs = self.step(x, y, train=True)
-        return loss_map.sum(), probs
+        return self._loss_total(loss_map), probs
+
+    def _loss_total(self, loss_map):
+        """The scalar the mirrored step reduces (MainParallel.py:131-134): the sum of the [H,W] loss map, by the library's ordered sum."""
+        if getattr(self, "_lsum", None) is None or self._lsum.device != loss_map.device:
+            self._lsum = torch.zeros(ops.ACC_FLOATS, dtype=torch.float32, device=loss_map.device)
+        return ops.sum_f32(loss_map.contiguous().reshape(-1), self._lsum)

@@ -192,6 +192,7 @@ _PROTOS = {
     "usseg_token_mean_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "usseg_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "usseg_sumsq": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "usseg_sum_f32": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "usseg_sumsq_advance": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),
     "usseg_reinject_hidden": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "usseg_adam_clip_step": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_f32, c_f32, c_f32, c_vp]),

@@ -1002,7 +1002,24 @@ extern "C" int usseg_loss_from_probs(const UssegLossDesc* d, const float* probs,
 __global__ __launch_bounds__(256) void accuracy_kernel(const float* probs, const float* y, int64_t M, int C, float inv_m, float* acc) {
   __shared__ float red[4];
   float cnt = 0.f;
-  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (C == 3) {      // the reference's three classes: four pixels per thread and trip, all 24 loads issued before the first compare
+    for (; m + 3 * stride < M; m += 4 * stride) {
+      float pv[4][3], tv[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pv[u][c] = probs[(m + u * stride) * 3 + c]; tv[u][c] = y[(m + u * stride) * 3 + c]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ip = pv[u][1] > pv[u][0] ? (pv[u][2] > pv[u][1] ? 2 : 1) : (pv[u][2] > pv[u][0] ? 2 : 0);   // FIRST maximum, as the loop below
+        const int it = tv[u][1] > tv[u][0] ? (tv[u][2] > tv[u][1] ? 2 : 1) : (tv[u][2] > tv[u][0] ? 2 : 0);
+        cnt += ip == it ? 1.f : 0.f;
+      }
+    }
+  }
+  for (; m < M; m += stride) {
     const float* p = probs + m * C;
     const float* t = y + m * C;
     int ip = 0, it = 0;
@@ -1042,6 +1059,32 @@ extern "C" int usseg_loss_cat_scale(const float* y_true, int32_t B, int32_t HW, 
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(loss_cat_scale_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y_true, B, HW, C, scale);
   return usseg_check_launch("loss_cat_scale");
+}
+
+// out[0] = sum of n floats, workgroup partials added in workgroup order (grid_ordered_sum): the scalar of a loss MAP (TBI_ResNest.py:234-248
+// returns [H,W]; MainParallel.py:131-134 reduces a scalar) without a framework reduction on the step path
+__global__ __launch_bounds__(256) void sum_f32_kernel(const float* x, int64_t n, float* out) {
+  __shared__ float red[4];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const float a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+    s += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; i < n; i += stride) s += x[i];
+  s = (s + s1) + (s2 + s3);
+  for (int msk = 32; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  grid_ordered_sum((red[0] + red[1]) + (red[2] + red[3]), out, gridDim.x);
+}
+extern "C" int usseg_sum_f32(const float* x, int64_t n, float* out, usseg_stream_t stream) {
+  USSEG_CHECK_ARG(x && out && n >= 0, "sum_f32: bad arguments");
+  int64_t g = cdiv64(n > 0 ? n : 1, 256 * 4);
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(sum_f32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  return usseg_check_launch("sum_f32");
 }
 
 // ------------------------------------------------------------------------------------------ optimiser

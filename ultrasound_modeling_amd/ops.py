@@ -710,6 +710,13 @@ def sumsq(g: torch.Tensor, out: torch.Tensor):
     L.check(L.load().usseg_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "sumsq")
 
 
+def sum_f32(x: torch.Tensor, out: torch.Tensor):
+    """out[0] = sum(x) (fp32, contiguous) through an ACC_FLOATS accumulator (zeroed once): fixed-order, no framework reduction."""
+    assert out.numel() >= ACC_FLOATS and x.dtype == torch.float32 and x.is_contiguous()
+    L.check(L.load().usseg_sum_f32(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sum_f32")
+    return out[0]
+
+
 def sumsq_advance(g: torch.Tensor, out: torch.Tensor, step_dev, lr_t_dev, lr, b1, b2):
     """sumsq + adam_advance in ONE launch (the last workgroup of the ordered sum moves the step counter on)."""
     assert out.numel() >= ACC_FLOATS
