@@ -20,8 +20,10 @@ struct RJob {
 };
 struct RBatch {
   int32_t njobs, pad;
-  RJob job[63];      // 63 x 64 B + 8 B: the 4 KB of kernel arguments
+  int32_t start[60];   // first flat workgroup id of each job (start[njobs] = total): no empty workgroups in the grid (as WBatch)
+  RJob job[59];        // 59 x 64 B + 248 B: inside the 4 KB of kernel arguments
 };
+static_assert(sizeof(RBatch) <= 4096, "RBatch must fit the kernel-argument segment");
 
 // workgroup = 16 outputs x 16 row slices: the nb partial rows of an output are summed by 16 threads in parallel
 // (a serial walk over 512 rows is a 512-deep chain of dependent loads: 45 us; this form is ~3 us)
@@ -39,8 +41,13 @@ __device__ __forceinline__ void reduce_finish_body(const RJob& q, int bx, int nb
       g = i / (q.C * q.K);
       const float* src = q.ws + ((int64_t)g * q.nb * q.K + k) * q.Cp + c;
       const int64_t rs = (int64_t)q.K * q.Cp;
-      float s1 = 0.f, s2 = 0.f, s3 = 0.f;    // four independent chains: the loads of a slice are in flight together
-      int j = sl;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;    // independent chains: the loads of a slice are in flight together (eight per trip while the rows last:
+      int j = sl;                            //  the 1024 partial rows of a full-chip norm backward were 16 dependent trips of four)
+      for (; j + 112 < q.nb; j += 128) {
+        const float a0 = src[j * rs], a1 = src[(j + 16) * rs], a2 = src[(j + 32) * rs], a3 = src[(j + 48) * rs];
+        const float a4 = src[(j + 64) * rs], a5 = src[(j + 80) * rs], a6 = src[(j + 96) * rs], a7 = src[(j + 112) * rs];
+        s += a0; s1 += a1; s2 += a2; s3 += a3; s += a4; s1 += a5; s2 += a6; s3 += a7;
+      }
       for (; j + 48 < q.nb; j += 64) {
         s += src[j * rs]; s1 += src[(j + 16) * rs]; s2 += src[(j + 32) * rs]; s3 += src[(j + 48) * rs];
       }
@@ -60,10 +67,13 @@ __device__ __forceinline__ void reduce_finish_body(const RJob& q, int bx, int nb
   }
 }
 __global__ __launch_bounds__(256) void reduce_finish_kernel(const RJob q) { reduce_finish_body(q, blockIdx.x, gridDim.x); }
+// flat grid: a (max blocks x jobs) grid of the step's ~50 jobs was 36 850 workgroups of which ~4 000 had work (one job has 670 blocks, most
+// have under 100) - dispatching the empty ones was most of the launch's 21 us
 __global__ __launch_bounds__(256) void reduce_finish_batched_kernel(const RBatch b) {
-  const RJob& q = b.job[blockIdx.y];
-  if ((int)blockIdx.x >= q.nblocks) return;
-  reduce_finish_body(q, blockIdx.x, q.nblocks);
+  int j = 0;
+  while (j + 1 < b.njobs && (int)blockIdx.x >= b.start[j + 1]) ++j;
+  const RJob& q = b.job[j];
+  reduce_finish_body(q, blockIdx.x - b.start[j], q.nblocks);
 }
 
 // ------------------------------------------------------------------------------------------ split-K slabs of a weight gradient
@@ -182,13 +192,15 @@ static void flush_reduce(DeferCtx& c) {
   size_t i = 0;
   while (i < c.rj.size()) {
     RBatch b = {};
-    int gx = 1;
-    while (i < c.rj.size() && b.njobs < 63 && !rjob_shares_dst(b, c.rj[i])) {
+    int total = 0;
+    while (i < c.rj.size() && b.njobs < 59 && !rjob_shares_dst(b, c.rj[i])) {
       b.job[b.njobs] = c.rj[i++];
-      if (b.job[b.njobs].nblocks > gx) gx = b.job[b.njobs].nblocks;
+      b.start[b.njobs] = total;
+      total += b.job[b.njobs].nblocks;
       ++b.njobs;
     }
-    hipLaunchKernelGGL(reduce_finish_batched_kernel, dim3(gx, b.njobs), dim3(256), 0, c.s, b);
+    b.start[b.njobs] = total;
+    hipLaunchKernelGGL(reduce_finish_batched_kernel, dim3(total), dim3(256), 0, c.s, b);
   }
   c.rj.clear();
   c.rused = 0;
