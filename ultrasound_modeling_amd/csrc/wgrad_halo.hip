@@ -509,7 +509,7 @@ static int wgrad_halo_launch(const WgHaloGeom* gm, int njobs, float* ws, int64_t
   }
   const dim3 grid(splits, tiles, njobs);
   static const int xcd_env = getenv("USSEG_WGHALO_XCD") ? atoi(getenv("USSEG_WGHALO_XCD")) : 1;
-  P.xcd_remap = xcd_env && tiles * njobs > 1;
+  P.xcd_remap = xcd_env && tiles * njobs > 1 && (int64_t)splits * tiles * njobs < (1ll << 20);     // (fdiv() in the remap)
   static const int dbg = getenv("USSEG_WGRAD_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[wgrad_halo] B %d H %d W %d d %d Ma %d Nb %d jobs %d shape %d tiles %d ngroups %d splits %d gpb %d max_splits %d traffic_cap %lld slab_MB %.2f in_MB %.2f\n",
                    gm[0].B, gm[0].H, gm[0].W, gm[0].d, Ma, Nb, njobs, shape, tiles, ngroups, splits, gpb, max_splits, (long long)traffic_cap, slab_bytes / 1e6, in_bytes / 1e6);
