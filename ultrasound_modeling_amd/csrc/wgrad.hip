@@ -160,7 +160,7 @@ typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
 // operand) that follows: every K step then waited for the piece it had just issued, DMA and MFMAs strictly in sequence.  The
 // kernel orders the ring itself (vmcnt(pieces of the younger steps) + barrier at the top of a step), so the compiler must not
 // see the DMA at all.  No other vector memory LOAD may be added to the loop of a kernel that uses this: the compiler's own vmcnt
-// bookkeeping does not count these pieces.
+// bookkeeping does not count these pieces (the build checks it: tools/check_dma_loops.py).
 typedef int wg_i32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ wg_i32x4_t wg_rsrc(const void* base) {   // stride 0, no range limit, raw dword addressing: as make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000)
   const uint64_t a = (uint64_t)base;
