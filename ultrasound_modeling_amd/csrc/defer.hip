@@ -70,8 +70,11 @@ __global__ __launch_bounds__(256) void reduce_finish_kernel(const RJob q) { redu
 // flat grid: a (max blocks x jobs) grid of the step's ~50 jobs was 36 850 workgroups of which ~4 000 had work (one job has 670 blocks, most
 // have under 100) - dispatching the empty ones was most of the launch's 21 us
 __global__ __launch_bounds__(256) void reduce_finish_batched_kernel(const RBatch b) {
-  int j = 0;
-  while (j + 1 < b.njobs && (int)blockIdx.x >= b.start[j + 1]) ++j;
+  // this workgroup's job: lane i holds start[i + 1]; the jobs whose range ends at or before this workgroup form a prefix (one vector load and a
+  // ballot instead of a walk of up to 58 dependent scalar loads - 2-3 us for the workgroups of the last jobs)
+  const int lane = threadIdx.x & 63;
+  const int nxt = lane + 1 < b.njobs ? b.start[lane + 1] : 0x7fffffff;
+  const int j = __builtin_amdgcn_readfirstlane(__popcll(__ballot((int)blockIdx.x >= nxt)));
   const RJob& q = b.job[j];
   reduce_finish_body(q, blockIdx.x - b.start[j], q.nblocks);
 }
@@ -143,8 +146,9 @@ __device__ __forceinline__ void wgrad_finish_body(const WJob& q, int bx) {
 }
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WJob q) { wgrad_finish_body(q, blockIdx.x); }
 __global__ __launch_bounds__(256) void wgrad_finish_batched_kernel(const WBatch b) {
-  int j = 0;
-  while (j + 1 < b.njobs && (int)blockIdx.x >= b.start[j + 1]) ++j;
+  const int lane = threadIdx.x & 63;      // (job lookup as in reduce_finish_batched_kernel)
+  const int nxt = lane + 1 < b.njobs ? b.start[lane + 1 < 16 ? lane + 1 : 15] : 0x7fffffff;
+  const int j = __builtin_amdgcn_readfirstlane(__popcll(__ballot((int)blockIdx.x >= nxt)));
   wgrad_finish_body(b.job[j], blockIdx.x - b.start[j]);
 }
 
